@@ -1,0 +1,130 @@
+// capi.hip -- library lifecycle + pattern-table accessors of the C-ABI (include/gomoku_hip.h).
+#include <cstring>
+#include <string>
+
+#include "capi_common.h"
+
+namespace gmk {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+
+DeviceState& device_state() {
+    static DeviceState s;
+    return s;
+}
+
+}  // namespace gmk
+
+using gmk::device_state;
+using gmk::production_automaton;
+
+extern "C" const char* gmk_last_error(void) { return gmk::g_error; }
+
+extern "C" int gmk_init(int device) {
+    gmk::DeviceState& st = device_state();
+    if (st.ready) return GMK_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        gmk::set_error("no HIP device is visible: libgomoku_hip has no CPU fallback");
+        return GMK_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) { gmk::set_error("device %d out of range (%d devices)", device, count); return GMK_ERR_ARG; }
+    GMK_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GMK_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    st.device = device;
+    st.cu_count = prop.multiProcessorCount;
+    const gmk::DeviceTables& t = production_automaton().device();
+    st.n_states = t.n_states;
+    st.n_patterns = t.n_patterns;
+    st.emit_words = static_cast<int>(t.emit_lists.size());
+    GMK_HIP_CHECK(hipMalloc(&st.d_trans, t.trans.size() * sizeof(uint32_t)));
+    GMK_HIP_CHECK(hipMalloc(&st.d_emit, t.emit_lists.size() * sizeof(uint16_t)));
+    GMK_HIP_CHECK(hipMalloc(&st.d_pattern_info, t.pattern_info.size() * sizeof(uint32_t)));
+    GMK_HIP_CHECK(hipMemcpy(st.d_trans, t.trans.data(), t.trans.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(st.d_emit, t.emit_lists.data(), t.emit_lists.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(st.d_pattern_info, t.pattern_info.data(), t.pattern_info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    st.ready = true;
+    return GMK_OK;
+}
+
+extern "C" int gmk_shutdown(void) {
+    gmk::DeviceState& st = device_state();
+    if (!st.ready) return GMK_OK;
+    (void)hipFree(st.d_trans);
+    (void)hipFree(st.d_emit);
+    (void)hipFree(st.d_pattern_info);
+    st = gmk::DeviceState{};
+    return GMK_OK;
+}
+
+extern "C" int gmk_device_info(int* cu_count, size_t* hbm_bytes, char* name, int name_cap) {
+    gmk::DeviceState& st = device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded"); return GMK_ERR_STATE; }
+    hipDeviceProp_t prop;
+    GMK_HIP_CHECK(hipGetDeviceProperties(&prop, st.device));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    if (name && name_cap > 0) { std::strncpy(name, prop.name, static_cast<size_t>(name_cap) - 1); name[name_cap - 1] = 0; }
+    return GMK_OK;
+}
+
+extern "C" int gmk_tables_info(gmk_table_info* info) {
+    if (!info) return GMK_ERR_ARG;
+    const gmk::PatternAutomaton& a = production_automaton();
+    const gmk::DeviceTables& t = a.device();
+    info->n_patterns = t.n_patterns;
+    info->n_states = t.n_states;
+    info->dat_size = static_cast<int32_t>(a.base().size());
+    info->max_emissions = t.max_emissions;
+    info->trans_words = static_cast<int32_t>(t.trans.size());
+    info->emit_words = static_cast<int32_t>(t.emit_lists.size());
+    for (int i = 0; i < 5; ++i) info->invariants[i] = a.invariants()[i];
+    return GMK_OK;
+}
+
+extern "C" int gmk_tables_pattern(int i, char str[8], int* favour, int* type, int* score) {
+    const auto& pats = production_automaton().patterns();
+    if (i < 0 || i >= static_cast<int>(pats.size())) return GMK_ERR_ARG;
+    if (str) { std::memset(str, 0, 8); std::memcpy(str, pats[i].rich.data(), pats[i].rich.size()); }
+    if (favour) *favour = pats[i].favour;
+    if (type) *type = pats[i].type;
+    if (score) *score = pats[i].score;
+    return GMK_OK;
+}
+
+extern "C" int gmk_tables_copy(uint32_t* trans, uint16_t* emit_lists, uint32_t* pattern_info) {
+    const gmk::DeviceTables& t = production_automaton().device();
+    if (trans) std::memcpy(trans, t.trans.data(), t.trans.size() * sizeof(uint32_t));
+    if (emit_lists) std::memcpy(emit_lists, t.emit_lists.data(), t.emit_lists.size() * sizeof(uint16_t));
+    if (pattern_info) std::memcpy(pattern_info, t.pattern_info.data(), t.pattern_info.size() * sizeof(uint32_t));
+    return GMK_OK;
+}
+
+extern "C" int gmk_tables_copy_dat(int32_t* base, int32_t* check, int32_t* fail) {
+    const gmk::PatternAutomaton& a = production_automaton();
+    const size_t bytes = a.base().size() * sizeof(int32_t);
+    if (base) std::memcpy(base, a.base().data(), bytes);
+    if (check) std::memcpy(check, a.check().data(), bytes);
+    if (fail) std::memcpy(fail, a.fail().data(), bytes);
+    return GMK_OK;
+}
+
+extern "C" int gmk_tables_scan(const uint8_t* codes, int n, int32_t* patterns, int32_t* offsets, int cap) {
+    if (!codes || n < 0) return GMK_ERR_ARG;
+    for (int i = 0; i < n; ++i) if (codes[i] < 1 || codes[i] > 4) return GMK_ERR_ARG;
+    const auto stream = production_automaton().scan(codes, n);
+    int m = 0;
+    for (const auto& pr : stream) {
+        if (m < cap) { if (patterns) patterns[m] = pr.first; if (offsets) offsets[m] = pr.second; }
+        ++m;
+    }
+    return m;
+}

@@ -1,0 +1,165 @@
+"""ctypes binding of libgomoku_hip.so (include/gomoku_hip.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgomoku_hip.so")
+
+N = 225
+
+
+class GmkError(RuntimeError):
+    pass
+
+
+class TableInfo(C.Structure):
+    _fields_ = [("n_patterns", C.c_int32), ("n_states", C.c_int32), ("dat_size", C.c_int32),
+                ("max_emissions", C.c_int32), ("trans_words", C.c_int32), ("emit_words", C.c_int32),
+                ("invariants", C.c_int32 * 5)]
+
+
+_lib = None
+
+# every symbol include/gomoku_hip.h declares (checked by tests/test_cabi.py)
+EXPORTS = [
+    "gmk_init", "gmk_shutdown", "gmk_last_error", "gmk_device_info",
+    "gmk_tables_info", "gmk_tables_pattern", "gmk_tables_copy", "gmk_tables_copy_dat", "gmk_tables_scan",
+    "gmk_synth_boards", "gmk_moves_to_planes",
+    "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
+]
+
+
+def load():
+    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise GmkError("libgomoku_hip.so is missing: run `python -m gomokuai_amd.build` "
+                       "(there is no CPU fallback for the compute path)")
+    L = C.CDLL(_SO)
+    vp = C.c_void_p
+    L.gmk_last_error.restype = C.c_char_p
+    L.gmk_init.argtypes = [C.c_int]
+    L.gmk_device_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.c_char_p, C.c_int]
+    L.gmk_tables_info.argtypes = [C.POINTER(TableInfo)]
+    L.gmk_tables_pattern.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gmk_tables_copy.argtypes = [vp, vp, vp]
+    L.gmk_tables_copy_dat.argtypes = [vp, vp, vp]
+    L.gmk_tables_scan.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.gmk_synth_boards.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+    L.gmk_moves_to_planes.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    L.gmk_eval_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.gmk_eval_batch_host.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.gmk_eval_launch_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise GmkError("libgomoku_hip: %s (status %d)" % (load().gmk_last_error().decode(), rc))
+    return rc
+
+
+def init(device=0):
+    _check(load().gmk_init(device))
+
+
+def device_info():
+    cu = C.c_int()
+    mem = C.c_size_t()
+    name = C.create_string_buffer(256)
+    _check(load().gmk_device_info(C.byref(cu), C.byref(mem), name, 256))
+    return {"cu_count": cu.value, "hbm_bytes": mem.value, "name": name.value.decode()}
+
+
+# ---------------- pattern tables (host) ----------------
+def tables_info():
+    info = TableInfo()
+    _check(load().gmk_tables_info(C.byref(info)))
+    return info
+
+
+def tables_pattern(i):
+    s = C.create_string_buffer(8)
+    fav, typ, score = C.c_int(), C.c_int(), C.c_int()
+    _check(load().gmk_tables_pattern(i, s, C.byref(fav), C.byref(typ), C.byref(score)))
+    return s.value.decode(), fav.value, typ.value, score.value
+
+
+def tables_copy():
+    info = tables_info()
+    trans = np.zeros(info.trans_words, dtype=np.uint32)
+    emit = np.zeros(info.emit_words, dtype=np.uint16)
+    pinfo = np.zeros(info.n_patterns * 2, dtype=np.uint32)
+    _check(load().gmk_tables_copy(trans.ctypes.data, emit.ctypes.data, pinfo.ctypes.data))
+    return trans, emit, pinfo
+
+
+def tables_copy_dat():
+    info = tables_info()
+    base = np.zeros(info.dat_size, dtype=np.int32)
+    check = np.zeros(info.dat_size, dtype=np.int32)
+    fail = np.zeros(info.dat_size, dtype=np.int32)
+    _check(load().gmk_tables_copy_dat(base.ctypes.data, check.ctypes.data, fail.ctypes.data))
+    return base, check, fail
+
+
+def tables_scan(codes):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    pats = np.zeros(512, dtype=np.int32)
+    offs = np.zeros(512, dtype=np.int32)
+    m = _check(load().gmk_tables_scan(codes.ctypes.data, len(codes), pats.ctypes.data, offs.ctypes.data, 512))
+    return list(zip(pats[:m].tolist(), offs[:m].tolist()))
+
+
+# ---------------- synthetic workloads (host) ----------------
+DEFAULT_SEED = 0x9E3779B97F4A7C15
+
+
+def synth_boards(n, kind=0, seed=DEFAULT_SEED, first_board=0, stride=64):
+    """-> (moves u8[n,stride], lens i32[n], planes u16[n,2,16])."""
+    moves = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    planes = np.zeros((n, 2, 16), dtype=np.uint16)
+    _check(load().gmk_synth_boards(seed, first_board, n, kind, moves.ctypes.data, stride, lens.ctypes.data, planes.ctypes.data))
+    return moves, lens, planes
+
+
+def moves_to_planes(moves, lens):
+    moves = np.ascontiguousarray(moves, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    n, stride = moves.shape
+    planes = np.zeros((n, 2, 16), dtype=np.uint16)
+    _check(load().gmk_moves_to_planes(moves.ctypes.data, stride, lens.ctypes.data, n, planes.ctypes.data))
+    return planes
+
+
+# ---------------- K1: batched position evaluation ----------------
+def eval_batch_host(planes):
+    """planes u16[n,2,16] (host) -> scores i32[n,4,225], density i32[n,2,2,225], totals u32[n,11], status i32[n].
+    Runs on the GPU through gmk_eval_batch_host; raises without one."""
+    init()
+    planes = np.ascontiguousarray(planes, dtype=np.uint16)
+    n = planes.shape[0]
+    scores = np.zeros((n, 4, N), dtype=np.int32)
+    density = np.zeros((n, 2, 2, N), dtype=np.int32)
+    totals = np.zeros((n, 11), dtype=np.uint32)
+    status = np.zeros(n, dtype=np.int32)
+    _check(load().gmk_eval_batch_host(planes.ctypes.data, n, scores.ctypes.data, density.ctypes.data,
+                                      totals.ctypes.data, status.ctypes.data))
+    return scores, density, totals, status
+
+
+def eval_batch(d_planes, n, d_scores=None, d_density=None, d_totals=None, d_status=None, stream=None):
+    """Device-pointer form (ints, e.g. torch.Tensor.data_ptr()); asynchronous on `stream`."""
+    _check(load().gmk_eval_batch(d_planes, n, d_scores, d_density, d_totals, d_status, stream))
+
+
+def eval_launch_info(n):
+    g, b, l = C.c_int(), C.c_int(), C.c_int()
+    _check(load().gmk_eval_launch_info(n, C.byref(g), C.byref(b), C.byref(l)))
+    return {"grid": g.value, "block": b.value, "lds_bytes": l.value}

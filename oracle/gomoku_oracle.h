@@ -115,6 +115,13 @@ void go_eval_line_view(const go_evaluator *ev, int pos, int dir, uint8_t *out13)
 void go_eval_replay_batch(const uint8_t *moves, const int32_t *lens, int stride, int n,
                           int32_t *scores, int32_t *density, uint32_t *totals, int32_t *status);
 
+/* From-scratch formulation of the same outputs (go_scratch.c): model of the GPU kernel's algorithm.
+   cell: int8[225] (-1 white, 0 empty, +1 black); lead/trail = '?' symbols around each line (reference 6/6). */
+int  go_scratch_eval(const int8_t *cell, int lead, int trail, int32_t *scores, int32_t *density,
+                     uint32_t *totals, int32_t *status);
+void go_scratch_eval_batch(const uint8_t *moves, const int32_t *lens, int stride, int n, int lead, int trail,
+                           int32_t *scores, int32_t *density, uint32_t *totals, int32_t *status);
+
 /* ---------------- Philox4x32-10 (counter-based RNG shared with the GPU path) ---------------- */
 void go_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -20,7 +20,7 @@ TYPE_NAMES = ["DeadOne", "LiveOne", "DeadTwo", "LiveTwo", "DeadThree", "LiveThre
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("go_board.c", "go_ac.c", "go_eval.c", "go_mcts.c", "gomoku_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("go_board.c", "go_ac.c", "go_eval.c", "go_mcts.c", "go_scratch.c", "go_stdsort.cpp", "gomoku_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -80,6 +80,8 @@ def lib():
     L.go_eval_line_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.go_eval_replay_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.go_eval_replay_batch.restype = None
+    L.go_scratch_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.go_scratch_eval_batch.restype = None
     L.go_philox4x32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.go_philox4x32.restype = None
     L.go_mcts_new.argtypes = [C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_uint32]
@@ -206,6 +208,20 @@ def replay_batch(moves, lens):
     status = np.zeros(n, dtype=np.int32)
     lib().go_eval_replay_batch(moves.ctypes.data, lens.ctypes.data, stride, n,
                                scores.ctypes.data, density.ctypes.data, totals.ctypes.data, status.ctypes.data)
+    return scores, density, totals, status
+
+
+def scratch_batch(moves, lens, lead=6, trail=6):
+    """From-scratch formulation (go_scratch.c) on the final positions of the move lists."""
+    moves = np.ascontiguousarray(moves, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    n, stride = moves.shape
+    scores = np.zeros((n, 4, N), dtype=np.int32)
+    density = np.zeros((n, 2, 2, N), dtype=np.int32)
+    totals = np.zeros((n, 11), dtype=np.uint32)
+    status = np.zeros(n, dtype=np.int32)
+    lib().go_scratch_eval_batch(moves.ctypes.data, lens.ctypes.data, stride, n, lead, trail,
+                                scores.ctypes.data, density.ctypes.data, totals.ctypes.data, status.ctypes.data)
     return scores, density, totals, status
 
 
