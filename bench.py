@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path.  Contract: python bench.py --gpus N --steps K --warmup W prints ONE
+JSON line on rank 0.  A step = one pass of K1 (gmk_eval_batch) over one resident batch of synthetic
+boards (BASELINE.json configs[1]: 65 536 random 15x15 boards per GPU)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_EVAL = 64 + 3600 + 3600 + 44 + 4      # planes in; scores, density, totals, status out
+HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(n_sample, kind):
+    """The CPU oracle (restatement of the reference's incremental evaluator: replay of each move list)
+    timed single-threaded on this host, on a bounded sample of the same workload."""
+    from gomokuai_amd import lib as G
+    from oracle import oracle as O
+    moves, lens, _ = G.synth_boards(n_sample, kind)
+    O.lib()
+    t0 = time.perf_counter()
+    O.replay_batch(moves, lens)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "board-evals/s", "cores": 1, "kind": "port",
+            "sample": "%d boards of the same synthetic set, in-order replay through the oracle evaluator, %.1f s" % (n_sample, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--boards", type=int, default=65536, help="boards per GPU (BASELINE configs[1])")
+    ap.add_argument("--kind", type=int, default=0, help="0 random-opening, 1 clustered")
+    ap.add_argument("--cpu-sample", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from gomokuai_amd import lib as G
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    G.init(torch.cuda.current_device())
+
+    # independent boards shard across ranks by global board id; no collective on the data path
+    n = args.boards
+    _, _, planes = G.synth_boards(n, args.kind, first_board=rank * n)
+    d_planes = torch.from_numpy(planes.view(np.int16).reshape(n, 32)).to(dev)
+    d_scores = torch.empty((n, 4, 225), dtype=torch.int32, device=dev)
+    d_density = torch.empty((n, 2, 2, 225), dtype=torch.int32, device=dev)
+    d_totals = torch.empty((n, 11), dtype=torch.int32, device=dev)
+    d_status = torch.empty((n,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        G.eval_batch(d_planes.data_ptr(), n, d_scores.data_ptr(), d_density.data_ptr(), d_totals.data_ptr(),
+                     d_status.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps           # HIP events on the launch stream
+    if distributed:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        achieved = ALG_BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "board-evals/s",
+            "value": n * world * args.steps / elapsed,
+            "unit": "board-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "batched AC-automaton position eval (K1), %d %s boards per GPU, 15x15, inputs resident in HBM"
+                                   % (n, "random-opening" if args.kind == 0 else "clustered"),
+                       "boards_per_gpu": n, "parallelism": "boards sharded by rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "eval_positions_kernel", "kernel_ms": kernel_ms,
+                         "alg_bytes_per_launch": ALG_BYTES_PER_EVAL * n},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.kind)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
