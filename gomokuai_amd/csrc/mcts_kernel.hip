@@ -1,0 +1,461 @@
+// mcts_kernel.hip -- K3: batched MCTS playouts (RandomPolicy) as one persistent launch on gfx950.
+//
+// Per game the loop is the reference's MCTS::playout (core/lib/src/MCTS.cpp:158-177) with
+// Default::Select / Expand / BackPropogate (core/lib/include/algorithms/MonteCarlo.hpp:57-95) and
+// RandomPolicy::averagedSimulate (core/lib/include/policies/Random.h:22-35); the numerics (f64 PUCB from
+// f32 operands, f32 running mean, first-maximum tie break, children in ascending cell order) are kept so
+// that visit counts and Q are bit-identical to the CPU restatement under the shared Philox stream.
+//
+// Mapping onto CDNA4
+//   * one 64-lane wavefront (= one workgroup) owns G = 64 / c_rollouts games (12 for the default 5) for
+//     the whole search: all `playouts` iterations run inside ONE launch, no host round trips;
+//   * tree phases (select / expand / backup) give each game a quarter-wave (16 lanes = one DPP row): the
+//     <= 225 children of a node are scored 16 at a time with f64 PUCB and reduced with row shuffles, four
+//     games proceed concurrently per wave so that their dependent HBM loads overlap;
+//   * the simulate phase gives every ROLLOUT a lane: lane = (game, rollout); each lane plays its random
+//     game on a private bit-board kept in LDS (column layout [row][lane]: conflict-free), draws come from
+//     Philox4x32-10 keyed by (seed; game, playout, root stones << 8 | rollout, ply >> 2);
+//   * the tree lives in HBM, one arena per game, structure-of-arrays: stats {visits u32, value f32} (8 B,
+//     what select reads per child), link {first child << 8 | cell} and parent (4 B each).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "capi_common.h"
+#include "philox.h"
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kMaxGamesPerBlock = 16;
+
+struct GameHeader {                 // 128 B per game, in HBM
+    uint32_t rows[16];              // root position: black | white << 16 per row
+    uint32_t root;                  // node index of the root inside the arena
+    uint32_t n_nodes;               // nodes in use (MCTS::m_size)
+    uint32_t stones;                // stones on the root board (= Policy::m_initActs)
+    uint32_t last_move;             // cell of the last move, 255 if none
+    uint32_t game_id;               // global game id (RNG counter word 0)
+    uint32_t status;                // bit1: arena full
+    uint64_t alg_bytes;             // algorithmic tree bytes of the last run
+    uint32_t pad[8];
+};
+static_assert(sizeof(GameHeader) == 128, "GameHeader layout");
+
+struct SearchParams {
+    double c_puct;
+    uint32_t seed_lo, seed_hi;
+    int c_rollouts;
+    int games_per_block;
+    int node_capacity;
+    int n_games;
+    int playouts;
+};
+
+__constant__ float c_prior[226];          // 1.0f / float(n) evaluated on the host (MonteCarlo.hpp:50-55)
+__constant__ float c_value[129];          // float(double(sum) / double(c_rollouts)), index sum + c_rollouts (Random.h:30-33)
+
+__device__ __forceinline__ bool run_of_five(uint32_t m) { return (m & (m >> 1) & (m >> 2) & (m >> 3) & (m >> 4)) != 0; }
+
+// Five or more in a row through (x, y) for the colour in bits [shift, shift+15) of the row words
+// (Board::checkGameEnd, core/lib/src/Game.cpp:88-136).  rows[y * Stride].
+template <int Stride>
+__device__ __forceinline__ bool five_through(const uint32_t* rows, int x, int y, int shift) {
+    const uint32_t own = (rows[y * Stride] >> shift) & 0x7FFFu;
+    if (run_of_five(own)) return true;
+    uint32_t v = 16u, d1 = 16u, d2 = 16u;                       // bit 4 = the stone itself
+#pragma unroll
+    for (int i = 1; i <= 4; ++i) {
+        if (y + i < 15) {
+            const uint32_t o = ((rows[(y + i) * Stride] >> shift) & 0x7FFFu) << 4;
+            v |= ((o >> (x + 4)) & 1u) << (4 + i);
+            d1 |= ((o >> (x + i + 4)) & 1u) << (4 + i);
+            d2 |= ((o >> (x - i + 4)) & 1u) << (4 + i);
+        }
+        if (y - i >= 0) {
+            const uint32_t o = ((rows[(y - i) * Stride] >> shift) & 0x7FFFu) << 4;
+            v |= ((o >> (x + 4)) & 1u) << (4 - i);
+            d1 |= ((o >> (x - i + 4)) & 1u) << (4 - i);
+            d2 |= ((o >> (x + i + 4)) & 1u) << (4 - i);
+        }
+    }
+    return run_of_five(v) || run_of_five(d1) || run_of_five(d2);
+}
+
+// Default::RandomRollout (MonteCarlo.hpp:37-47) on a lane-private board; returns the winner (+1 / -1 / 0).
+__device__ int random_rollout(uint32_t* rows /* [y * 64] */, int to_move, int stones,
+                              uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    for (uint32_t k = 0;; ++k) {
+        if ((k & 3u) == 0u) {
+            const gmk::Philox4 p = gmk::philox4x32_10(game_id, playout, c2, k >> 2, k0, k1);
+            w0 = p.v[0]; w1 = p.v[1]; w2 = p.v[2]; w3 = p.v[3];
+        }
+        const uint32_t word = (k & 2u) ? ((k & 1u) ? w3 : w2) : ((k & 1u) ? w1 : w0);
+        const uint32_t r = word % 225u;                               // Board::getRandomMove (Game.cpp:64-73)
+        int y = static_cast<int>(r / 15u);
+        int x = static_cast<int>(r - 15u * static_cast<uint32_t>(y));
+        uint32_t rw = rows[y * 64];
+        uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
+        while (!open) {                                               // linear probe with wrap
+            y = (y == 14) ? 0 : y + 1;
+            rw = rows[y * 64];
+            open = ~(rw | (rw >> 16)) & 0x7FFFu;
+        }
+        x = __ffs(open) - 1;
+        const int shift = to_move > 0 ? 0 : 16;
+        rows[y * 64] = rw | (1u << (x + shift));
+        ++stones;
+        if (five_through<64>(rows, x, y, shift)) return to_move;
+        if (stones == 225) return 0;
+        to_move = -to_move;
+    }
+}
+
+__global__ __launch_bounds__(64)
+void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
+                          uint32_t* __restrict__ parent, SearchParams prm) {
+    __shared__ uint32_t s_lane_board[16 * 64];                   // rollout boards, [row][lane]
+    __shared__ uint32_t s_leaf[kMaxGamesPerBlock][16];           // leaf position of each game
+    __shared__ uint32_t s_cur[kMaxGamesPerBlock], s_ply[kMaxGamesPerBlock], s_last[kMaxGamesPerBlock];
+    __shared__ uint32_t s_need[kMaxGamesPerBlock];               // 1: leaf needs rollouts, 0: terminal
+    __shared__ float s_term_value[kMaxGamesPerBlock];
+    __shared__ int s_sum[kMaxGamesPerBlock];
+    __shared__ uint32_t s_nodes[kMaxGamesPerBlock], s_status[kMaxGamesPerBlock];
+    __shared__ unsigned long long s_bytes[kMaxGamesPerBlock];
+
+    const int lane = threadIdx.x, quarter = lane >> 4, l16 = lane & 15;
+    const int G = prm.games_per_block, R = prm.c_rollouts;
+    const int game0 = blockIdx.x * G;
+    const int games_here = min(G, prm.n_games - game0);
+    const int rounds = (G + 3) >> 2;
+    const size_t cap = static_cast<size_t>(prm.node_capacity);
+
+    if (lane < kMaxGamesPerBlock) {
+        const bool ok = lane < games_here;
+        s_nodes[lane] = ok ? headers[game0 + lane].n_nodes : 0;
+        s_status[lane] = ok ? headers[game0 + lane].status : 0;
+        s_bytes[lane] = 0;
+    }
+    __syncthreads();
+
+    for (int playout = 0; playout < prm.playouts; ++playout) {
+        if (lane < kMaxGamesPerBlock) s_sum[lane] = 0;
+
+        // ---- select: quarter-wave per game, descend to a leaf (MCTS.cpp:160-163) ----
+        for (int round = 0; round < rounds; ++round) {
+            const int gs = round * 4 + quarter;
+            if (gs < games_here) {
+                const GameHeader& hdr = headers[game0 + gs];
+                const size_t base = static_cast<size_t>(game0 + gs) * cap;
+                uint32_t row = hdr.rows[l16];                        // lane y holds row y of the board
+                uint32_t cur = hdr.root, ply = hdr.stones, last = hdr.last_move;
+                unsigned long long bytes = 0;
+                for (;;) {
+                    const uint32_t first = link[base + cur] >> 8;
+                    if (!first) break;                               // Node::isLeaf
+                    const int n_child = 225 - static_cast<int>(ply);
+                    const double n_parent = static_cast<double>(stats[base + cur].x);
+                    const double explore = prm.c_puct * static_cast<double>(c_prior[n_child]) * sqrt(n_parent);   // MonteCarlo.hpp:23-28
+                    double best = -1.0;
+                    int best_i = 0;
+                    for (int i = l16; i < n_child; i += 16) {
+                        const uint2 st = stats[base + first + i];
+                        const double score = static_cast<double>(__uint_as_float(st.y)) + explore / static_cast<double>(st.x + 1u);
+                        if (score > best) { best = score; best_i = i; }
+                    }
+#pragma unroll
+                    for (int m = 8; m >= 1; m >>= 1) {               // first maximum wins (strict > in ascending order)
+                        const double o = __shfl_xor(best, m, 16);
+                        const int oi = __shfl_xor(best_i, m, 16);
+                        if (o > best || (o == best && oi < best_i)) { best = o; best_i = oi; }
+                    }
+                    bytes += static_cast<unsigned long long>(n_child) * 8ull;
+                    cur = first + static_cast<uint32_t>(best_i);
+                    last = link[base + cur] & 0xFFu;
+                    if (l16 == static_cast<int>(last / 15u)) row |= 1u << ((last % 15u) + ((ply & 1u) ? 16u : 0u));   // Policy::applyMove, no victory check
+                    ++ply;
+                }
+                s_leaf[gs][l16] = (l16 < 15) ? row : 0u;
+                if (l16 == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; }
+            }
+        }
+        __syncthreads();
+
+        // ---- terminal test at the leaf (Policy::checkGameEnd, MCTS.cpp:166) ----
+        if (lane < games_here) {
+            const uint32_t ply = s_ply[lane], last = s_last[lane];
+            bool five = false;
+            if (ply > 0 && last < 225u) five = five_through<1>(s_leaf[lane], static_cast<int>(last % 15u), static_cast<int>(last / 15u), (ply & 1u) ? 0 : 16);
+            const bool over = five || ply == 225u;
+            s_need[lane] = over ? 0u : 1u;
+            s_term_value[lane] = five ? 1.0f : 0.0f;                 // CalcScore(node->player, winner): the mover won, or a tie
+        }
+        __syncthreads();
+
+        // ---- simulate: one lane per rollout (Random.h:22-35) ----
+        {
+            const int gs = lane / R, r = lane - gs * R;
+            if (gs < games_here && gs < G && s_need[gs]) {
+#pragma unroll
+                for (int y = 0; y < 15; ++y) s_lane_board[y * 64 + lane] = s_leaf[gs][y];
+                const uint32_t ply = s_ply[gs];
+                const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
+                const GameHeader& hdr = headers[game0 + gs];
+                const int winner = random_rollout(&s_lane_board[lane], init_player, static_cast<int>(ply), hdr.game_id,
+                                                  static_cast<uint32_t>(playout), (hdr.stones << 8) | static_cast<uint32_t>(r),
+                                                  prm.seed_lo, prm.seed_hi);
+                atomicAdd(&s_sum[gs], init_player * winner);         // CalcScore(init_player, winner)
+            }
+        }
+        __syncthreads();
+
+        // ---- expand + backup: quarter-wave per game (MonteCarlo.hpp:71-95) ----
+        for (int round = 0; round < rounds; ++round) {
+            const int gs = round * 4 + quarter;
+            if (gs < games_here) {
+                const size_t base = static_cast<size_t>(game0 + gs) * cap;
+                const uint32_t cur = s_cur[gs], ply = s_ply[gs];
+                float value;
+                unsigned long long bytes = 0;
+                if (s_need[gs]) {
+                    const float state_value = c_value[s_sum[gs] + R];
+                    value = -state_value;                            // MCTS.cpp:169
+                    const uint32_t rw = s_leaf[gs][l16];
+                    const uint32_t open = (l16 < 15) ? (~(rw | (rw >> 16)) & 0x7FFFu) : 0u;
+                    const int mine = __popc(open);
+                    int before = mine;                               // inclusive scan over the 16 lanes
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) {
+                        const int t = __shfl_up(before, d, 16);
+                        if (l16 >= d) before += t;
+                    }
+                    before -= mine;
+                    const uint32_t n_child = 225u - ply;
+                    const uint32_t first = s_nodes[gs];
+                    if (static_cast<size_t>(first) + n_child <= cap) {
+                        uint32_t idx = first + static_cast<uint32_t>(before);
+                        for (uint32_t m = open; m; m &= m - 1u, ++idx) {
+                            const uint32_t cell = static_cast<uint32_t>(l16) * 15u + static_cast<uint32_t>(__ffs(m) - 1);
+                            stats[base + idx] = make_uint2(0u, 0u);
+                            link[base + idx] = cell;
+                            parent[base + idx] = cur;
+                        }
+                        if (l16 == 0) {
+                            link[base + cur] = (first << 8) | (link[base + cur] & 0xFFu);
+                            s_nodes[gs] = first + n_child;
+                        }
+                        bytes += static_cast<unsigned long long>(n_child) * 16ull;
+                    } else if (l16 == 0) {
+                        s_status[gs] |= 2u;                          // arena full: the leaf stays a leaf
+                    }
+                } else {
+                    value = s_term_value[gs];                        // MCTS.cpp:172
+                }
+                if (l16 == 0) {                                      // Default::BackPropogate
+                    for (uint32_t node = cur; node != kNone; node = parent[base + node], value = -value) {
+                        uint2 st = stats[base + node];
+                        st.x += 1u;
+                        float q = __uint_as_float(st.y);
+                        q += (value - q) / static_cast<float>(st.x);
+                        st.y = __float_as_uint(q);
+                        stats[base + node] = st;
+                        bytes += 16ull;
+                    }
+                    s_bytes[gs] += bytes;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (lane < games_here) {
+        headers[game0 + lane].n_nodes = s_nodes[lane];
+        headers[game0 + lane].status = s_status[lane];
+        headers[game0 + lane].alg_bytes = s_bytes[lane];
+    }
+}
+
+// fresh single-node trees (MCTS::reset, MCTS.cpp:149-156)
+__global__ void mcts_init_roots_kernel(const GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
+                                       uint32_t* __restrict__ parent, size_t cap, int n_games) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_games) return;
+    const size_t base = static_cast<size_t>(g) * cap;
+    stats[base] = make_uint2(0u, 0u);
+    link[base] = headers[g].last_move;
+    parent[base] = kNone;
+}
+
+// children of the root -> visit counts by cell (MCTS::evalState, MCTS.cpp:104-110)
+__global__ void mcts_root_stats_kernel(const GameHeader* __restrict__ headers, const uint2* __restrict__ stats,
+                                       const uint32_t* __restrict__ link, size_t cap, int n_games,
+                                       uint32_t* __restrict__ visits, float* __restrict__ root_value,
+                                       uint32_t* __restrict__ root_visits, uint32_t* __restrict__ nodes, int32_t* __restrict__ status) {
+    const int g = blockIdx.x;
+    if (g >= n_games) return;
+    const GameHeader& hdr = headers[g];
+    const size_t base = static_cast<size_t>(g) * cap;
+    for (int i = threadIdx.x; i < 225; i += blockDim.x) visits[static_cast<size_t>(g) * 225 + i] = 0;
+    __syncthreads();
+    const uint32_t first = link[base + hdr.root] >> 8;
+    if (first) {
+        const int n_child = 225 - static_cast<int>(hdr.stones);
+        for (int i = threadIdx.x; i < n_child; i += blockDim.x)
+            visits[static_cast<size_t>(g) * 225 + (link[base + first + i] & 0xFFu)] = stats[base + first + i].x;
+    }
+    if (threadIdx.x == 0) {
+        const uint2 st = stats[base + hdr.root];
+        root_visits[g] = st.x;
+        root_value[g] = __uint_as_float(st.y);
+        nodes[g] = hdr.n_nodes;
+        status[g] = static_cast<int32_t>(hdr.status);
+    }
+}
+
+}  // namespace
+
+struct gmk_mcts {
+    int n_games = 0, node_capacity = 0, c_rollouts = 5, games_per_block = 12;
+    double c_puct = 5.0;
+    uint64_t seed = 0;
+    GameHeader* d_headers = nullptr;
+    uint2* d_stats = nullptr;
+    uint32_t* d_link = nullptr;
+    uint32_t* d_parent = nullptr;
+    hipStream_t last_stream = nullptr;
+};
+
+extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, int c_rollouts, uint64_t seed, gmk_mcts** out) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!out || n_games <= 0 || node_capacity < 2 || c_rollouts < 1 || c_rollouts > 64) { gmk::set_error("gmk_mcts_create: bad arguments"); return GMK_ERR_ARG; }
+    gmk_mcts* m = new gmk_mcts;
+    m->n_games = n_games; m->node_capacity = node_capacity; m->c_puct = c_puct; m->c_rollouts = c_rollouts; m->seed = seed;
+    m->games_per_block = std::min(kMaxGamesPerBlock, 64 / c_rollouts);
+    const size_t nodes = static_cast<size_t>(n_games) * static_cast<size_t>(node_capacity);
+    if (hipMalloc(&m->d_headers, sizeof(GameHeader) * n_games) != hipSuccess || hipMalloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess ||
+        hipMalloc(&m->d_link, nodes * 4) != hipSuccess || hipMalloc(&m->d_parent, nodes * 4) != hipSuccess) {
+        gmk::set_error("gmk_mcts_create: hipMalloc of %zu nodes (%.1f GB) failed", nodes, nodes * 16.0 / 1e9);
+        gmk_mcts_destroy(m);
+        return GMK_ERR_HIP;
+    }
+    float prior[226];
+    prior[0] = 0.0f;
+    for (int i = 1; i <= 225; ++i) prior[i] = 1.0f / static_cast<float>(i);
+    float value[129] = {};
+    for (int s = -c_rollouts; s <= c_rollouts; ++s) value[s + c_rollouts] = static_cast<float>(static_cast<double>(s) / static_cast<double>(c_rollouts));
+    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_prior), prior, sizeof prior));
+    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_value), value, sizeof value));
+    *out = m;
+    return GMK_OK;
+}
+
+extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
+    if (!m) return GMK_OK;
+    (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent);
+    delete m;
+    return GMK_OK;
+}
+
+extern "C" int gmk_mcts_set_roots(gmk_mcts* m, const uint16_t* h_planes, const int16_t* h_last_move, uint32_t first_game_id) {
+    if (!m || !h_planes || !h_last_move) { gmk::set_error("gmk_mcts_set_roots: bad arguments"); return GMK_ERR_ARG; }
+    std::vector<GameHeader> hdr(static_cast<size_t>(m->n_games));
+    for (int g = 0; g < m->n_games; ++g) {
+        GameHeader& h = hdr[static_cast<size_t>(g)];
+        std::memset(&h, 0, sizeof h);
+        uint32_t stones = 0;
+        for (int y = 0; y < 15; ++y) {
+            const uint32_t b = h_planes[static_cast<size_t>(g) * 32 + y] & 0x7FFFu, w = h_planes[static_cast<size_t>(g) * 32 + 16 + y] & 0x7FFFu;
+            h.rows[y] = b | (w << 16);
+            stones += static_cast<uint32_t>(__builtin_popcount(b) + __builtin_popcount(w));
+        }
+        h.root = 0; h.n_nodes = 1; h.stones = stones;
+        h.last_move = (h_last_move[g] >= 0 && h_last_move[g] < 225) ? static_cast<uint32_t>(h_last_move[g]) : 255u;
+        h.game_id = first_game_id + static_cast<uint32_t>(g);
+    }
+    GMK_HIP_CHECK(hipMemcpy(m->d_headers, hdr.data(), sizeof(GameHeader) * hdr.size(), hipMemcpyHostToDevice));
+    // root node of every arena: unvisited, no children, no parent
+    hipLaunchKernelGGL(mcts_init_roots_kernel, dim3((m->n_games + 255) / 256), dim3(256), 0, nullptr, m->d_headers, m->d_stats, m->d_link,
+                       m->d_parent, static_cast<size_t>(m->node_capacity), m->n_games);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    return GMK_OK;
+}
+
+extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
+    if (!m || playouts < 0) { gmk::set_error("gmk_mcts_run: bad arguments"); return GMK_ERR_ARG; }
+    SearchParams prm;
+    prm.c_puct = m->c_puct;
+    prm.seed_lo = static_cast<uint32_t>(m->seed); prm.seed_hi = static_cast<uint32_t>(m->seed >> 32);
+    prm.c_rollouts = m->c_rollouts; prm.games_per_block = m->games_per_block;
+    prm.node_capacity = m->node_capacity; prm.n_games = m->n_games; prm.playouts = playouts;
+    const int grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
+    m->last_stream = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent, prm);
+    GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+extern "C" int gmk_mcts_launch_info(gmk_mcts* m, int* grid, int* block, int* lds_bytes) {
+    if (!m) return GMK_ERR_ARG;
+    if (grid) *grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
+    if (block) *block = 64;
+    if (lds_bytes) *lds_bytes = 16 * 64 * 4 + kMaxGamesPerBlock * (16 * 4 + 4 * 8 + 8);
+    return GMK_OK;
+}
+
+extern "C" int gmk_mcts_root_stats(gmk_mcts* m, uint32_t* h_visits, float* h_root_value, uint32_t* h_root_visits,
+                                   uint32_t* h_nodes, int32_t* h_status) {
+    if (!m) return GMK_ERR_ARG;
+    const size_t n = static_cast<size_t>(m->n_games);
+    uint32_t *d_visits = nullptr, *d_rv = nullptr, *d_nodes = nullptr;
+    float* d_q = nullptr;
+    int32_t* d_status = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_rv); (void)hipFree(d_nodes); (void)hipFree(d_q); (void)hipFree(d_status); };
+#define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
+    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4));
+    GMK_TRY(hipMalloc(&d_rv, n * 4));
+    GMK_TRY(hipMalloc(&d_nodes, n * 4));
+    GMK_TRY(hipMalloc(&d_q, n * 4));
+    GMK_TRY(hipMalloc(&d_status, n * 4));
+    hipLaunchKernelGGL(mcts_root_stats_kernel, dim3(m->n_games), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link,
+                       static_cast<size_t>(m->node_capacity), m->n_games, d_visits, d_q, d_rv, d_nodes, d_status);
+    GMK_TRY(hipGetLastError());
+    GMK_TRY(hipStreamSynchronize(m->last_stream));
+    if (h_visits) GMK_TRY(hipMemcpy(h_visits, d_visits, n * 225 * 4, hipMemcpyDeviceToHost));
+    if (h_root_value) GMK_TRY(hipMemcpy(h_root_value, d_q, n * 4, hipMemcpyDeviceToHost));
+    if (h_root_visits) GMK_TRY(hipMemcpy(h_root_visits, d_rv, n * 4, hipMemcpyDeviceToHost));
+    if (h_nodes) GMK_TRY(hipMemcpy(h_nodes, d_nodes, n * 4, hipMemcpyDeviceToHost));
+    if (h_status) GMK_TRY(hipMemcpy(h_status, d_status, n * 4, hipMemcpyDeviceToHost));
+#undef GMK_TRY
+    cleanup();
+    return GMK_OK;
+}
+
+extern "C" int gmk_mcts_alg_bytes(gmk_mcts* m, uint64_t* bytes) {
+    if (!m || !bytes) return GMK_ERR_ARG;
+    std::vector<GameHeader> hdr(static_cast<size_t>(m->n_games));
+    GMK_HIP_CHECK(hipStreamSynchronize(m->last_stream));
+    GMK_HIP_CHECK(hipMemcpy(hdr.data(), m->d_headers, sizeof(GameHeader) * hdr.size(), hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (const GameHeader& h : hdr) total += h.alg_bytes;
+    *bytes = total;
+    return GMK_OK;
+}
+
+// MCTS::evalState's pi (MCTS.cpp:112-116) with Stats::TempBasedProbs (Statistical.hpp:37-42); host side.
+extern "C" int gmk_visits_to_pi(const uint32_t* visits, int stones, float* pi) {
+    if (!visits || !pi) return GMK_ERR_ARG;
+    const float eps = 1.1920929e-07f;                             // Eigen::NumTraits<float>::epsilon()
+    float v[225], sq = 0.0f;
+    for (int i = 0; i < 225; ++i) { v[i] = static_cast<float>(visits[i]); sq += v[i] * v[i]; }
+    if (sq > 0.0f) { const float nrm = std::sqrt(sq); for (float& x : v) x = x / nrm; }       // VectorXf::normalized()
+    for (float& x : v) x = x ? x + 1 : x;
+    const float temperature = static_cast<float>(stones < 15 ? 1 : 1e-2);
+    double e[225], sum = 0.0;
+    for (int i = 0; i < 225; ++i) { e[i] = std::exp(static_cast<double>(std::log(v[i] + eps) / temperature)); sum += e[i]; }
+    for (int i = 0; i < 225; ++i) { const float p = static_cast<float>(e[i] / sum); pi[i] = p > eps ? p : 0.0f; }
+    return GMK_OK;
+}

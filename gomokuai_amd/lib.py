@@ -28,6 +28,8 @@ EXPORTS = [
     "gmk_tables_info", "gmk_tables_pattern", "gmk_tables_copy", "gmk_tables_copy_dat", "gmk_tables_scan",
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
+    "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
+    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi",
 ]
 
 
@@ -54,6 +56,14 @@ def load():
     L.gmk_eval_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.gmk_eval_batch_host.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.gmk_eval_launch_info.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gmk_mcts_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.POINTER(vp)]
+    L.gmk_mcts_destroy.argtypes = [vp]
+    L.gmk_mcts_set_roots.argtypes = [vp, vp, vp, C.c_uint32]
+    L.gmk_mcts_run.argtypes = [vp, C.c_int, vp]
+    L.gmk_mcts_root_stats.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.gmk_mcts_alg_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.gmk_mcts_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gmk_visits_to_pi.argtypes = [vp, C.c_int, vp]
     _lib = L
     return L
 
@@ -163,3 +173,58 @@ def eval_launch_info(n):
     g, b, l = C.c_int(), C.c_int(), C.c_int()
     _check(load().gmk_eval_launch_info(n, C.byref(g), C.byref(b), C.byref(l)))
     return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+# ---------------- K3: batched MCTS (RandomPolicy) ----------------
+class BatchedMCTS:
+    """n_games independent searches on the GPU (gmk_mcts_*).  Fresh roots per set_roots()."""
+
+    def __init__(self, n_games, playouts_capacity=800, c_puct=5.0, c_rollouts=5, seed=DEFAULT_SEED, node_capacity=None):
+        init()
+        self.n = n_games
+        self.cap = node_capacity if node_capacity is not None else playouts_capacity * 225 + 1
+        h = C.c_void_p()
+        _check(load().gmk_mcts_create(n_games, self.cap, c_puct, c_rollouts, seed, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().gmk_mcts_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_roots(self, planes, last_moves, first_game_id=0):
+        planes = np.ascontiguousarray(planes, dtype=np.uint16)
+        last = np.ascontiguousarray(last_moves, dtype=np.int16)
+        assert planes.shape == (self.n, 2, 16) and last.shape == (self.n,)
+        _check(load().gmk_mcts_set_roots(self.h, planes.ctypes.data, last.ctypes.data, first_game_id))
+
+    def run(self, playouts, stream=None):
+        _check(load().gmk_mcts_run(self.h, playouts, stream))
+
+    def root_stats(self):
+        visits = np.zeros((self.n, N), dtype=np.uint32)
+        q = np.zeros(self.n, dtype=np.float32)
+        rv = np.zeros(self.n, dtype=np.uint32)
+        nodes = np.zeros(self.n, dtype=np.uint32)
+        status = np.zeros(self.n, dtype=np.int32)
+        _check(load().gmk_mcts_root_stats(self.h, visits.ctypes.data, q.ctypes.data, rv.ctypes.data, nodes.ctypes.data, status.ctypes.data))
+        return visits, q, rv, nodes, status
+
+    def alg_bytes(self):
+        b = C.c_uint64()
+        _check(load().gmk_mcts_alg_bytes(self.h, C.byref(b)))
+        return b.value
+
+    def launch_info(self):
+        g, b, l = C.c_int(), C.c_int(), C.c_int()
+        _check(load().gmk_mcts_launch_info(self.h, C.byref(g), C.byref(b), C.byref(l)))
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+
+def visits_to_pi(visits, stones):
+    v = np.ascontiguousarray(visits, dtype=np.uint32)
+    pi = np.zeros(N, dtype=np.float32)
+    _check(load().gmk_visits_to_pi(v.ctypes.data, int(stones), pi.ctypes.data))
+    return pi

@@ -97,6 +97,39 @@ int gmk_eval_batch_host(const uint16_t *h_planes, int n,
 /* launch geometry the library chose for gmk_eval_batch (for profiling reports) */
 int gmk_eval_launch_info(int n, int *grid, int *block, int *lds_bytes);
 
+/* ---- K3: batched MCTS with the reference's default RandomPolicy ----
+ * One handle = n_games independent searches, each with its own tree arena in HBM.  Replaces, per game,
+ * Gomoku::MCTS + Policies::RandomPolicy (core/lib/include/MCTS.h:135-180, core/lib/src/MCTS.cpp:99-198,
+ * core/lib/include/algorithms/MonteCarlo.hpp:13-110, core/lib/include/policies/Random.h:22-35):
+ *   select   argmax_i Q_i + c_puct * P_i * sqrt(N) / (n_i + 1) in double, first maximum wins
+ *   expand   one child per empty cell in ascending id, prior 1/float(#empty)
+ *   simulate c_rollouts uniform-probe random games (Game.cpp:64-73), value = float(sum / c_rollouts)
+ *   backup   visits += 1; value += (v - value) / float(visits); v = -v, up to the root
+ * The reference's random_device-seeded mt19937 is replaced by Philox4x32-10 with
+ *   key = seed, counter = (global game id, playout index, (stones on the root board << 8) | rollout, ply >> 2),
+ *   word ply & 3, move draw = word % 225
+ * so results do not depend on how games are spread over GPUs.
+ * Node capacity per game: at most 225 - stones new nodes per playout; exceeding it sets bit 1 of status. */
+typedef struct gmk_mcts gmk_mcts;
+int gmk_mcts_create(int n_games, int node_capacity, double c_puct, int c_rollouts, uint64_t seed, gmk_mcts **out);
+int gmk_mcts_destroy(gmk_mcts *m);
+/* Fresh roots (MCTS::reset + syncWithBoard on a tree without the position, MCTS.cpp:119-125,149-156):
+ * h_planes uint16[n][2][16]; h_last_move int16[n] (-1 for an empty board).  first_game_id = global id of game 0. */
+int gmk_mcts_set_roots(gmk_mcts *m, const uint16_t *h_planes, const int16_t *h_last_move, uint32_t first_game_id);
+/* MCTS::runPlayouts with the iteration constraint (MCTS.cpp:179-198): `playouts` playouts for every game, one launch. */
+int gmk_mcts_run(gmk_mcts *m, int playouts, void *stream);
+/* Root statistics after a run (synchronises the stream used by the last run):
+ *   h_visits uint32[n][225] child visit counts by cell (MCTS::evalState, MCTS.cpp:104-110),
+ *   h_root_value float[n], h_root_visits uint32[n], h_nodes uint32[n] (MCTS::m_size), h_status int32[n] (bit1: arena full). */
+int gmk_mcts_root_stats(gmk_mcts *m, uint32_t *h_visits, float *h_root_value, uint32_t *h_root_visits,
+                        uint32_t *h_nodes, int32_t *h_status);
+/* algorithmic tree bytes moved by the last run, summed over games (select 8 B/child, expand 16 B/node, backup 16 B/level) */
+int gmk_mcts_alg_bytes(gmk_mcts *m, uint64_t *bytes);
+int gmk_mcts_launch_info(gmk_mcts *m, int *grid, int *block, int *lds_bytes);
+/* pi from visit counts exactly as MCTS::evalState does (MCTS.cpp:112-116, Statistical.hpp:37-42); host side.
+ * visits uint32[225], stones = moves on the board (temperature 1 below 15 stones, else 0.01). */
+int gmk_visits_to_pi(const uint32_t *visits, int stones, float *pi);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""K3 parity on the GPU: gmk_mcts_* (persistent playout kernel) vs the CPU oracle's restatement of
+MCTS + RandomPolicy under the same Philox stream.  Visit counts, tree size: exact.  Root Q (f32): bitwise."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gomokuai_amd import lib as G
+
+pytestmark = pytest.mark.gpu
+
+SEED = G.DEFAULT_SEED
+
+
+def _oracle_search(O, moves, length, playouts, game_id, c_puct=5.0, c_rollouts=5, seed=SEED):
+    b = O.new_board()
+    L = O.lib()
+    for i in range(length):
+        L.go_board_apply(C.byref(b), int(moves[i]), 1)
+    m = O.MCTS(playouts, c_puct, c_rollouts, seed, game_id)
+    q, pi, visits = m.eval_state(b)
+    assert b.nrec == length                     # mcts_unittest.cpp:26-35: the board is left untouched
+    return visits, np.float32(q), m.root_visits, m.size, m.alg_bytes
+
+
+def _openings(n, plies, first=0):
+    """n random openings of exactly `plies` stones (the synthetic generator truncated)."""
+    moves, lens, _ = G.synth_boards(n, 0, first_board=first)
+    lens = np.minimum(lens, plies).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[i, lens[i] - 1] if lens[i] > 0 else -1 for i in range(n)], dtype=np.int16)
+    return moves, lens, planes, last
+
+
+@pytest.mark.parametrize("n_games,plies,playouts", [(24, 4, 200), (13, 0, 120), (5, 9, 300)])
+def test_visits_match_oracle(oracle, n_games, plies, playouts):
+    moves, lens, planes, last = _openings(n_games, plies, first=77)
+    t = G.BatchedMCTS(n_games, playouts_capacity=playouts)
+    t.set_roots(planes, last, first_game_id=1000)
+    t.run(playouts)
+    visits, q, rv, nodes, status = t.root_stats()
+    total_bytes = 0
+    for g in range(n_games):
+        ov, oq, orv, osize, obytes = _oracle_search(oracle, moves[g], int(lens[g]), playouts, 1000 + g)
+        assert (visits[g] == ov).all(), "game %d visits differ" % g
+        assert rv[g] == orv == playouts
+        assert nodes[g] == osize
+        assert q[g].tobytes() == oq.tobytes(), "game %d root Q %r vs %r" % (g, q[g], oq)
+        total_bytes += obytes
+    assert not status.any()
+    assert t.alg_bytes() == total_bytes
+    t.close()
+
+
+def test_results_independent_of_batching(oracle):
+    """Game g's result depends on its global id only: 30 games in one handle == the same games run as 7 + 23."""
+    moves, lens, planes, last = _openings(30, 4, first=5)
+    a = G.BatchedMCTS(30, playouts_capacity=100)
+    a.set_roots(planes, last, first_game_id=0)
+    a.run(100)
+    va = a.root_stats()[0]
+    b1 = G.BatchedMCTS(7, playouts_capacity=100)
+    b1.set_roots(planes[:7], last[:7], first_game_id=0)
+    b1.run(100)
+    b2 = G.BatchedMCTS(23, playouts_capacity=100)
+    b2.set_roots(planes[7:], last[7:], first_game_id=7)
+    b2.run(100)
+    assert (va[:7] == b1.root_stats()[0]).all() and (va[7:] == b2.root_stats()[0]).all()
+
+
+def test_terminal_and_near_terminal_roots(oracle):
+    pos = lambda x, y: y * 15 + x
+    won = [pos(3, 3), pos(3, 4), pos(4, 4), pos(3, 5), pos(5, 5), pos(3, 6), pos(6, 6), pos(3, 7), pos(7, 7)]      # black has five
+    four = won[:-1]                                                                                               # black to move, one move wins
+    games = [won, four, four + [pos(0, 0)]]
+    n = len(games)
+    moves = np.zeros((n, 64), dtype=np.uint8)
+    lens = np.array([len(g) for g in games], dtype=np.int32)
+    for i, g in enumerate(games):
+        moves[i, :len(g)] = g
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([g[-1] for g in games], dtype=np.int16)
+    t = G.BatchedMCTS(n, playouts_capacity=150)
+    t.set_roots(planes, last, first_game_id=9)
+    t.run(150)
+    visits, q, rv, nodes, status = t.root_stats()
+    # finished game: every playout ends at the root with value +1 for the player who made the last move
+    assert rv[0] == 150 and nodes[0] == 1 and q[0] == np.float32(1.0) and not visits[0].any()
+    for g in (1, 2):
+        ov, oq, orv, osize, _ = _oracle_search(oracle, moves[g], int(lens[g]), 150, 9 + g)
+        assert (visits[g] == ov).all() and nodes[g] == osize and q[g].tobytes() == oq.tobytes()
+
+
+def test_arena_capacity_flag():
+    moves, lens, planes, last = _openings(3, 4)
+    t = G.BatchedMCTS(3, node_capacity=1000)
+    t.set_roots(planes, last)
+    t.run(50)
+    _, _, rv, nodes, status = t.root_stats()
+    assert (status & 2).all() and (nodes <= 1000).all() and (rv == 50).all()
+
+
+def test_pi_from_visits(oracle):
+    """gmk_visits_to_pi (host) vs the oracle's restatement of MCTS::evalState's pi; float32 transcendental
+    order is unpinned in the reference (Eigen), so the comparison carries a tolerance of 1e-6 absolute."""
+    rng = np.random.RandomState(0)
+    for stones in (0, 14, 15, 60):
+        v = np.zeros(225, dtype=np.uint32)
+        idx = rng.choice(225, size=120, replace=False)
+        v[idx] = rng.randint(0, 60, size=120)
+        a = G.visits_to_pi(v, stones)
+        b = oracle.visits_to_pi(v, stones)
+        assert np.abs(a - b).max() <= 1e-6 and abs(float(a.sum()) - 1.0) < 1e-4
