@@ -29,6 +29,76 @@ def cpu_baseline(n_sample, kind):
             "sample": "%d boards of the same synthetic set, in-order replay through the oracle evaluator, %.1f s" % (n_sample, dt)}
 
 
+def mcts_openings(G, np, n, first):
+    """BASELINE configs[2]: every game starts from a 4-ply random opening of the synthetic generator."""
+    moves, lens, _ = G.synth_boards(n, 0, first_board=first)
+    lens = np.minimum(lens, 4).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[i, lens[i] - 1] for i in range(n)], dtype=np.int16)
+    return moves, lens, planes, last
+
+
+def bench_mcts(args, G, torch, dev, rank, world, distributed):
+    """Secondary metric of BASELINE.json: MCTS playouts/s, configs[2] (4 096 games x 800 playouts per GPU,
+    RandomPolicy c_puct=5 c_rollouts=5, fresh roots).  One step = one whole search of all games (one launch)."""
+    import numpy as np
+    n, P = args.mcts_games, args.mcts_playouts
+    _, _, planes, last = mcts_openings(G, np, n, rank * n)
+    tree = G.BatchedMCTS(n, playouts_capacity=P)
+    stream = torch.cuda.current_stream().cuda_stream
+    tree.set_roots(planes, last, first_game_id=rank * n)
+    tree.run(P, stream)                                   # warm-up search
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(args.mcts_reps):
+        tree.set_roots(planes, last, first_game_id=rank * n)
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tree.run(P, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    ms = sorted(times)[len(times) // 2]
+    alg = tree.alg_bytes()
+    if distributed:
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = float(t[0])
+    tree.close()
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"metric": "mcts-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms,
+            "config": {"workload": "batched MCTS (K3), %d games x %d playouts per GPU, RandomPolicy c_puct=5 c_rollouts=5, 4-ply openings, fresh roots" % (n, P)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "mcts_playouts_kernel", "kernel_ms": ms, "alg_bytes_per_launch": alg,
+                         "note": "tree bytes only (select 8 B/child, expand 16 B/node, backup 16 B/level); rollouts run in LDS/registers, the kernel is latency/issue bound"}}
+
+
+def cpu_baseline_mcts(playouts):
+    """BASELINE configs[0]-style CPU point: the oracle's MCTS restatement, single thread, a few whole searches."""
+    import ctypes as C
+    import numpy as np
+    from gomokuai_amd import lib as G
+    from oracle import oracle as O
+    moves, lens, _, _ = mcts_openings(G, np, 16, 0)
+    L = O.lib()
+    t0 = time.perf_counter()
+    done = 0
+    for g in range(16):
+        b = O.new_board()
+        for i in range(int(lens[g])):
+            L.go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        O.MCTS(playouts, 5.0, 5, G.DEFAULT_SEED, g).run_playouts(b)
+        done += playouts
+        if time.perf_counter() - t0 > 15:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "playouts/s", "cores": 1, "kind": "port",
+            "sample": "%d searches of %d playouts from the same 4-ply openings, oracle MCTS restatement, %.1f s" % (done // playouts, playouts, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -38,6 +108,9 @@ def main():
     ap.add_argument("--kind", type=int, default=0, help="0 random-opening, 1 clustered")
     ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mcts-games", type=int, default=4096, help="games per GPU for the secondary MCTS measurement (BASELINE configs[2]); 0 = skip")
+    ap.add_argument("--mcts-playouts", type=int, default=800)
+    ap.add_argument("--mcts-reps", type=int, default=3)
     args = ap.parse_args()
 
     import numpy as np
@@ -95,6 +168,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    mcts = None
+    if args.mcts_games > 0:
+        mcts = bench_mcts(args, G, torch, dev, rank, world, distributed)
+
     if rank == 0:
         achieved = ALG_BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -118,8 +195,12 @@ def main():
                          "kernel": "eval_positions_kernel", "kernel_ms": kernel_ms,
                          "alg_bytes_per_launch": ALG_BYTES_PER_EVAL * n},
         }
+        if mcts is not None:
+            out["secondary"] = mcts
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.kind)
+            if mcts is not None:
+                out["secondary"]["cpu_baseline"] = cpu_baseline_mcts(args.mcts_playouts)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -1,0 +1,88 @@
+"""Host-side mirror of the reference's agent interface for the hot path: agents/agent.py:7-33,
+agents/mcts.py:5-34 and agents/utils.py:5-63 (same names, arguments and return shapes), on top of the
+MI355X CorePyExt.  Written for this repo; the reference's own files run unchanged on the same module
+(see tests/test_pyext.py and INTEGRATION.md)."""
+import numpy as np
+
+from .core import Board, GameConfig as Game, MCTS, Player, RandomPolicy
+
+
+class Agent:
+    """Base class, also the random agent (agents/agent.py:7-33)."""
+
+    def get_action(self, state):
+        return state.random_move()
+
+    def eval_state(self, state):
+        return 0, np.full((Game["width"], Game["height"]), 1 / Game["board_size"]), self.get_action(state)
+
+    def reset(self):
+        pass
+
+    def __repr__(self):
+        return "Base Random Agent"
+
+
+RandomAgent = Agent
+
+
+class MCTSAgent(Agent):
+    """agents/mcts.py:5-27: c_iterations=... or c_duration=... as the constraint."""
+
+    def __init__(self, policy=None, **constraint):
+        self.mcts = MCTS(policy=policy, **constraint)
+
+    def get_action(self, state):
+        self.mcts.sync_with_board(state)
+        return self.mcts.get_action(state)
+
+    def eval_state(self, state):
+        self.mcts.sync_with_board(state)
+        Q, pi = self.mcts.eval_state(state)
+        self.mcts.step_forward()
+        return Q, pi, self.mcts.root.position
+
+    def reset(self):
+        self.mcts.reset()
+
+    def __repr__(self):
+        return "MCTS Agent with {}".format(self.mcts.policy.__class__.__name__)
+
+
+def RandomMCTSAgent(c_puct, c_rollouts=5, **constraint):
+    return MCTSAgent(policy=RandomPolicy(c_puct, c_rollouts), **constraint)
+
+
+def dual_play(agents, board=None, verbose=False):
+    """agents/utils.py:5-63: {Player.black: a1, Player.white: a2} -> winner, or the training tuples
+    [(uint8[6,15,15] states, float score, float32[225] probs)] when verbose."""
+    if board is None:
+        board = Board()
+    elif board.status["is_end"]:
+        board.reset()
+    result = [] if verbose else Player.none
+    while True:
+        cur_agent = agents[board.status["cur_player"]]
+        if verbose:
+            _, action_probs, next_move = cur_agent.eval_state(board)
+            result.append([board.encoded_states(), board.status["cur_player"], action_probs])
+        else:
+            next_move = cur_agent.get_action(board)
+        board.apply_move(next_move)
+        if board.status["is_end"]:
+            winner = board.status["winner"]
+            if verbose:
+                return [(s[0], np.array(Player.calc_score(s[1], winner)), s[2]) for s in result]
+            return winner
+
+
+def augment_game_data(data):
+    """network/data_helper.py:36-55: 4 rotations x {identity, fliplr} of every (states, value, probs) sample."""
+    out = []
+    for states, value, probs in data:
+        for i in range(4):
+            rot_states = np.array([np.rot90(s, i) for s in states])
+            rot_probs = np.rot90(probs.reshape(Game["height"], Game["width"]), i)
+            out.append((rot_states, value, rot_probs.flatten()))
+            out.append((np.array([np.fliplr(s) for s in rot_states]), value, np.fliplr(rot_probs).flatten()))
+    return out

@@ -19,6 +19,7 @@
 //     what select reads per child), link {first child << 8 | cell} and parent (4 B each).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,7 +40,8 @@ struct GameHeader {                 // 128 B per game, in HBM
     uint32_t game_id;               // global game id (RNG counter word 0)
     uint32_t status;                // bit1: arena full
     uint64_t alg_bytes;             // algorithmic tree bytes of the last run
-    uint32_t pad[8];
+    uint32_t playouts_done;         // playouts already run from this root (RNG counter word 1 continues across launches)
+    uint32_t pad[7];
 };
 static_assert(sizeof(GameHeader) == 128, "GameHeader layout");
 
@@ -204,7 +206,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                 const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
                 const GameHeader& hdr = headers[game0 + gs];
                 const int winner = random_rollout(&s_lane_board[lane], init_player, static_cast<int>(ply), hdr.game_id,
-                                                  static_cast<uint32_t>(playout), (hdr.stones << 8) | static_cast<uint32_t>(r),
+                                                  hdr.playouts_done + static_cast<uint32_t>(playout), (hdr.stones << 8) | static_cast<uint32_t>(r),
                                                   prm.seed_lo, prm.seed_hi);
                 atomicAdd(&s_sum[gs], init_player * winner);         // CalcScore(init_player, winner)
             }
@@ -274,6 +276,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         headers[game0 + lane].n_nodes = s_nodes[lane];
         headers[game0 + lane].status = s_status[lane];
         headers[game0 + lane].alg_bytes = s_bytes[lane];
+        headers[game0 + lane].playouts_done += static_cast<uint32_t>(prm.playouts);
     }
 }
 
@@ -333,7 +336,15 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
     if (!out || n_games <= 0 || node_capacity < 2 || c_rollouts < 1 || c_rollouts > 64) { gmk::set_error("gmk_mcts_create: bad arguments"); return GMK_ERR_ARG; }
     gmk_mcts* m = new gmk_mcts;
     m->n_games = n_games; m->node_capacity = node_capacity; m->c_puct = c_puct; m->c_rollouts = c_rollouts; m->seed = seed;
-    m->games_per_block = std::min(kMaxGamesPerBlock, 64 / c_rollouts);
+    // Games per wavefront.  A game is a sequential chain (select -> rollouts -> backup), so wall time is set by
+    // the chain's latency, not by lane utilisation: fewer games per wave = fewer sequential tree rounds and a
+    // shorter longest-rollout tail, as long as the chip has wave slots to spare (1024 SIMDs on MI355X).
+    const int max_gpb = std::min(kMaxGamesPerBlock, 64 / c_rollouts);
+    const int simds = std::max(1, st.cu_count * 4);
+    int gpb = (n_games + 2 * simds - 1) / (2 * simds);            // aim at ~2 waves per SIMD
+    gpb = ((gpb + 3) / 4) * 4;                                    // whole quarter-wave rounds
+    if (const char* env = std::getenv("GMK_MCTS_GAMES_PER_BLOCK")) gpb = std::atoi(env);
+    m->games_per_block = std::max(1, std::min(max_gpb, gpb));
     const size_t nodes = static_cast<size_t>(n_games) * static_cast<size_t>(node_capacity);
     if (hipMalloc(&m->d_headers, sizeof(GameHeader) * n_games) != hipSuccess || hipMalloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess ||
         hipMalloc(&m->d_link, nodes * 4) != hipSuccess || hipMalloc(&m->d_parent, nodes * 4) != hipSuccess) {

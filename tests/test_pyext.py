@@ -1,0 +1,159 @@
+"""The drop-in boundary: the CorePyExt module of this repo exposes the reference's Python surface
+(core/py_ext/src/{game_ext,mcts_ext,policy_ext}.hpp).  CPU part: names, value types, Board rules checked
+against the oracle.  In this container only: the REFERENCE's own agents/utils.py + agents/agent.py are
+imported from /root/reference and played on top of the module (they never travel to the GPU box)."""
+import ctypes as C
+import datetime
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from gomokuai_amd import core
+
+
+def test_surface_names():
+    for name in ["GameConfig", "Player", "Position", "Board", "Node", "Policy", "MCTS", "RandomPolicy", "PoolRAVEPolicy", "TraditionalPolicy"]:
+        assert hasattr(core, name)                                  # core/__init__.py:2-4
+    assert core.GameConfig == dict(width=15, height=15, board_size=225, max_renju=5)     # game_ext.hpp:13-19
+
+
+def test_player_and_position():
+    P, Pos = core.Player, core.Position
+    assert float(P.white) == -1.0 and float(P.black) == 1.0 and -P.black == P.white and -P.none == P.none
+    assert P.calc_score(P.black, P.black) == 1.0 and P.calc_score(P.white, P.black) == -1.0 and P.calc_score(P.black, P.none) == 0.0
+    assert P.calc_score(P.white, 0.5) == -0.5
+    p = Pos(7, 3)
+    assert p.id == 52 and (p.x, p.y) == (7, 3) and int(p) == 52 and hash(p) == 52 and len(p) == 2
+    assert str(p) == "(7, 3)" and repr(p) == "Position(7, 3)" and dict(p) == {"x": 7, "y": 3}      # game_ext.hpp:33-47
+    p.x = 1
+    assert p.id == 46
+    p.y = 0
+    assert p.id == 1
+    assert Pos(-1).id == -1 and Pos(52) == p.__class__(7, 3)
+
+
+def test_board_rules_match_oracle(oracle):
+    """Board (Game.cpp:37-146) against the oracle's restatement on random games incl. invalid moves and reverts."""
+    O = oracle
+    L = O.lib()
+    rng = np.random.RandomState(1)
+    for _ in range(30):
+        b, ob = core.Board(), O.new_board()
+        for _step in range(300):
+            mv = int(rng.randint(-2, 227))
+            r1 = b.apply_move(core.Position(mv))
+            r2 = L.go_board_apply(C.byref(ob), mv, 1)
+            assert int(float(r1)) == r2
+            if rng.rand() < 0.1:
+                k = int(rng.randint(0, 4))
+                assert int(float(b.revert_move(k))) == L.go_board_revert(C.byref(ob), k)
+            st = b.status
+            assert st["is_end"] == (ob.cur_player == 0) and int(float(st["winner"])) == ob.winner
+            assert [p.id for p in b.move_record] == list(ob.record[:ob.nrec])
+            enc = np.zeros((6, 15, 15), dtype=np.uint8)
+            L.go_board_encoded_states(C.byref(ob), enc.ctypes.data)
+            assert (b.encoded_states() == enc).all()                # game_ext.hpp:87-104
+            if st["is_end"]:
+                break
+        counts = b.move_counts
+        assert counts[core.Player.black] + counts[core.Player.white] + counts[core.Player.none] == 225
+        ms = b.move_states
+        assert ms[core.Player.none].dtype == np.uint8 and ms[core.Player.none].shape == (15, 15)
+        assert int(ms[core.Player.black].sum()) == counts[core.Player.black]
+
+
+def test_board_full_raises_overflow():
+    b = core.Board()
+    for j in range(15):
+        y = 2 * j if j <= 7 else 2 * (j - 7) - 1
+        for i in range(15):
+            b.apply_move(core.Position(i, y))
+    assert b.status["is_end"] and b.status["winner"] == core.Player.none
+    with pytest.raises(OverflowError):                              # Game.cpp:65-67 via pybind11
+        b.random_move()
+    assert b.last_move.id == 13 * 15 + 14
+
+
+def test_policy_and_mcts_construction():
+    pol = core.RandomPolicy(5.0, 5)
+    assert isinstance(pol, core.Policy) and pol.c_rollouts == 5 and pol.select is None
+    m = core.MCTS(policy=pol, c_iterations=100)                     # agents/mcts.py:11
+    assert m.iterations == 100 and m.size == 1 and m.root.position.id == -1 and m.root.player == core.Player.white
+    assert m.root.is_leaf() and m.policy is pol
+    m2 = core.MCTS(c_duration=datetime.timedelta(milliseconds=50))
+    assert m2.duration == datetime.timedelta(milliseconds=50)
+    b = core.Board()
+    for mv in (112, 113, 97):
+        b.apply_move(core.Position(mv))
+    m.sync_with_board(b)                                            # MCTS.cpp:119-125
+    assert m.root.position.id == 97 and m.root.player == core.Player.black
+    m.step_forward(core.Position(5))
+    assert m.root.position.id == 5 and m.root.player == core.Player.white and m.root.action_prob == 1.0
+    m.reset()
+    assert m.root.position.id == -1
+    cb = core.Policy(eval_state=lambda board: (0.0, np.zeros(225, np.float32)), c_puct=3.0)        # agents/alphazero.py:5-9
+    assert cb.eval_state is not None and cb.c_puct == 3.0
+    n = core.Node(position=core.Position(3), player=core.Player.black, state_value=0.5, action_prob=0.25)
+    assert n.is_leaf() and n.parent is None and abs(n.state_value - 0.5) < 1e-7
+
+
+def test_no_cpu_search_path():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    m = core.MCTS(c_iterations=10)
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        m.get_action(core.Board())
+    with pytest.raises(RuntimeError):
+        core.MCTS(c_iterations=10, policy=core.TraditionalPolicy()).eval_state(core.Board())
+
+
+def test_augmentation_property():
+    """test/test_network.py:9-36 of the reference: every augmented sample is the permutation-consistent
+    image of its base sample (checked on synthetic samples; the GPU test plays real games)."""
+    from gomokuai_amd.agents import augment_game_data
+    rng = np.random.RandomState(0)
+    data = [(rng.randint(0, 2, size=(6, 15, 15)).astype(np.uint8), np.array(1.0), rng.rand(225).astype(np.float32)) for _ in range(3)]
+    aug = augment_game_data(data)
+    ids = augment_game_data([(d[0], d[1], np.arange(225)) for d in data])
+    assert len(aug) == 8 * len(data)
+    for i in range(len(data)):
+        ref_states, _, ref_probs = aug[8 * i]
+        for j in range(1, 8):
+            perm = ids[8 * i + j][2].astype(int)
+            states, _, probs = aug[8 * i + j]
+            for a, b in zip(states, ref_states):
+                assert (a.flatten() == b.flatten()[perm]).all()
+            assert (probs == ref_probs[perm]).all()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/agents"), reason="reference tree only exists in the build container")
+def test_reference_agents_run_unchanged_on_this_module():
+    """Imports the reference's OWN agents/agent.py + agents/utils.py (numpy only) with this repo's CorePyExt
+    on sys.path and plays its dual_play loop: the callers of the hot path need no change."""
+    import importlib
+    sys.path.insert(0, core.module_path)
+    sys.path.insert(0, "/root/reference")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "core" or k.startswith("core.") or k == "agents" or k.startswith("agents.") or k == "config"}
+    try:
+        ref_core = importlib.import_module("core")                  # /root/reference/core/__init__.py
+        assert ref_core.Board is core.Board
+        agent_mod = importlib.import_module("agents.agent")
+        utils = importlib.import_module("agents.utils")
+        mcts_mod = importlib.import_module("agents.mcts")
+        a = agent_mod.Agent()
+        winner = utils.dual_play({ref_core.Player.black: a, ref_core.Player.white: a})
+        assert winner in (ref_core.Player.black, ref_core.Player.white, ref_core.Player.none)
+        data = utils.dual_play({ref_core.Player.black: a, ref_core.Player.white: a}, verbose=True)
+        states, score, probs = data[0]
+        assert states.shape == (6, 15, 15) and states.dtype == np.uint8 and float(score) in (-1.0, 0.0, 1.0)
+        agent = mcts_mod.RandomMCTSAgent(5.0, 5, c_iterations=10)   # agents/mcts.py:30-34 constructs through our MCTS
+        assert "RandomPolicy" in repr(agent)
+    finally:
+        for k in list(sys.modules):
+            if k == "core" or k.startswith("core.") or k == "agents" or k.startswith("agents.") or k == "config":
+                sys.modules.pop(k)
+        sys.modules.update(saved)
+        sys.path.remove("/root/reference")

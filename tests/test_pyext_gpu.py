@@ -1,0 +1,57 @@
+"""CorePyExt on the GPU: the reference-shaped agent loop (MCTSAgent.eval_state -> dual_play) runs its
+searches through gmk_mcts_* and agrees with the CPU oracle on the same seeds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gomokuai_amd import agents, core
+
+pytestmark = pytest.mark.gpu
+
+
+def test_eval_state_matches_oracle(oracle):
+    O = oracle
+    core.set_seed(12345)
+    m = core.MCTS(c_iterations=300, policy=core.RandomPolicy(5.0, 5))
+    b = core.Board()
+    ob = O.new_board()
+    for mv in (112, 98, 127):
+        b.apply_move(core.Position(mv))
+        O.lib().go_board_apply(C.byref(ob), mv, 1)
+    q, pi = m.eval_state(b)
+    om = O.MCTS(300, 5.0, 5, 12345, 0)                              # first MCTS after set_seed has game id 0
+    oq, opi, ovisits = om.eval_state(ob)
+    assert np.float32(q).tobytes() == np.float32(oq).tobytes()
+    assert [c.node_visits for c in m.root.children] == [int(v) for i, v in enumerate(ovisits) if ob.states[1][i]]
+    assert np.abs(pi - opi).max() <= 1e-6                           # float32 log/exp order is unpinned (Eigen): tolerance
+    assert m.size == om.size and m.iterations == 300 and len(b.move_record) == 3
+    m.step_forward()
+    assert m.root.position.id == int(np.argmax(ovisits))
+
+
+def test_self_play_game_and_training_tuples():
+    core.set_seed(7)
+    agent = agents.RandomMCTSAgent(5.0, 5, c_iterations=60)
+    data = agents.dual_play({core.Player.black: agent, core.Player.white: agent}, verbose=True)
+    assert len(data) >= 9
+    states, score, probs = data[0]
+    assert states.shape == (6, 15, 15) and states.dtype == np.uint8 and probs.shape == (225,) and probs.dtype == np.float32
+    assert abs(float(probs.sum()) - 1.0) < 1e-3 and float(score) in (-1.0, 0.0, 1.0)
+    assert states[2].sum() == 225 and states[5].all()               # empty board, black to move
+    winner_scores = {float(s) for _, s, _ in data}
+    assert winner_scores <= {-1.0, 0.0, 1.0}
+    aug = agents.augment_game_data(data)
+    assert len(aug) == 8 * len(data)
+    # same seed, same game
+    core.set_seed(7)
+    agent2 = agents.RandomMCTSAgent(5.0, 5, c_iterations=60)
+    again = agents.dual_play({core.Player.black: agent2, core.Player.white: agent2}, verbose=True)
+    assert len(again) == len(data) and all((a[2] == b[2]).all() for a, b in zip(data, again))
+
+
+def test_duration_constraint():
+    import datetime
+    m = core.MCTS(c_duration=datetime.timedelta(milliseconds=100))
+    mv = m.get_action(core.Board())
+    assert 0 <= mv.id < 225 and m.iterations >= 256 and m.size > 1

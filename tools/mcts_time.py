@@ -7,8 +7,10 @@ moves,lens,_=G.synth_boards(n,0)
 lens=np.minimum(lens,4).astype(np.int32)
 planes=G.moves_to_planes(moves,lens)
 last=np.array([moves[i,lens[i]-1] for i in range(n)],dtype=np.int16)
+import os
 t=G.BatchedMCTS(n,playouts_capacity=P)
-for rep in range(3):
+print('gpb env',os.environ.get('GMK_MCTS_GAMES_PER_BLOCK'),t.launch_info())
+for rep in range(2):
     t.set_roots(planes,last,0)
     torch.cuda.synchronize()
     t0=time.perf_counter(); t.run(P); torch.cuda.synchronize(); dt=time.perf_counter()-t0
