@@ -126,6 +126,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     __shared__ int s_sum[kMaxGamesPerBlock];
     __shared__ uint32_t s_nodes[kMaxGamesPerBlock], s_status[kMaxGamesPerBlock];
     __shared__ unsigned long long s_bytes[kMaxGamesPerBlock];
+    __shared__ uint32_t s_active[kMaxGamesPerBlock];             // 0: the game is over (status bit 0), nothing to search
 
     const int lane = threadIdx.x, quarter = lane >> 4, l16 = lane & 15;
     const int G = prm.games_per_block, R = prm.c_rollouts;
@@ -139,6 +140,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         s_nodes[lane] = ok ? headers[game0 + lane].n_nodes : 0;
         s_status[lane] = ok ? headers[game0 + lane].status : 0;
         s_bytes[lane] = 0;
+        s_active[lane] = (ok && !(headers[game0 + lane].status & 1u)) ? 1u : 0u;
     }
     __syncthreads();
 
@@ -148,7 +150,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         // ---- select: quarter-wave per game, descend to a leaf (MCTS.cpp:160-163) ----
         for (int round = 0; round < rounds; ++round) {
             const int gs = round * 4 + quarter;
-            if (gs < games_here) {
+            if (gs < games_here && s_active[gs]) {
                 const GameHeader& hdr = headers[game0 + gs];
                 const size_t base = static_cast<size_t>(game0 + gs) * cap;
                 uint32_t row = hdr.rows[l16];                        // lane y holds row y of the board
@@ -186,7 +188,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         __syncthreads();
 
         // ---- terminal test at the leaf (Policy::checkGameEnd, MCTS.cpp:166) ----
-        if (lane < games_here) {
+        if (lane < games_here && s_active[lane]) {
             const uint32_t ply = s_ply[lane], last = s_last[lane];
             bool five = false;
             if (ply > 0 && last < 225u) five = five_through<1>(s_leaf[lane], static_cast<int>(last % 15u), static_cast<int>(last / 15u), (ply & 1u) ? 0 : 16);
@@ -199,7 +201,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         // ---- simulate: one lane per rollout (Random.h:22-35) ----
         {
             const int gs = lane / R, r = lane - gs * R;
-            if (gs < games_here && gs < G && s_need[gs]) {
+            if (gs < games_here && gs < G && s_active[gs] && s_need[gs]) {
 #pragma unroll
                 for (int y = 0; y < 15; ++y) s_lane_board[y * 64 + lane] = s_leaf[gs][y];
                 const uint32_t ply = s_ply[gs];
@@ -216,7 +218,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         // ---- expand + backup: quarter-wave per game (MonteCarlo.hpp:71-95) ----
         for (int round = 0; round < rounds; ++round) {
             const int gs = round * 4 + quarter;
-            if (gs < games_here) {
+            if (gs < games_here && s_active[gs]) {
                 const size_t base = static_cast<size_t>(game0 + gs) * cap;
                 const uint32_t cur = s_cur[gs], ply = s_ply[gs];
                 float value;
@@ -276,7 +278,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         headers[game0 + lane].n_nodes = s_nodes[lane];
         headers[game0 + lane].status = s_status[lane];
         headers[game0 + lane].alg_bytes = s_bytes[lane];
-        headers[game0 + lane].playouts_done += static_cast<uint32_t>(prm.playouts);
+        if (s_active[lane]) headers[game0 + lane].playouts_done += static_cast<uint32_t>(prm.playouts);
     }
 }
 
@@ -289,6 +291,75 @@ __global__ void mcts_init_roots_kernel(const GameHeader* __restrict__ headers, u
     stats[base] = make_uint2(0u, 0u);
     link[base] = headers[g].last_move;
     parent[base] = kNone;
+}
+
+// One self-play move per unfinished game: MCTS::stepForward() (MCTS.cpp:129-134) + Board::applyMove with the
+// victory check (Game.cpp:37-47, 88-136) on the root position, the (move, visit counts) record of
+// agents/utils.py:29-41, and the new root.  One wavefront per game.
+__global__ __launch_bounds__(64)
+void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
+                         uint32_t* __restrict__ parent, size_t cap, int n_games,
+                         uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
+                         int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (g >= n_games) return;
+    GameHeader& hdr = headers[g];
+    if (hdr.status & 1u) return;                                    // already over
+    const size_t base = static_cast<size_t>(g) * cap;
+    const uint32_t root = hdr.root, stones = hdr.stones;
+    const uint32_t first = link[base + root] >> 8;
+    if (!first) return;                                             // never searched: nothing to play
+    const int n_child = 225 - static_cast<int>(stones);
+    long long best = -1;
+    int best_i = 0;
+    for (int i = lane; i < n_child; i += 64) {
+        const long long v = stats[base + first + i].x;
+        if (v > best) { best = v; best_i = i; }                      // std::max_element: first maximum
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const long long o = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(best_i, m, 64);
+        if (o > best || (o == best && oi < best_i)) { best = o; best_i = oi; }
+    }
+    const uint32_t child = first + static_cast<uint32_t>(best_i);
+    const uint32_t cell = link[base + child] & 0xFFu;
+    const int len = rec_lens[g];
+    if (rec_visits) {
+        uint16_t* rv = rec_visits + (static_cast<size_t>(g) * 225 + static_cast<size_t>(len)) * 225;
+        for (int i = lane; i < 225; i += 64) rv[i] = 0;
+        __syncthreads();
+        for (int i = lane; i < n_child; i += 64)
+            rv[link[base + first + i] & 0xFFu] = static_cast<uint16_t>(min(stats[base + first + i].x, 65535u));
+    }
+    __syncthreads();
+    if (lane == 0) {
+        rec_moves[static_cast<size_t>(g) * 225 + len] = static_cast<uint8_t>(cell);
+        rec_lens[g] = len + 1;
+        const int x = static_cast<int>(cell % 15u), y = static_cast<int>(cell / 15u);
+        const int shift = (stones & 1u) ? 16 : 0;                   // black moves on even stone counts
+        hdr.rows[y] |= 1u << (x + shift);
+        hdr.stones = stones + 1;
+        hdr.last_move = cell;
+        const bool five = five_through<1>(hdr.rows, x, y, shift);
+        if (five || stones + 1 == 225u) {
+            hdr.status |= 1u;
+            rec_winner[g] = five ? static_cast<int8_t>(shift ? -1 : 1) : static_cast<int8_t>(0);
+        } else {
+            atomicAdd(unfinished, 1);
+        }
+        hdr.playouts_done = 0;
+        if (reuse) {                                                // the subtree of the move becomes the tree
+            hdr.root = child;
+            parent[base + child] = kNone;
+        } else {                                                    // MCTS::reset + syncWithBoard: a fresh one-node tree
+            hdr.root = 0;
+            hdr.n_nodes = 1;
+            stats[base] = make_uint2(0u, 0u);
+            link[base] = cell;
+            parent[base] = kNone;
+        }
+    }
 }
 
 // children of the root -> visit counts by cell (MCTS::evalState, MCTS.cpp:104-110)
@@ -405,6 +476,18 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     const int grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
     m->last_stream = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent, prm);
+    GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+extern "C" int gmk_mcts_advance(gmk_mcts* m, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner,
+                                int32_t* d_unfinished, int reuse_subtree, void* stream) {
+    if (!m || !d_moves || !d_lens || !d_winner || !d_unfinished) { gmk::set_error("gmk_mcts_advance: bad arguments"); return GMK_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    m->last_stream = s;
+    GMK_HIP_CHECK(hipMemsetAsync(d_unfinished, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(mcts_advance_kernel, dim3(m->n_games), dim3(64), 0, s, m->d_headers, m->d_stats, m->d_link, m->d_parent,
+                       static_cast<size_t>(m->node_capacity), m->n_games, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }

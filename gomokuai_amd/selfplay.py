@@ -1,0 +1,149 @@
+"""Batched self-play on the GPU and the one exchange step of the path: gathering finished game records.
+
+Replaces the reference's data generation loop -- `network/data_helper.py:58-83` (`simulate_game_data` ->
+`dual_play(..., verbose=True)`) run by `DATA_CONFIG["process_num"]` = 2 Python processes that append to a
+`multiprocessing.Manager().list()` (`data_helper.py:97-113, 152-169`) -- by thousands of concurrent games per
+GPU (K3 + `gmk_mcts_advance`) sharded over ranks by global game id, and ONE gather of the compact records
+(moves, per-move root visit counts, winner) to rank 0 over `torch.distributed` (RCCL on MI355X, gloo on CPU).
+"""
+import numpy as np
+import torch
+
+from . import lib as G
+
+N = 225
+
+
+class GameRecords:
+    """Fixed-stride game records: moves u8[n,225], lens i32[n], winner i8[n], visits u16[n,225,225] (optional)."""
+
+    def __init__(self, moves, lens, winner, visits=None, first_game_id=0):
+        self.moves, self.lens, self.winner, self.visits, self.first_game_id = moves, lens, winner, visits, first_game_id
+
+    def __len__(self):
+        return int(self.lens.shape[0])
+
+    def cpu(self):
+        return GameRecords(self.moves.cpu(), self.lens.cpu(), self.winner.cpu(),
+                           None if self.visits is None else self.visits.cpu(), self.first_game_id)
+
+    def samples(self, game):
+        """The training tuples of one game as `dual_play(verbose=True)` returns them (agents/utils.py:36-40, 55-59):
+        [(uint8[6,15,15] encoded states, float score for the player to move, float32[225] pi)]."""
+        assert self.visits is not None
+        rec = self.cpu()
+        L = int(rec.lens[game])
+        winner = int(rec.winner[game])
+        cell = np.zeros(N, dtype=np.int8)
+        out = []
+        for t in range(L):
+            cur = 1 if t % 2 == 0 else -1
+            states = np.zeros((6, N), dtype=np.uint8)
+            states[0] = cell == cur
+            states[1] = cell == -cur
+            states[2] = cell == 0
+            if t >= 1:
+                states[3, int(rec.moves[game, t - 1])] = 1
+            if t >= 2:
+                states[4, int(rec.moves[game, t - 2])] = 1
+            states[5] = cur == 1
+            pi = G.visits_to_pi(rec.visits[game, t].numpy().astype(np.uint32), t)
+            out.append((states.reshape(6, 15, 15), np.array(float(cur * winner)), pi))
+            cell[int(rec.moves[game, t])] = cur
+        return out
+
+
+def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5.0, c_rollouts=5,
+               opening_plies=0, record_visits=True, reuse_subtree=False, max_moves=N, device=None, node_capacity=None):
+    """Plays n_games complete games on the current GPU: every move = one K3 search of `playouts` playouts for all
+    unfinished games, then `gmk_mcts_advance`.  Game g uses the global id first_game_id + g for its RNG streams, so
+    the records do not depend on how games are spread over GPUs."""
+    G.init(torch.cuda.current_device() if device is None else device.index)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    planes = np.zeros((n_games, 2, 16), dtype=np.uint16)
+    last = np.full(n_games, -1, dtype=np.int16)
+    moves0 = np.zeros((n_games, N), dtype=np.uint8)
+    lens0 = np.zeros(n_games, dtype=np.int32)
+    if opening_plies > 0:
+        m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+        lens0 = np.minimum(l, opening_plies).astype(np.int32)
+        planes = G.moves_to_planes(m, lens0)
+        for g in range(n_games):
+            moves0[g, :lens0[g]] = m[g, :lens0[g]]
+            last[g] = m[g, lens0[g] - 1] if lens0[g] > 0 else -1
+    cap = node_capacity if node_capacity is not None else playouts * N * (4 if reuse_subtree else 1) + 1
+    tree = G.BatchedMCTS(n_games, c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap)
+    tree.set_roots(planes, last, first_game_id)
+    d_moves = torch.from_numpy(moves0).to(dev)
+    d_lens = torch.from_numpy(lens0).to(dev)
+    d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
+    d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev) if record_visits else None
+    d_unfinished = torch.ones(1, dtype=torch.int32, device=dev)
+    for _ in range(max_moves):
+        tree.run(playouts, stream)
+        tree.advance(d_moves.data_ptr(), d_visits.data_ptr() if record_visits else None, d_lens.data_ptr(),
+                     d_winner.data_ptr(), d_unfinished.data_ptr(), reuse_subtree, stream)
+        if int(d_unfinished.item()) == 0:             # 4-byte readback per move: the only host sync in the loop
+            break
+    status = tree.root_stats()[4]
+    tree.close()
+    rec = GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id)
+    rec.overflow = bool((status & 2).any())
+    return rec
+
+
+def gather_records(rec, dst=0, group=None):
+    """The exchange step: every rank contributes its fixed-stride records, rank `dst` receives the concatenation in
+    rank order (= global game id order).  Works on any torch.distributed backend; with world size 1 it is the identity."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return rec
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    # shards may differ by one game: exchange the counts, pad to the longest, trim after the gather
+    mine = torch.tensor([len(rec)], dtype=torch.int64, device=rec.lens.device)
+    counts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts = [int(c) for c in counts]
+    longest = max(counts)
+    out = {}
+    for name in ("moves", "lens", "winner", "visits"):
+        t = getattr(rec, name)
+        if t is None:
+            out[name] = None
+            continue
+        t = t.contiguous()
+        dtype, tail = t.dtype, tuple(t.shape[1:])
+        t = t.reshape(t.shape[0], -1).view(torch.uint8)             # bytes on the wire: every backend carries uint8
+        if t.shape[0] < longest:
+            t = torch.cat([t, torch.zeros((longest - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)], dim=0)
+        bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+        if dist.get_backend(group) == "nccl":
+            # RCCL has no native gather: all ranks post one send, dst posts world-1 receives (grouped point-to-point
+            # over xGMI, 7 peers send concurrently), self-copy on dst
+            if rank == dst:
+                ops = [dist.P2POp(dist.irecv, bucket[r], r, group) for r in range(world) if r != dst]
+                bucket[dst].copy_(t)
+            else:
+                ops = [dist.P2POp(dist.isend, t, dst, group)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        else:
+            dist.gather(t, bucket, dst=dst, group=group)
+        if rank == dst:
+            whole = torch.cat([bucket[r][:counts[r]] for r in range(world)], dim=0)
+            out[name] = whole.view(dtype).reshape((whole.shape[0],) + tail)
+        else:
+            out[name] = None
+    first = torch.tensor([rec.first_game_id], dtype=torch.int64, device=rec.lens.device)
+    dist.all_reduce(first, op=dist.ReduceOp.MIN, group=group)       # id of the first game of the gathered block
+    if rank != dst:
+        return None
+    return GameRecords(out["moves"], out["lens"], out["winner"], out["visits"], int(first))
+
+
+def shard(n_total, rank, world):
+    """Contiguous id blocks: game g lives on rank g * world // n_total."""
+    lo = (n_total * rank) // world
+    hi = (n_total * (rank + 1)) // world
+    return lo, hi - lo

@@ -118,6 +118,17 @@ int gmk_mcts_destroy(gmk_mcts *m);
 int gmk_mcts_set_roots(gmk_mcts *m, const uint16_t *h_planes, const int16_t *h_last_move, uint32_t first_game_id);
 /* MCTS::runPlayouts with the iteration constraint (MCTS.cpp:179-198): `playouts` playouts for every game, one launch. */
 int gmk_mcts_run(gmk_mcts *m, int playouts, void *stream);
+/* One self-play move for every unfinished game, to be called after gmk_mcts_run (replaces the loop body of
+ * agents/utils.py:29-47 around MCTSAgent.eval_state, agents/mcts.py:17-21):
+ *   the most visited root child (first maximum: MCTS::stepForward, MCTS.cpp:129-134) is played on the root position,
+ *   (move, root child visit counts by cell) is appended to the game record, the game is closed when the move makes
+ *   five or fills the board (Board::checkGameEnd, Game.cpp:88-136), and the tree is re-rooted: reuse_subtree = 0
+ *   starts the next search from a fresh one-node tree (MCTS::reset), 1 keeps the subtree of the move.
+ * Device buffers: d_moves uint8[n][225], d_visits uint16[n][225][225] (may be NULL), d_lens int32[n] (zero before the
+ * first move), d_winner int8[n] (valid once the game is over), d_unfinished int32[1] = games still running afterwards.
+ * Finished games are skipped by later gmk_mcts_run calls. */
+int gmk_mcts_advance(gmk_mcts *m, uint8_t *d_moves, uint16_t *d_visits, int32_t *d_lens, int8_t *d_winner,
+                     int32_t *d_unfinished, int reuse_subtree, void *stream);
 /* Root statistics after a run (synchronises the stream used by the last run):
  *   h_visits uint32[n][225] child visit counts by cell (MCTS::evalState, MCTS.cpp:104-110),
  *   h_root_value float[n], h_root_visits uint32[n], h_nodes uint32[n] (MCTS::m_size), h_status int32[n] (bit1: arena full). */

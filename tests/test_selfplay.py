@@ -1,0 +1,99 @@
+"""Self-play records and the multi-rank gather (CPU part).  The gather is the only exchange step of the path
+(SURVEY.md 8e); it is exercised here with world_size 2 on gloo, the GPU box uses the same code over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gomokuai_amd import core, selfplay
+
+
+def _fake_records(n, first, seed):
+    rng = np.random.RandomState(seed)
+    moves = np.zeros((n, 225), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    winner = np.zeros(n, dtype=np.int8)
+    visits = np.zeros((n, 225, 225), dtype=np.int16)
+    for g in range(n):
+        b = core.Board()
+        t = 0
+        while not b.status["is_end"]:
+            mv = b.random_move()
+            empties = [i for i in range(225) if b.check_move(core.Position(i))]
+            visits[g, t, empties] = rng.randint(0, 50, size=len(empties))
+            visits[g, t, mv.id] = 60
+            moves[g, t] = mv.id
+            b.apply_move(mv)
+            t += 1
+        lens[g] = t
+        winner[g] = int(float(b.status["winner"]))
+    return selfplay.GameRecords(torch.from_numpy(moves), torch.from_numpy(lens), torch.from_numpy(winner), torch.from_numpy(visits), first)
+
+
+def test_samples_match_dual_play_tuples():
+    """GameRecords.samples == what agents/utils.py:29-63 builds move by move from Board.encoded_states()."""
+    rec = _fake_records(2, 0, 1)
+    for g in range(2):
+        samples = rec.samples(g)
+        b = core.Board()
+        L = int(rec.lens[g])
+        assert len(samples) == L
+        for t in range(L):
+            states, score, pi = samples[t]
+            assert (states == b.encoded_states()).all()
+            cur = b.status["cur_player"]
+            b.apply_move(core.Position(int(rec.moves[g, t])))
+            assert pi.shape == (225,) and abs(float(pi.sum()) - 1.0) < 1e-3
+            assert float(score) == core.Player.calc_score(cur, core.Player.black if rec.winner[g] == 1 else core.Player.white if rec.winner[g] == -1 else core.Player.none)
+        assert b.status["is_end"]
+
+
+def test_shard_blocks_cover_everything():
+    for total, world in ((32768, 8), (4096, 3), (10, 4)):
+        blocks = [selfplay.shard(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and sum(n for _, n in blocks) == total
+        for (lo, n), (lo2, _) in zip(blocks, blocks[1:]):
+            assert lo + n == lo2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, n = selfplay.shard(7, rank, world)
+    rec = _fake_records(n, lo, 100 + rank)
+    got = selfplay.gather_records(rec, dst=0)
+    torch.save({"moves": rec.moves, "lens": rec.lens, "winner": rec.winner, "visits": rec.visits}, os.path.join(out_dir, "part%d.pt" % rank))
+    if rank == 0:
+        assert got is not None and len(got) == 7 and got.first_game_id == 0
+        torch.save({"moves": got.moves, "lens": got.lens, "winner": got.winner, "visits": got.visits}, os.path.join(out_dir, "all.pt"))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo(tmp_path):
+    world = 2
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(tmp_path, "part%d.pt" % r)) for r in range(world)]
+    allrec = torch.load(os.path.join(tmp_path, "all.pt"))
+    for key in ("moves", "lens", "winner", "visits"):
+        assert torch.equal(allrec[key], torch.cat([p[key] for p in parts], dim=0)), key
+
+
+def test_gather_single_process_is_identity():
+    rec = _fake_records(2, 5, 3)
+    assert selfplay.gather_records(rec) is rec

@@ -1,0 +1,54 @@
+"""Whole games on the GPU (K3 + gmk_mcts_advance) vs the oracle playing the same games move by move."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gomokuai_amd import lib as G
+from gomokuai_amd import selfplay
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_game(O, game_id, playouts, seed, opening):
+    L = O.lib()
+    b = O.new_board()
+    for mv in opening:
+        L.go_board_apply(C.byref(b), int(mv), 1)
+    moves, visits = list(opening), []
+    while b.cur_player != 0:
+        m = O.MCTS(playouts, 5.0, 5, seed, game_id)        # fresh tree every move (MCTS::reset + syncWithBoard)
+        _, _, v = m.eval_state(b)
+        mv = m.step_forward()
+        visits.append(v)
+        moves.append(mv)
+        L.go_board_apply(C.byref(b), mv, 1)
+    return moves, visits, b.winner
+
+
+@pytest.mark.parametrize("opening_plies", [0, 4])
+def test_games_match_oracle(oracle, opening_plies):
+    n, playouts, seed, first = 5, 40, 99, 300
+    rec = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, opening_plies=opening_plies).cpu()
+    assert not rec.overflow
+    for g in range(n):
+        L = int(rec.lens[g])
+        opening = [int(x) for x in rec.moves[g, :opening_plies]] if opening_plies else []
+        if opening_plies:
+            m, l, _ = G.synth_boards(n, 0, seed=seed, first_board=first)
+            assert opening == [int(x) for x in m[g, :min(int(l[g]), opening_plies)]]
+        moves, visits, winner = _oracle_game(oracle, first + g, playouts, seed, opening)
+        assert [int(x) for x in rec.moves[g, :L]] == moves, "game %d" % g
+        assert int(rec.winner[g]) == winner
+        for t, v in enumerate(visits):
+            assert (rec.visits[g, len(opening) + t].numpy().astype(np.uint32) == v).all()
+
+
+def test_records_do_not_depend_on_sharding():
+    a = selfplay.play_games(6, 30, seed=5, first_game_id=0, record_visits=False).cpu()
+    b1 = selfplay.play_games(2, 30, seed=5, first_game_id=0, record_visits=False).cpu()
+    b2 = selfplay.play_games(4, 30, seed=5, first_game_id=2, record_visits=False).cpu()
+    assert (a.moves[:2] == b1.moves).all() and (a.moves[2:] == b2.moves).all()
+    assert (a.winner[:2] == b1.winner).all() and (a.winner[2:] == b2.winner).all()
+    samples_ok = selfplay.play_games(1, 30, seed=5).samples(0)
+    assert samples_ok[0][0].shape == (6, 15, 15) and len(samples_ok) == int(a.lens[0])
