@@ -7,6 +7,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 if _HERE not in sys.path:
     sys.path.insert(0, _HERE)           # the reference locates CorePyExt through sys.path too (core/bin/__init__.py:20-25)
 
+from . import lib as _lib  # noqa: E402
+_lib.load()                             # brings torch's HIP runtime up first when torch is present (see lib._torch_first)
+
 try:
     from CorePyExt import GameConfig, Player, Position, Board  # noqa: E402,F401
     from CorePyExt import Node, Policy, MCTS  # noqa: E402,F401

@@ -33,11 +33,25 @@ EXPORTS = [
 ]
 
 
+def _torch_first():
+    """PyTorch-ROCm bundles its own copy of the HIP runtime (torch/lib/libamdhip64.so) next to the system one this
+    library links (libamdhip64.so.7).  Both can serve one process, but only when torch's copy brings the GPU up
+    first; the other order leaves torch with "No HIP GPUs are available".  So: initialise torch.cuda before the
+    first HIP call of this library whenever torch is importable (it provides device memory and streams here)."""
+    try:
+        import torch
+    except ImportError:
+        return
+    if torch.cuda.is_available():
+        torch.cuda.init()
+
+
 def load():
     """Loads the HIP library; raises if it has not been built (no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
+    _torch_first()
     if not os.path.exists(_SO):
         raise GmkError("libgomoku_hip.so is missing: run `python -m gomokuai_amd.build` "
                        "(there is no CPU fallback for the compute path)")

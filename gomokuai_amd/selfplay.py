@@ -17,15 +17,16 @@ N = 225
 class GameRecords:
     """Fixed-stride game records: moves u8[n,225], lens i32[n], winner i8[n], visits u16[n,225,225] (optional)."""
 
-    def __init__(self, moves, lens, winner, visits=None, first_game_id=0):
+    def __init__(self, moves, lens, winner, visits=None, first_game_id=0, overflow=False):
         self.moves, self.lens, self.winner, self.visits, self.first_game_id = moves, lens, winner, visits, first_game_id
+        self.overflow = overflow            # a tree arena filled up during some search (results then deviate)
 
     def __len__(self):
         return int(self.lens.shape[0])
 
     def cpu(self):
         return GameRecords(self.moves.cpu(), self.lens.cpu(), self.winner.cpu(),
-                           None if self.visits is None else self.visits.cpu(), self.first_game_id)
+                           None if self.visits is None else self.visits.cpu(), self.first_game_id, self.overflow)
 
     def samples(self, game):
         """The training tuples of one game as `dual_play(verbose=True)` returns them (agents/utils.py:36-40, 55-59):
@@ -88,9 +89,7 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
             break
     status = tree.root_stats()[4]
     tree.close()
-    rec = GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id)
-    rec.overflow = bool((status & 2).any())
-    return rec
+    return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, bool((status & 2).any()))
 
 
 def gather_records(rec, dst=0, group=None):
