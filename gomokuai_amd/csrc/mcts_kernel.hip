@@ -298,17 +298,26 @@ __global__ void mcts_init_roots_kernel(const GameHeader* __restrict__ headers, u
 // agents/utils.py:29-41, and the new root.  One wavefront per game.
 __global__ __launch_bounds__(64)
 void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
-                         uint32_t* __restrict__ parent, size_t cap, int n_games,
+                         uint32_t* __restrict__ parent, uint2* __restrict__ stats2, uint32_t* __restrict__ link2,
+                         uint32_t* __restrict__ parent2, size_t cap, int n_games,
                          uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
                          int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= n_games) return;
     GameHeader& hdr = headers[g];
-    if (hdr.status & 1u) return;                                    // already over
     const size_t base = static_cast<size_t>(g) * cap;
     const uint32_t root = hdr.root, stones = hdr.stones;
     const uint32_t first = link[base + root] >> 8;
-    if (!first) return;                                             // never searched: nothing to play
+    if ((hdr.status & 1u) || !first) {                              // already over, or never searched: nothing to play
+        if (reuse && lane == 0) {                                   // the live arena flips for every game: carry the root over
+            stats2[base] = stats[base + root];
+            link2[base] = link[base + root] & 0xFFu;
+            parent2[base] = kNone;
+            hdr.root = 0;
+            hdr.n_nodes = 1;
+        }
+        return;
+    }
     const int n_child = 225 - static_cast<int>(stones);
     long long best = -1;
     int best_i = 0;
@@ -349,10 +358,7 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
             atomicAdd(unfinished, 1);
         }
         hdr.playouts_done = 0;
-        if (reuse) {                                                // the subtree of the move becomes the tree
-            hdr.root = child;
-            parent[base + child] = kNone;
-        } else {                                                    // MCTS::reset + syncWithBoard: a fresh one-node tree
+        if (!reuse) {                                               // MCTS::reset + syncWithBoard: a fresh one-node tree
             hdr.root = 0;
             hdr.n_nodes = 1;
             stats[base] = make_uint2(0u, 0u);
@@ -360,6 +366,41 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
             parent[base] = kNone;
         }
     }
+    if (!reuse) return;
+
+    // The subtree of the move becomes the tree (updateRoot, MCTS.cpp:63-67); the reference frees the siblings, here
+    // the kept subtree is copied level by level into the other arena so that node indices stay dense.  In the new
+    // arena a node's `link` carries its OLD first-child index until the scan reaches it and copies its children.
+    if (lane == 0) {
+        stats2[base] = stats[base + child];
+        link2[base] = link[base + child];
+        parent2[base] = kNone;
+    }
+    __syncthreads();
+    uint32_t next = 1, level_end = 1;
+    int depth = 0;                                                  // of the nodes being scanned; root = 0
+    for (uint32_t i0 = 0; i0 < next;) {
+        if (i0 == level_end) { ++depth; level_end = next; }
+        const uint32_t chunk = min(64u, level_end - i0);
+        const uint32_t old_first = (static_cast<uint32_t>(lane) < chunk) ? (link2[base + i0 + lane] >> 8) : 0u;
+        unsigned long long todo = __ballot(old_first != 0u);
+        const uint32_t n = 225u - (stones + 1u + static_cast<uint32_t>(depth));     // children of a node at this depth
+        while (todo) {
+            const int j = __ffsll(static_cast<long long>(todo)) - 1;
+            todo &= todo - 1ull;
+            const uint32_t of = __shfl(old_first, j, 64), node = i0 + static_cast<uint32_t>(j);
+            for (uint32_t k = lane; k < n; k += 64) {
+                stats2[base + next + k] = stats[base + of + k];
+                link2[base + next + k] = link[base + of + k];
+                parent2[base + next + k] = node;
+            }
+            if (lane == 0) link2[base + node] = (next << 8) | (link2[base + node] & 0xFFu);
+            next += n;
+        }
+        __syncthreads();                                            // children written above are scanned below
+        i0 += chunk;
+    }
+    if (lane == 0) { hdr.root = 0; hdr.n_nodes = next; }
 }
 
 // children of the root -> visit counts by cell (MCTS::evalState, MCTS.cpp:104-110)
@@ -395,9 +436,12 @@ struct gmk_mcts {
     double c_puct = 5.0;
     uint64_t seed = 0;
     GameHeader* d_headers = nullptr;
-    uint2* d_stats = nullptr;
+    uint2* d_stats = nullptr;          // live arena
     uint32_t* d_link = nullptr;
     uint32_t* d_parent = nullptr;
+    uint2* d_stats2 = nullptr;         // second arena, allocated by the first advance() that keeps subtrees
+    uint32_t* d_link2 = nullptr;
+    uint32_t* d_parent2 = nullptr;
     hipStream_t last_stream = nullptr;
 };
 
@@ -437,6 +481,7 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
 extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     if (!m) return GMK_OK;
     (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent);
+    (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2);
     delete m;
     return GMK_OK;
 }
@@ -485,10 +530,24 @@ extern "C" int gmk_mcts_advance(gmk_mcts* m, uint8_t* d_moves, uint16_t* d_visit
     if (!m || !d_moves || !d_lens || !d_winner || !d_unfinished) { gmk::set_error("gmk_mcts_advance: bad arguments"); return GMK_ERR_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     m->last_stream = s;
+    if (reuse_subtree && !m->d_stats2) {
+        const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
+        if (hipMalloc(&m->d_stats2, nodes * sizeof(uint2)) != hipSuccess || hipMalloc(&m->d_link2, nodes * 4) != hipSuccess ||
+            hipMalloc(&m->d_parent2, nodes * 4) != hipSuccess) {
+            gmk::set_error("gmk_mcts_advance: hipMalloc of the second arena (%zu nodes) failed", nodes);
+            return GMK_ERR_HIP;
+        }
+    }
     GMK_HIP_CHECK(hipMemsetAsync(d_unfinished, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(mcts_advance_kernel, dim3(m->n_games), dim3(64), 0, s, m->d_headers, m->d_stats, m->d_link, m->d_parent,
-                       static_cast<size_t>(m->node_capacity), m->n_games, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree);
+                       m->d_stats2, m->d_link2, m->d_parent2, static_cast<size_t>(m->node_capacity), m->n_games,
+                       d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree);
     GMK_HIP_CHECK(hipGetLastError());
+    if (reuse_subtree) {                                            // the copy is the live tree from here on
+        std::swap(m->d_stats, m->d_stats2);
+        std::swap(m->d_link, m->d_link2);
+        std::swap(m->d_parent, m->d_parent2);
+    }
     return GMK_OK;
 }
 

@@ -73,7 +73,7 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
         for g in range(n_games):
             moves0[g, :lens0[g]] = m[g, :lens0[g]]
             last[g] = m[g, lens0[g] - 1] if lens0[g] > 0 else -1
-    cap = node_capacity if node_capacity is not None else playouts * N * (4 if reuse_subtree else 1) + 1
+    cap = node_capacity if node_capacity is not None else playouts * N * (3 if reuse_subtree else 1) + 1
     tree = G.BatchedMCTS(n_games, c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap)
     tree.set_roots(planes, last, first_game_id)
     d_moves = torch.from_numpy(moves0).to(dev)

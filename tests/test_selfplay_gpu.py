@@ -52,3 +52,34 @@ def test_records_do_not_depend_on_sharding():
     assert (a.winner[:2] == b1.winner).all() and (a.winner[2:] == b2.winner).all()
     samples_ok = selfplay.play_games(1, 30, seed=5).samples(0)
     assert samples_ok[0][0].shape == (6, 15, 15) and len(samples_ok) == int(a.lens[0])
+
+
+def _oracle_game_reuse(O, game_id, playouts, seed):
+    """One MCTS object for the whole game, as agents/mcts.py:17-21 drives it: sync, search, step_forward()."""
+    L = O.lib()
+    b = O.new_board()
+    m = O.MCTS(playouts, 5.0, 5, seed, game_id)
+    moves, visits = [], []
+    while b.cur_player != 0:
+        m.sync_with_board(b)
+        _, _, v = m.eval_state(b)
+        mv = m.step_forward()
+        visits.append(v)
+        moves.append(mv)
+        L.go_board_apply(C.byref(b), mv, 1)
+    return moves, visits, b.winner
+
+
+def test_subtree_reuse_matches_oracle(oracle):
+    """reuse_subtree=1: the chosen child's subtree is the next search's tree (MCTS::stepForward, MCTS.cpp:129-134),
+    without root noise (Default::AddNoise draws from a random_device-seeded std::gamma_distribution: unpinned)."""
+    n, playouts, seed, first = 4, 50, 1234, 40
+    rec = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, reuse_subtree=True).cpu()
+    assert not rec.overflow
+    for g in range(n):
+        moves, visits, winner = _oracle_game_reuse(oracle, first + g, playouts, seed)
+        L = int(rec.lens[g])
+        assert [int(x) for x in rec.moves[g, :L]] == moves, "game %d" % g
+        assert int(rec.winner[g]) == winner
+        for t, v in enumerate(visits):
+            assert (rec.visits[g, t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all()
