@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "capi_common.h"
@@ -41,7 +42,9 @@ struct GameHeader {                 // 128 B per game, in HBM
     uint32_t status;                // bit1: arena full
     uint64_t alg_bytes;             // algorithmic tree bytes of the last run
     uint32_t playouts_done;         // playouts already run from this root (RNG counter word 1 continues across launches)
-    uint32_t pad[7];
+    uint32_t noise;                 // 1: the root's children take their priors from root_prior[] (Default::AddNoise ran)
+    uint32_t root_expanded;         // scratch for gmk_mcts_add_root_noise
+    uint32_t pad[5];
 };
 static_assert(sizeof(GameHeader) == 128, "GameHeader layout");
 
@@ -117,7 +120,7 @@ __device__ int random_rollout(uint32_t* rows /* [y * 64] */, int to_move, int st
 
 __global__ __launch_bounds__(64)
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
-                          uint32_t* __restrict__ parent, SearchParams prm) {
+                          uint32_t* __restrict__ parent, const float* __restrict__ root_prior, SearchParams prm) {
     __shared__ uint32_t s_lane_board[16 * 64];                   // rollout boards, [row][lane]
     __shared__ uint32_t s_leaf[kMaxGamesPerBlock][16];           // leaf position of each game
     __shared__ uint32_t s_cur[kMaxGamesPerBlock], s_ply[kMaxGamesPerBlock], s_last[kMaxGamesPerBlock];
@@ -161,12 +164,16 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     if (!first) break;                               // Node::isLeaf
                     const int n_child = 225 - static_cast<int>(ply);
                     const double n_parent = static_cast<double>(stats[base + cur].x);
-                    const double explore = prm.c_puct * static_cast<double>(c_prior[n_child]) * sqrt(n_parent);   // MonteCarlo.hpp:23-28
+                    const double root_n = sqrt(n_parent);
+                    const double explore = prm.c_puct * static_cast<double>(c_prior[n_child]) * root_n;   // MonteCarlo.hpp:23-28
+                    const bool noisy = hdr.noise && cur == hdr.root;  // only the root's children ever carry non-uniform priors
                     double best = -1.0;
                     int best_i = 0;
                     for (int i = l16; i < n_child; i += 16) {
                         const uint2 st = stats[base + first + i];
-                        const double score = static_cast<double>(__uint_as_float(st.y)) + explore / static_cast<double>(st.x + 1u);
+                        double bonus = explore;
+                        if (noisy) bonus = prm.c_puct * static_cast<double>(root_prior[static_cast<size_t>(game0 + gs) * 225 + i]) * root_n;
+                        const double score = static_cast<double>(__uint_as_float(st.y)) + bonus / static_cast<double>(st.x + 1u);
                         if (score > best) { best = score; best_i = i; }
                     }
 #pragma unroll
@@ -358,6 +365,7 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
             atomicAdd(unfinished, 1);
         }
         hdr.playouts_done = 0;
+        hdr.noise = 0;
         if (!reuse) {                                               // MCTS::reset + syncWithBoard: a fresh one-node tree
             hdr.root = 0;
             hdr.n_nodes = 1;
@@ -403,6 +411,12 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
     if (lane == 0) { hdr.root = 0; hdr.n_nodes = next; }
 }
 
+__global__ void mcts_root_flags_kernel(GameHeader* __restrict__ headers, const uint32_t* __restrict__ link, size_t cap, int n_games) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_games) return;
+    headers[g].root_expanded = (link[static_cast<size_t>(g) * cap + headers[g].root] >> 8) != 0u;
+}
+
 // children of the root -> visit counts by cell (MCTS::evalState, MCTS.cpp:104-110)
 __global__ void mcts_root_stats_kernel(const GameHeader* __restrict__ headers, const uint2* __restrict__ stats,
                                        const uint32_t* __restrict__ link, size_t cap, int n_games,
@@ -442,6 +456,7 @@ struct gmk_mcts {
     uint2* d_stats2 = nullptr;         // second arena, allocated by the first advance() that keeps subtrees
     uint32_t* d_link2 = nullptr;
     uint32_t* d_parent2 = nullptr;
+    float* d_root_prior = nullptr;     // [n_games][225] by child index, used while GameHeader::noise is set
     hipStream_t last_stream = nullptr;
 };
 
@@ -481,7 +496,7 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
 extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     if (!m) return GMK_OK;
     (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent);
-    (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2);
+    (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2); (void)hipFree(m->d_root_prior);
     delete m;
     return GMK_OK;
 }
@@ -520,7 +535,8 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     prm.node_capacity = m->node_capacity; prm.n_games = m->n_games; prm.playouts = playouts;
     const int grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
     m->last_stream = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent, prm);
+    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
+                       m->d_root_prior, prm);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }
@@ -548,6 +564,50 @@ extern "C" int gmk_mcts_advance(gmk_mcts* m, uint8_t* d_moves, uint16_t* d_visit
         std::swap(m->d_link, m->d_link2);
         std::swap(m->d_parent, m->d_parent2);
     }
+    return GMK_OK;
+}
+
+// Default::AddNoise (MonteCarlo.hpp:97-108) for every unfinished game whose root already has children:
+//   P <- (1 - epsilon) * P + epsilon * normalized(gamma(alpha, 1) per child)        (Statistical.hpp:29-34)
+// The draws use the toolchain's own std::gamma_distribution<float> over std::mt19937, exactly the distribution
+// code the reference runs; only the engine's seed differs (the reference: random_device; here: Philox of
+// (seed; game id, stones on the root board, 'nois')), so searches stay reproducible.  Host side: 225 floats a game.
+extern "C" int gmk_mcts_add_root_noise(gmk_mcts* m, float alpha, float epsilon, void* stream) {
+    if (!m || !(alpha > 0.0f)) { gmk::set_error("gmk_mcts_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    m->last_stream = s;
+    const size_t n = static_cast<size_t>(m->n_games);
+    if (!m->d_root_prior) GMK_HIP_CHECK(hipMalloc(&m->d_root_prior, n * 225 * sizeof(float)));
+    hipLaunchKernelGGL(mcts_root_flags_kernel, dim3((m->n_games + 255) / 256), dim3(256), 0, s, m->d_headers, m->d_link,
+                       static_cast<size_t>(m->node_capacity), m->n_games);
+    GMK_HIP_CHECK(hipGetLastError());
+    std::vector<GameHeader> hdr(n);
+    GMK_HIP_CHECK(hipMemcpyAsync(hdr.data(), m->d_headers, sizeof(GameHeader) * n, hipMemcpyDeviceToHost, s));
+    GMK_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<float> prior(n * 225, 0.0f);
+    const uint32_t k0 = static_cast<uint32_t>(m->seed), k1 = static_cast<uint32_t>(m->seed >> 32);
+    for (size_t g = 0; g < n; ++g) {
+        GameHeader& h = hdr[g];
+        h.noise = 0;
+        if ((h.status & 1u) || !h.root_expanded) continue;           // AddNoise is a no-op on a childless root
+        const int n_child = 225 - static_cast<int>(h.stones);
+        float* p = &prior[g * 225];
+        std::mt19937 engine(gmk::philox4x32_10(h.game_id, h.stones, 0x6E6F6973u, 0u, k0, k1).v[0]);
+        std::gamma_distribution<float> gamma(alpha, 1.0f);
+        float noise[225], sq = 0.0f;
+        const float uniform = 1.0f / static_cast<float>(n_child);
+        for (int i = 0; i < n_child; ++i) {
+            p[i] = uniform * (1 - epsilon);                           // prior_probs *= 1 - epsilon
+            noise[i] = p[i] ? gamma(engine) : 0.0f;
+            sq += noise[i] * noise[i];
+        }
+        const float norm = sq > 0.0f ? std::sqrt(sq) : 1.0f;          // VectorXf::normalized()
+        for (int i = 0; i < n_child; ++i) p[i] += epsilon * (sq > 0.0f ? noise[i] / norm : noise[i]);
+        h.noise = 1;
+    }
+    GMK_HIP_CHECK(hipMemcpyAsync(m->d_root_prior, prior.data(), prior.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    GMK_HIP_CHECK(hipMemcpyAsync(m->d_headers, hdr.data(), sizeof(GameHeader) * n, hipMemcpyHostToDevice, s));
+    GMK_HIP_CHECK(hipStreamSynchronize(s));
     return GMK_OK;
 }
 

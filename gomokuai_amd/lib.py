@@ -29,7 +29,7 @@ EXPORTS = [
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
-    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance",
+    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_add_root_noise",
 ]
 
 
@@ -79,6 +79,7 @@ def load():
     L.gmk_mcts_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gmk_visits_to_pi.argtypes = [vp, C.c_int, vp]
     L.gmk_mcts_advance.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.gmk_mcts_add_root_noise.argtypes = [vp, C.c_float, C.c_float, vp]
     _lib = L
     return L
 
@@ -230,6 +231,9 @@ class BatchedMCTS:
     def advance(self, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree=False, stream=None):
         """One self-play move for every unfinished game (device pointers as ints)."""
         _check(load().gmk_mcts_advance(self.h, d_moves, d_visits, d_lens, d_winner, d_unfinished, int(reuse_subtree), stream))
+
+    def add_root_noise(self, alpha=0.05, epsilon=0.25, stream=None):
+        _check(load().gmk_mcts_add_root_noise(self.h, alpha, epsilon, stream))
 
     def alg_bytes(self):
         b = C.c_uint64()

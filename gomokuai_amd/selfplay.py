@@ -55,7 +55,8 @@ class GameRecords:
 
 
 def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5.0, c_rollouts=5,
-               opening_plies=0, record_visits=True, reuse_subtree=False, max_moves=N, device=None, node_capacity=None):
+               opening_plies=0, record_visits=True, reuse_subtree=False, root_noise=None, max_moves=N, device=None,
+               node_capacity=None):
     """Plays n_games complete games on the current GPU: every move = one K3 search of `playouts` playouts for all
     unfinished games, then `gmk_mcts_advance`.  Game g uses the global id first_game_id + g for its RNG streams, so
     the records do not depend on how games are spread over GPUs."""
@@ -82,6 +83,8 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev) if record_visits else None
     d_unfinished = torch.ones(1, dtype=torch.int32, device=dev)
     for _ in range(max_moves):
+        if root_noise is not None and reuse_subtree:      # Default::AddNoise at the start of every search (MCTS.cpp:182)
+            tree.add_root_noise(root_noise[0], root_noise[1], stream)
         tree.run(playouts, stream)
         tree.advance(d_moves.data_ptr(), d_visits.data_ptr() if record_visits else None, d_lens.data_ptr(),
                      d_winner.data_ptr(), d_unfinished.data_ptr(), reuse_subtree, stream)

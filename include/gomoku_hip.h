@@ -129,6 +129,11 @@ int gmk_mcts_run(gmk_mcts *m, int playouts, void *stream);
  * Finished games are skipped by later gmk_mcts_run calls. */
 int gmk_mcts_advance(gmk_mcts *m, uint8_t *d_moves, uint16_t *d_visits, int32_t *d_lens, int8_t *d_winner,
                      int32_t *d_unfinished, int reuse_subtree, void *stream);
+/* Default::AddNoise (MonteCarlo.hpp:97-108, Statistical.hpp:29-34) on every unfinished game whose root has children:
+ * P <- (1-epsilon) P + epsilon * normalized(gamma(alpha,1)); the reference calls it at the start of every runPlayouts
+ * (MCTS.cpp:182) with alpha 0.05, epsilon 0.25.  No-op for childless (fresh) roots.  The priors stay in force until the
+ * next gmk_mcts_advance / gmk_mcts_set_roots.  Synchronises `stream`. */
+int gmk_mcts_add_root_noise(gmk_mcts *m, float alpha, float epsilon, void *stream);
 /* Root statistics after a run (synchronises the stream used by the last run):
  *   h_visits uint32[n][225] child visit counts by cell (MCTS::evalState, MCTS.cpp:104-110),
  *   h_root_value float[n], h_root_visits uint32[n], h_nodes uint32[n] (MCTS::m_size), h_status int32[n] (bit1: arena full). */

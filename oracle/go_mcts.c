@@ -67,7 +67,10 @@ struct go_mcts {
     uint64_t alg_bytes;
     int      use_mt;
     go_mt19937 mt;
+    float    noise_alpha, noise_epsilon;      /* alpha == 0: AddNoise disabled */
 };
+
+void go__gamma_draws(unsigned seed, float alpha, int n, float *out);     /* go_stdsort.cpp */
 
 static int32_t new_node(go_mcts *m, int parent, int pos, int player, float value, float prob) {
     if (m->n == m->cap) { m->cap = m->cap ? 2 * m->cap : 4096; m->nodes = (mnode *)realloc(m->nodes, sizeof(mnode) * (size_t)m->cap); }
@@ -226,11 +229,31 @@ static size_t playout(go_mcts *m, go_board *b, uint32_t idx) {
     return expand_size;
 }
 
-/* MCTS.cpp:179-198 (iteration constraint).  Default::AddNoise (MonteCarlo.hpp:97-108) is a no-op on a
-   childless root; for a root with children the reference draws std::gamma_distribution<float> from a
-   random_device-seeded engine (implementation-defined): not restated here, roots are searched without noise. */
+/* MCTS.cpp:179-198 (iteration constraint). */
+/* Default::AddNoise (MonteCarlo.hpp:97-108) + Stats::DirichletNoise (Statistical.hpp:29-34).  The engine is
+   std::mt19937 seeded with Philox(game, stones, 'nois') instead of random_device. */
+static void add_noise(go_mcts *m, const go_board *b) {
+    mnode *root = &m->nodes[m->root];
+    if (!(m->noise_alpha > 0.0f) || root->n_children == 0) return;
+    float prior[GO_N], noise[GO_N], draws[GO_N], sq = 0.0f;
+    uint32_t ctr[4] = { m->game_id, (uint32_t)b->nrec, 0x6E6F6973u, 0u }, key[2] = { (uint32_t)m->seed, (uint32_t)(m->seed >> 32) }, w[4];
+    int k = 0;
+    for (int i = 0; i < GO_N; ++i) prior[i] = 0.0f;
+    for (int i = 0; i < root->n_children; ++i) prior[m->nodes[root->first_child + i].position] = m->nodes[root->first_child + i].action_prob;
+    for (int i = 0; i < GO_N; ++i) prior[i] *= 1 - m->noise_epsilon;
+    go_philox4x32(ctr, key, w);
+    go__gamma_draws(w[0], m->noise_alpha, root->n_children, draws);
+    for (int i = 0; i < GO_N; ++i) { noise[i] = prior[i] ? draws[k++] : 0.0f; sq += noise[i] * noise[i]; }
+    if (sq > 0.0f) { float nrm = sqrtf(sq); for (int i = 0; i < GO_N; ++i) noise[i] = noise[i] / nrm; }
+    for (int i = 0; i < GO_N; ++i) prior[i] += m->noise_epsilon * noise[i];
+    for (int i = 0; i < root->n_children; ++i) m->nodes[root->first_child + i].action_prob = prior[m->nodes[root->first_child + i].position];
+}
+
+void go_mcts_set_noise(go_mcts *m, float alpha, float epsilon) { m->noise_alpha = alpha; m->noise_epsilon = epsilon; }
+
 void go_mcts_run_playouts(go_mcts *m, go_board *b) {
     go_mcts_sync_with_board(m, b);
+    add_noise(m, b);                                             /* MCTS.cpp:182 */
     m->init_acts = b->nrec;                                      /* Policy::prepare */
     for (uint64_t i = 0; i < m->iterations; ++i) m->size += playout(m, b, (uint32_t)i);
     go_board_revert(b, b->nrec - m->init_acts);                  /* Policy::cleanup */

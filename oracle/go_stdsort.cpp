@@ -13,3 +13,15 @@ extern "C" void go__std_sort_indices(const int *codes, int *indices, int n) {
     std::iota(indices, indices + n, 0);
     std::sort(indices, indices + n, [codes](int lhs, int rhs) { return codes[lhs] < codes[rhs]; });
 }
+
+/*
+ * Default::AddNoise draws from std::gamma_distribution<float>(alpha, 1) over std::mt19937
+ * (core/lib/include/algorithms/Statistical.hpp:24-34); the distribution's algorithm is implementation-defined,
+ * so the oracle calls the toolchain's own template, as a g++ build of the reference does.
+ */
+#include <random>
+extern "C" void go__gamma_draws(unsigned seed, float alpha, int n, float *out) {
+    std::mt19937 engine(seed);
+    std::gamma_distribution<float> gamma(alpha, 1.0f);
+    for (int i = 0; i < n; ++i) out[i] = gamma(engine);
+}

@@ -146,6 +146,8 @@ float go_mcts_root_value(const go_mcts *m);
 void go_mcts_root_children(const go_mcts *m, uint32_t *visits /*[225]*/, float *values /*[225]*/, float *priors /*[225]*/);
 /* instrumentation for the roofline: algorithmic bytes touched by tree ops since reset */
 uint64_t go_mcts_alg_bytes(const go_mcts *m);
+/* Default::AddNoise at the start of every search (MCTS.cpp:182); alpha = 0 (default) disables it. */
+void go_mcts_set_noise(go_mcts *m, float alpha, float epsilon);
 /* KAT hook: draw rollout moves sequentially from std::mt19937(seed) (id = eng() % 225) instead of Philox,
    to replay the search recorded in SURVEY.md Appendix B.2. */
 void go_mcts_use_mt19937(go_mcts *m, uint32_t seed);

@@ -107,6 +107,8 @@ def lib():
     L.go_mcts_root_children.restype = None
     L.go_mcts_alg_bytes.argtypes = [C.c_void_p]
     L.go_mcts_alg_bytes.restype = C.c_uint64
+    L.go_mcts_set_noise.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    L.go_mcts_set_noise.restype = None
     L.go_visits_to_pi.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.go_visits_to_pi.restype = None
     _lib = L
@@ -242,6 +244,9 @@ class MCTS:
         if getattr(self, "h", None):
             self.L.go_mcts_free(self.h)
             self.h = None
+
+    def set_noise(self, alpha, epsilon):
+        self.L.go_mcts_set_noise(self.h, alpha, epsilon)
 
     def eval_state(self, board):
         probs = np.zeros(N, dtype=np.float32)

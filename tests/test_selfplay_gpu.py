@@ -54,11 +54,13 @@ def test_records_do_not_depend_on_sharding():
     assert samples_ok[0][0].shape == (6, 15, 15) and len(samples_ok) == int(a.lens[0])
 
 
-def _oracle_game_reuse(O, game_id, playouts, seed):
+def _oracle_game_reuse(O, game_id, playouts, seed, noise=None):
     """One MCTS object for the whole game, as agents/mcts.py:17-21 drives it: sync, search, step_forward()."""
     L = O.lib()
     b = O.new_board()
     m = O.MCTS(playouts, 5.0, 5, seed, game_id)
+    if noise:
+        m.set_noise(*noise)
     moves, visits = [], []
     while b.cur_player != 0:
         m.sync_with_board(b)
@@ -83,3 +85,22 @@ def test_subtree_reuse_matches_oracle(oracle):
         assert int(rec.winner[g]) == winner
         for t, v in enumerate(visits):
             assert (rec.visits[g, t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all()
+
+
+def test_root_noise_matches_oracle(oracle):
+    """The reference's self-play configuration: subtree reuse + Default::AddNoise(alpha 0.05, epsilon 0.25) at the
+    start of every search (MCTS.cpp:182).  Same std::gamma_distribution<float> on both sides, Philox-derived seeds."""
+    n, playouts, seed, first = 3, 50, 77, 900
+    rec = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, reuse_subtree=True, root_noise=(0.05, 0.25)).cpu()
+    plain = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, reuse_subtree=True).cpu()
+    assert not rec.overflow
+    differs = False
+    for g in range(n):
+        moves, visits, winner = _oracle_game_reuse(oracle, first + g, playouts, seed, noise=(0.05, 0.25))
+        L = int(rec.lens[g])
+        assert [int(x) for x in rec.moves[g, :L]] == moves, "game %d" % g
+        assert int(rec.winner[g]) == winner
+        for t, v in enumerate(visits):
+            assert (rec.visits[g, t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all()
+        differs |= [int(x) for x in plain.moves[g, :int(plain.lens[g])]] != moves
+    assert differs                      # the noise does change the games
