@@ -29,12 +29,12 @@ namespace {
 constexpr int kBoardsPerBlock = 4;
 constexpr int kThreads = 64 * kBoardsPerBlock;
 constexpr int kCells = 225;
-constexpr int kQueueCap = 512;
-constexpr int kMaxBlocksPerCu = 3;
+constexpr int kQueueCap = 384;
+constexpr int kMaxBlocksPerCu = 4;
 
 // per-board LDS region (32-bit words)
 constexpr int kScoreWords = 4 * kCells;          // 900, 16-byte aligned block
-constexpr int kCntWords = 3 * kCells;            // per cell: LiveThree, DeadThree, LiveTwo words; 4-bit fields [colour][dir]
+constexpr int kCntWords = 2 * kCells;            // per cell 2 words: [LiveThree | DeadThree << 16], [LiveTwo]; 2-bit fields [colour][dir]: bit0 ">= 1", bit1 ">= 2"
 constexpr int kRowWords = 16;                    // black | white << 16 per row
 constexpr int kMiscWords = 16;                   // [0] queue count, [1] winner bits, [2] error, [3] second queue count, [4..14] totals
 constexpr int kBoardWords = (kScoreWords + kCntWords + kRowWords + kQueueCap + kMiscWords + 3) & ~3;   // keeps each board's score block 16-byte aligned
@@ -66,6 +66,16 @@ __device__ __forceinline__ void block_density(const uint32_t win[7], int& count,
     count = __popc(p3 & 0x4949u) + __popc(p2 & 0x3E3Eu) + __popc(p1 & 0x3E3Eu) + __popc(p0 & 0x77u);
 }
 
+// Phases of one board only exchange data between lanes of the SAME wavefront through LDS.  LDS instructions of
+// one wave execute in issue order, so all that is needed between phases is that the compiler keeps the order:
+// a wavefront-scope fence (no instruction) instead of a workgroup barrier, which would make the four
+// independent boards of a block wait for each other at every phase.
+__device__ __forceinline__ void wave_phase_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(kThreads)
 void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int iterations,
                            int32_t* __restrict__ out_scores, int32_t* __restrict__ out_density,
@@ -89,6 +99,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     uint32_t* s_queue = s_rows + kRowWords;
     uint32_t* s_misc = s_queue + kQueueCap;
 
+    __syncthreads();                                         // tables staged; from here on waves never wait for each other
     const uint32_t job_a = c_lane_jobs[lane * 2], job_b = c_lane_jobs[lane * 2 + 1];
     const int scan_steps = c_scan_steps;
 
@@ -105,7 +116,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                           (static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + 16 + lane]) << 16);
             s_rows[lane] = w;
         }
-        __syncthreads();
+        wave_phase_fence();
 
         // ---- phase 1: walk the DFA along this lane's lines, queue the matches ----
         {
@@ -140,7 +151,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 }
             }
         }
-        __syncthreads();
+        wave_phase_fence();
 
         // ---- phase 2: one lane per match: score deposits (Pattern.cpp:138-165) ----
         {
@@ -163,12 +174,16 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     atomicAdd(&s_scores[g_opp * kCells + c], score);
                     if (kind == 1) {
                         atomicAdd(&s_scores[g_own * kCells + c], score);
-                        if (tslot >= 0) atomicAdd(&s_cnt[c * 3 + tslot], 1u << (4 * (fav * 4 + dir)));
+                        if (tslot >= 0) {                                                   // saturating count 0 / 1 / >= 2
+                            uint32_t* word = &s_cnt[c * 2 + (tslot >> 1)];
+                            const uint32_t bit = 1u << (16 * (tslot & 1) + 2 * (fav * 4 + dir));
+                            if (atomicOr(word, bit) & bit) atomicOr(word, bit << 1);
+                        }
                     }
                 }
             }
         }
-        __syncthreads();
+        wave_phase_fence();
 
         // ---- phase 3: one lane per cell: density stencil, area bonus, compound decision ----
         for (int q = lane; q < kCells; q += 64) {
@@ -200,24 +215,18 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             if (occupied) continue;
             // compound patterns (Pattern.cpp:167-197, 420-486): per colour, counters of '_' pieces of
             // LiveThree / DeadThree / LiveTwo on this cell per direction, saturated at 2
-            const uint32_t c_l3 = s_cnt[q * 3], c_d3 = s_cnt[q * 3 + 1], c_l2 = s_cnt[q * 3 + 2];
-            if (!(c_l3 | c_d3 | c_l2)) continue;
+            const uint32_t cw0 = s_cnt[q * 2], cw1 = s_cnt[q * 2 + 1];
+            if (!(cw0 | cw1)) continue;
             for (int c = 0; c < 2; ++c) {
-                const uint32_t f_l3 = (c_l3 >> (16 * c)) & 0xFFFFu, f_d3 = (c_d3 >> (16 * c)) & 0xFFFFu, f_l2 = (c_l2 >> (16 * c)) & 0xFFFFu;
+                // 2-bit fields per direction: 00 none, 01 one, 11 two or more (= the reference's flag encoding, Pattern.cpp:395-400)
+                const uint32_t f_l3 = (cw0 >> (8 * c)) & 0xFFu, f_d3 = (cw0 >> (16 + 8 * c)) & 0xFFu, f_l2 = (cw1 >> (8 * c)) & 0xFFu;
                 if (!(f_l3 | f_d3 | f_l2) || cnt_c[c] < 2) continue;
-                int marks = 0;                              // number of set flag bits over the four directions
-                for (int d = 0; d < 4; ++d) {
-                    const int k = max(max(min(static_cast<int>((f_l3 >> (4 * d)) & 15u), 2), min(static_cast<int>((f_d3 >> (4 * d)) & 15u), 2)),
-                                      min(static_cast<int>((f_l2 >> (4 * d)) & 15u), 2));
-                    marks += k;
-                }
-                if (marks < 2) continue;
+                if (__popc(f_l3 | f_d3 | f_l2) < 2) continue;       // Compound::Test (Pattern.cpp:424-433)
                 // state machine S0,L2,LD3,To33,To43,To44 = 0..5 (Pattern.cpp:440-486)
                 int state = 0, l3 = 0, triple = 0, n_comp = 0;
                 uint32_t comps = 0;                         // 4 bits per component: dir | tslot << 2
                 for (int d = 0; d < 4; ++d) {
-                    const int k3 = min(static_cast<int>((f_l3 >> (4 * d)) & 15u), 2), kd = min(static_cast<int>((f_d3 >> (4 * d)) & 15u), 2),
-                              k2 = min(static_cast<int>((f_l2 >> (4 * d)) & 15u), 2);
+                    const int k3 = __popc((f_l3 >> (2 * d)) & 3u), kd = __popc((f_d3 >> (2 * d)) & 3u), k2 = __popc((f_l2 >> (2 * d)) & 3u);
                     const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
                     if (t < 0) continue;
                     const int k = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
@@ -245,7 +254,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 }
             }
         }
-        __syncthreads();
+        wave_phase_fence();
 
         // ---- phase 4: one lane per compound component: first match of its type through the cell
         //      (Compound::updateAntis, Pattern.cpp:520-543) ----
@@ -283,7 +292,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 }
             }
         }
-        __syncthreads();
+        wave_phase_fence();
 
         // ---- phase 5: results leave LDS ----
         if (live) {
@@ -304,7 +313,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 out_status[board] = (over ? 1 : 0) | (s_misc[2] ? 2 : 0) | ((winner & 0xFF) << 8) | ((to_move & 0xFF) << 16);
             }
         }
-        __syncthreads();
+        wave_phase_fence();
     }
 }
 
