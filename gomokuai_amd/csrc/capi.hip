@@ -1,6 +1,7 @@
 // capi.hip -- library lifecycle + pattern-table accessors of the C-ABI (include/gomoku_hip.h).
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "capi_common.h"
 
@@ -48,7 +49,10 @@ extern "C" int gmk_init(int device) {
     GMK_HIP_CHECK(hipMalloc(&st.d_trans, t.trans.size() * sizeof(uint32_t)));
     GMK_HIP_CHECK(hipMalloc(&st.d_emit, t.emit_lists.size() * sizeof(uint16_t)));
     GMK_HIP_CHECK(hipMalloc(&st.d_pattern_info, t.pattern_info.size() * sizeof(uint32_t)));
-    GMK_HIP_CHECK(hipMemcpy(st.d_trans, t.trans.data(), t.trans.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // device form of a transition word: bits 0..13 byte offset of the next state's row (state * 16), bits 14.. emission list
+    std::vector<uint32_t> dev_trans(t.trans.size());
+    for (size_t i = 0; i < t.trans.size(); ++i) dev_trans[i] = ((t.trans[i] & 1023u) * 16u) | ((t.trans[i] >> 10) << 14);
+    GMK_HIP_CHECK(hipMemcpy(st.d_trans, dev_trans.data(), dev_trans.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     GMK_HIP_CHECK(hipMemcpy(st.d_emit, t.emit_lists.data(), t.emit_lists.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     GMK_HIP_CHECK(hipMemcpy(st.d_pattern_info, t.pattern_info.data(), t.pattern_info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     st.ready = true;

@@ -29,17 +29,19 @@ namespace {
 constexpr int kBoardsPerBlock = 4;
 constexpr int kThreads = 64 * kBoardsPerBlock;
 constexpr int kCells = 225;
-constexpr int kQueueCap = 384;
+constexpr int kQueueCap = 316;
 constexpr int kMaxBlocksPerCu = 4;
 
 // per-board LDS region (32-bit words)
 constexpr int kScoreWords = 4 * kCells;          // 900, 16-byte aligned block
 constexpr int kCntWords = 2 * kCells;            // per cell 2 words: [LiveThree | DeadThree << 16], [LiveTwo]; 2-bit fields [colour][dir]: bit0 ">= 1", bit1 ">= 2"
-constexpr int kRowWords = 16;                    // black | white << 16 per row
+constexpr int kRowWords = 92;                    // line words, black | white << 16, bit = position along the line:
+                                                 // rows [0,15), columns [16,31), diagonals x-y+14 at [32,61), anti-diagonals x+y at [61,90)
+constexpr int kColBase = 16, kDiagBase = 32, kAntiBase = 61;
 constexpr int kMiscWords = 16;                   // [0] queue count, [1] winner bits, [2] error, [3] second queue count, [4..14] totals
 constexpr int kBoardWords = (kScoreWords + kCntWords + kRowWords + kQueueCap + kMiscWords + 3) & ~3;   // keeps each board's score block 16-byte aligned
 
-// Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid.
+// Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
 __constant__ int c_scan_steps;
 
@@ -66,6 +68,32 @@ __device__ __forceinline__ void block_density(const uint32_t win[7], int& count,
     count = __popc(p3 & 0x4949u) + __popc(p2 & 0x3E3Eu) + __popc(p1 & 0x3E3Eu) + __popc(p0 & 0x77u);
 }
 
+// spreads the low 15 bits of v to the even bit positions
+__device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+// A line word (black | white << 16, bit = position) -> the DFA's symbol stream, 2 bits per symbol, first symbol in
+// the low bits: '?' (2), the len cells (0 black, 1 white, 3 blank), '?', '?'  (1 leading + 2 trailing pads).
+__device__ __forceinline__ uint64_t line_symbols(uint32_t lw, int len) {
+    const uint32_t in_line = (1u << len) - 1u;
+    const uint32_t black = lw & 0x7FFFu, white = lw >> 16;
+    const uint32_t lo = ~black & in_line, hi = ~(black | white) & in_line;      // blank 11, white 01, black 00
+    const uint64_t cells = static_cast<uint64_t>(spread_bits(lo) | (spread_bits(hi) << 1));
+    return 2ull | (cells << 2) | (0xAull << (2 * len + 2));
+}
+
+// queue entries carry dir << 10 | (cell + 16) << 12; the scan keeps the entry of the CURRENT symbol in a register
+__device__ __forceinline__ uint32_t queue_entry_step(uint32_t job) { return static_cast<uint32_t>(dir_stride((job >> 12) & 3)) << 12; }
+__device__ __forceinline__ uint32_t queue_entry_base(uint32_t job) {
+    const int x0 = (job >> 4) & 15, y0 = (job >> 8) & 15, dir = (job >> 12) & 3;
+    return (static_cast<uint32_t>(dir) << 10) | (static_cast<uint32_t>(y0 * 15 + x0 - dir_stride(dir) + 16) << 12);   // symbol 0 is the leading pad
+}
+
 // Phases of one board only exchange data between lanes of the SAME wavefront through LDS.  LDS instructions of
 // one wave execute in issue order, so all that is needed between phases is that the compiler keeps the order:
 // a wavefront-scope fence (no instruction) instead of a workgroup barrier, which would make the four
@@ -81,7 +109,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                            int32_t* __restrict__ out_scores, int32_t* __restrict__ out_density,
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint16_t* __restrict__ g_emit,
-                           const uint32_t* __restrict__ g_pinfo, int trans_words, int emit_words, int pinfo_words) {
+                           const uint32_t* __restrict__ g_pinfo, int trans_words, int emit_words, int pinfo_words,
+                           int phase_mask /* profiling aid: bit p runs phase p; 0x3F in production */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [boards: kBoardsPerBlock * kBoardWords][trans][pinfo][emit (u16)]
     uint32_t* s_trans = lds + kBoardsPerBlock * kBoardWords;
@@ -107,58 +136,80 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         const int board = (it * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave;
         const bool live = board < n_boards;
 
-        // ---- phase 0: clear accumulators, fetch the two bit-planes (64 B) ----
+        // ---- phase 0: clear accumulators, fetch the two bit-planes (64 B), transpose them into line words ----
         for (int i = lane; i < kScoreWords + kCntWords; i += 64) s_scores[i] = 0;
         if (lane < kMiscWords) s_misc[lane] = 0;
-        if (lane < 16) {
-            uint32_t w = 0;
-            if (live) w = static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + lane]) |
-                          (static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + 16 + lane]) << 16);
-            s_rows[lane] = w;
-        }
+        uint32_t my_row = 0;
+        if (lane < 16 && live) my_row = static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + lane]) |
+                                        (static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + 16 + lane]) << 16);
+        for (int i = lane; i < kRowWords; i += 64) s_rows[i] = (i < 16) ? my_row : 0u;
         wave_phase_fence();
-
-        // ---- phase 1: walk the DFA along this lane's lines, queue the matches ----
-        {
-            uint32_t job = job_a;
-            bool second_done = false;
-            int pos = -1;                                  // one leading '?', two trailing
-            uint32_t state = 0;
-            for (int step = 0; step < scan_steps; ++step) {
-                if (!(job & 0x4000u)) break;
-                const int len = job & 15, x0 = (job >> 4) & 15, y0 = (job >> 8) & 15, dir = (job >> 12) & 3;
-                int sym = 2;
-                if (pos >= 0 && pos < len) sym = cell_symbol(s_rows, x0 + pos * dir_dx(dir), y0 + pos * dir_dy(dir));
-                const uint32_t tw = s_trans[state * 4 + sym];
-                state = tw & 1023u;
-                const uint32_t li = tw >> 10;
-                if (li) {
-                    const int cnt = s_emit[li];
-                    for (int e = 0; e < cnt; ++e) {
-                        const uint32_t v = s_emit[li + 1 + e];
-                        const int endpos = pos - static_cast<int>(v >> 15);
-                        const int endcell = y0 * 15 + x0 + endpos * dir_stride(dir);
-                        const uint32_t slot = atomicAdd(&s_misc[0], 1u);
-                        if (slot < kQueueCap) s_queue[slot] = (v & 0x1FFu) | (static_cast<uint32_t>(dir) << 9) | (static_cast<uint32_t>(endcell + 16) << 11);
-                        else s_misc[2] = 1;
-                    }
-                }
-                if (++pos == len + 2) {
-                    job = second_done ? 0u : job_b;
-                    second_done = true;
-                    pos = -1;
-                    state = 0;
-                }
+        if (lane < 15) {                                            // lane y owns row y: one OR per stone into the 3 other line words
+            const int y = lane;
+            for (uint32_t m = (my_row | (my_row >> 16)) & 0x7FFFu; m; m &= m - 1u) {
+                const int x = __ffs(m) - 1;
+                const uint32_t cb = ((my_row >> x) & 1u) ? 0u : 16u;
+                atomicOr(&s_rows[kColBase + x], 1u << (y + cb));
+                atomicOr(&s_rows[kDiagBase + x - y + 14], 1u << (min(x, y) + cb));
+                atomicOr(&s_rows[kAntiBase + x + y], 1u << (min(14 - x, y) + cb));
             }
         }
         wave_phase_fence();
 
-        // ---- phase 2: one lane per match: score deposits (Pattern.cpp:138-165) ----
-        {
-            const int n_match = min(static_cast<int>(s_misc[0]), kQueueCap);
-            for (int m = lane; m < n_match; m += 64) {
-                const uint32_t ent = s_queue[m];
-                const int pat = ent & 0x1FF, dir = (ent >> 9) & 3, endcell = static_cast<int>(ent >> 11) - 16;
+        // ---- phase 1: walk the DFA along this lane's lines; transitions that emit go to the queue ----
+        // Per job the line is turned once into a stream of 2-bit DFA symbols in a 64-bit register ('?', cells, '?', '?'),
+        // so a step is: take 2 bits, one LDS lookup trans[state][sym] (the word holds the next row's byte offset), done.
+        // The queue slot comes from a ballot prefix (this wave is the only producer): no returning atomic in the loop;
+        // emission lists are expanded in phase 2.
+        int n_queued = 0;                                       // wave-uniform
+        if (phase_mask & 2) {
+            uint32_t job = job_a;
+            bool second_done = false;
+            uint64_t syms = line_symbols(s_rows[(job >> 16) & 127u], job & 15);
+            int steps_left = (job & 0x4000u) ? static_cast<int>(job & 15u) + 3 : 0;
+            uint32_t row_off = 0;                               // byte offset of the current state's row in trans[]
+            uint32_t entry = queue_entry_base(job);             // dir << 10 | (cell of the current symbol + 16) << 12
+            const char* trans_bytes = reinterpret_cast<const char*>(s_trans);
+            for (int step = 0; step < scan_steps; ++step) {
+                const uint32_t sym = static_cast<uint32_t>(syms) & 3u;
+                syms >>= 2;
+                const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym * 4u);
+                row_off = tw & 0x3FFFu;
+                const uint32_t li = steps_left > 0 ? (tw >> 14) : 0u;
+                const unsigned long long emitters = __ballot(li != 0u);
+                if (emitters) {
+                    if (li) {
+                        const int slot = n_queued + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
+                                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u)));
+                        if (slot < kQueueCap) s_queue[slot] = entry | li;
+                    }
+                    n_queued += __popcll(emitters);
+                }
+                entry += queue_entry_step(job);
+                if (--steps_left == 0 && !second_done) {       // the short second line of this lane, if it has one
+                    second_done = true;
+                    job = job_b;
+                    syms = line_symbols(s_rows[(job >> 16) & 127u], job & 15);
+                    steps_left = (job & 0x4000u) ? static_cast<int>(job & 15u) + 3 : 0;
+                    row_off = 0;
+                    entry = queue_entry_base(job);
+                }
+            }
+            if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
+        }
+        wave_phase_fence();
+
+        // ---- phase 2: one lane per emitting transition: its 1-2 matches' score deposits (Pattern.cpp:138-165) ----
+        if (phase_mask & 4) {
+            for (int m = lane; m < n_queued; m += 64) {
+              const uint32_t qe = s_queue[m];
+              const uint32_t li = qe & 1023u;
+              const int dir = (qe >> 10) & 3, cell_at = static_cast<int>(qe >> 12) - 16;
+              const int stride = dir_stride(dir);
+              const int n_emit = s_emit[li];
+              for (int e = 0; e < n_emit; ++e) {
+                const uint32_t v = s_emit[li + 1 + e];
+                const int pat = v & 0x1FF, endcell = cell_at - static_cast<int>(v >> 15) * stride;   // "back" emissions end one symbol earlier
                 const uint32_t w0 = s_pinfo[2 * pat], w1 = s_pinfo[2 * pat + 1];
                 const int type = w0 & 15, fav = (w0 >> 4) & 1, len = (w0 >> 5) & 7;
                 if (type == 8) { atomicOr(&s_misc[1], fav ? 1u : 2u); continue; }       // Five: winner only
@@ -166,7 +217,6 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 const uint32_t score = dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu);
                 const int g_own = fav ? 3 : 0, g_opp = fav ? 2 : 1;                     // Pattern.h:159-161
                 const int tslot = type == 5 ? 0 : type == 4 ? 1 : type == 3 ? 2 : -1;   // LiveThree, DeadThree, LiveTwo
-                const int stride = dir_stride(dir);
                 for (int j = 0; j < len; ++j) {
                     const uint32_t kind = (w0 >> (8 + 2 * j)) & 3u;
                     if (!kind) continue;
@@ -181,11 +231,13 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                         }
                     }
                 }
+              }
             }
         }
         wave_phase_fence();
 
         // ---- phase 3: one lane per cell: density stencil, area bonus, compound decision ----
+        if (phase_mask & 8)
         for (int q = lane; q < kCells; q += 64) {
             const int x = q % 15, y = q / 15;
             uint32_t win_w[7], win_b[7];
@@ -258,21 +310,32 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
 
         // ---- phase 4: one lane per compound component: first match of its type through the cell
         //      (Compound::updateAntis, Pattern.cpp:520-543) ----
-        {
+        if (phase_mask & 16) {
             const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap);
             for (int m = lane; m < n_comp; m += 64) {
                 const uint32_t ent = s_queue[m];
                 const int q = ent & 255, c = (ent >> 8) & 1, dir = (ent >> 9) & 3, tslot = (ent >> 11) & 3;
                 const int want = tslot == 0 ? 5 : tslot == 1 ? 4 : 3;
-                const int x = q % 15, y = q / 15, dx = dir_dx(dir), dy = dir_dy(dir), stride = dir_stride(dir);
-                uint32_t state = 0;
+                const int x = q % 15, y = q / 15, stride = dir_stride(dir);
+                // the line through q in this direction: its word, q's position on it, its length
+                const int diag = x - y + 14, anti = x + y;
+                const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
+                const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
+                const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
+                const uint32_t lw = s_rows[line];
+                uint32_t row_off = 0;
                 bool found = false;
                 for (int k = 0; k < 13 && !found; ++k) {
-                    const int sym = cell_symbol(s_rows, x + (k - 6) * dx, y + (k - 6) * dy);
-                    const uint32_t tw = s_trans[state * 4 + sym];
-                    state = tw & 1023u;
-                    const uint32_t li = tw >> 10;
-                    if (!li) continue;
+                    const int p = at + k - 6;
+                    int sym = 2;
+                    if (static_cast<unsigned>(p) < static_cast<unsigned>(len)) {
+                        const uint32_t t = lw >> p;
+                        sym = (t & 1u) ? 0 : (t & 0x10000u) ? 1 : 3;
+                    }
+                    const uint32_t tw = s_trans[(row_off >> 2) + sym];
+                    row_off = tw & 0x3FFFu;
+                    const uint32_t li = tw >> 14;
+                    if (!li || k < 6) continue;                              // a match covering q ends at window index >= 6
                     const int cnt = s_emit[li];
                     for (int e = 0; e < cnt && !found; ++e) {
                         const uint32_t v = s_emit[li + 1 + e];
@@ -295,7 +358,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         wave_phase_fence();
 
         // ---- phase 5: results leave LDS ----
-        if (live) {
+        if (live && (phase_mask & 32)) {
             if (out_scores) {
                 int4* dst = reinterpret_cast<int4*>(out_scores + static_cast<size_t>(board) * kScoreWords);
                 const int4* src = reinterpret_cast<const int4*>(s_scores);
@@ -328,7 +391,10 @@ int upload_lane_jobs() {
     for (int k = 4; k <= 24; ++k) { const int x0 = std::min(k, 14); lines.push_back({std::min(k, 28 - k) + 1, x0, k - x0, 3}); }
     std::stable_sort(lines.begin(), lines.end(), [](const LineJob& a, const LineJob& b) { return a.len > b.len; });
     uint32_t jobs[128] = {};
-    auto pack = [](const LineJob& l) { return static_cast<uint32_t>(l.len | (l.x0 << 4) | (l.y0 << 8) | (l.dir << 12) | 0x4000); };
+    auto pack = [](const LineJob& l) {
+        const int line = l.dir == 0 ? l.y0 : l.dir == 1 ? kColBase + l.x0 : l.dir == 2 ? kDiagBase + l.x0 - l.y0 + 14 : kAntiBase + l.x0 + l.y0;
+        return static_cast<uint32_t>(l.len | (l.x0 << 4) | (l.y0 << 8) | (l.dir << 12) | 0x4000 | (line << 16));
+    };
     int steps = 0;
     for (int lane = 0; lane < 64; ++lane) {
         jobs[lane * 2] = pack(lines[lane]);
@@ -338,6 +404,7 @@ int upload_lane_jobs() {
         steps = std::max(steps, total);
     }
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lane_jobs), jobs, sizeof jobs));
+    if (const char* env = std::getenv("GMK_EVAL_SCAN_STEPS")) steps = std::atoi(env);      // profiling aid only: wrong results
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_scan_steps), &steps, sizeof steps));
     return GMK_OK;
 }
@@ -371,9 +438,10 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
         g_jobs_uploaded = true;
     }
     const Launch l = plan_launch(n, st);
+    static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x3F;
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
                        d_planes, n, l.iterations, d_scores, d_density, d_totals, d_status,
-                       st.d_trans, st.d_emit, st.d_pattern_info, st.n_states * 4, st.emit_words, st.n_patterns * 2);
+                       st.d_trans, st.d_emit, st.d_pattern_info, st.n_states * 4, st.emit_words, st.n_patterns * 2, phase_mask);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }
