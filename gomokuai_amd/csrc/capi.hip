@@ -46,15 +46,11 @@ extern "C" int gmk_init(int device) {
     st.n_states = t.n_states;
     st.n_patterns = t.n_patterns;
     st.emit_words = static_cast<int>(t.emit_lists.size());
-    GMK_HIP_CHECK(hipMalloc(&st.d_trans, t.trans.size() * sizeof(uint32_t)));
-    GMK_HIP_CHECK(hipMalloc(&st.d_emit, t.emit_lists.size() * sizeof(uint16_t)));
-    GMK_HIP_CHECK(hipMalloc(&st.d_pattern_info, t.pattern_info.size() * sizeof(uint32_t)));
-    // device form of a transition word: bits 0..13 byte offset of the next state's row (state * 16), bits 14.. emission list
-    std::vector<uint32_t> dev_trans(t.trans.size());
-    for (size_t i = 0; i < t.trans.size(); ++i) dev_trans[i] = ((t.trans[i] & 1023u) * 16u) | ((t.trans[i] >> 10) << 14);
-    GMK_HIP_CHECK(hipMemcpy(st.d_trans, dev_trans.data(), dev_trans.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    GMK_HIP_CHECK(hipMemcpy(st.d_emit, t.emit_lists.data(), t.emit_lists.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    GMK_HIP_CHECK(hipMemcpy(st.d_pattern_info, t.pattern_info.data(), t.pattern_info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    st.n_records = t.n_records;
+    GMK_HIP_CHECK(hipMalloc(&st.d_trans, t.dev_trans.size() * sizeof(uint32_t)));
+    GMK_HIP_CHECK(hipMalloc(&st.d_records, t.dev_records.size() * sizeof(uint32_t)));
+    GMK_HIP_CHECK(hipMemcpy(st.d_trans, t.dev_trans.data(), t.dev_trans.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(st.d_records, t.dev_records.data(), t.dev_records.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     st.ready = true;
     return GMK_OK;
 }
@@ -63,8 +59,7 @@ extern "C" int gmk_shutdown(void) {
     gmk::DeviceState& st = device_state();
     if (!st.ready) return GMK_OK;
     (void)hipFree(st.d_trans);
-    (void)hipFree(st.d_emit);
-    (void)hipFree(st.d_pattern_info);
+    (void)hipFree(st.d_records);
     st = gmk::DeviceState{};
     return GMK_OK;
 }

@@ -17,10 +17,9 @@ struct DeviceState {
     bool ready = false;
     int device = -1;
     int cu_count = 0;
-    uint32_t* d_trans = nullptr;        // n_states*4 words
-    uint16_t* d_emit = nullptr;         // emission lists
-    uint32_t* d_pattern_info = nullptr; // 2 words per pattern
-    int n_states = 0, n_patterns = 0, emit_words = 0;
+    uint32_t* d_trans = nullptr;        // n_states*4 words, device form (DeviceTables::dev_trans)
+    uint32_t* d_records = nullptr;      // 4 words per emission record (DeviceTables::dev_records)
+    int n_states = 0, n_patterns = 0, emit_words = 0, n_records = 0;
 };
 DeviceState& device_state();
 

@@ -6,16 +6,19 @@
 // validated against in-order replay in tests/test_formulation.py.
 //
 // Mapping onto CDNA4
-//   * one 64-lane wavefront per board, four boards per 256-thread workgroup, persistent grid-stride loop:
-//     the automaton (dense DFA 556x4 words, emission lists, pattern records: ~12.5 KB) is staged into LDS
-//     ONCE per workgroup and reused for every board the workgroup evaluates;
-//   * phase 1: the 72 board lines that can hold a pattern (>= 5 cells) are spread over the 64 lanes (the 8
-//     shortest lines ride behind the shortest primaries: <= 19 steps per lane); each step is one LDS
-//     lookup trans[state][symbol]; matches go to a per-board LDS queue;
-//   * phase 2: one lane per match scatters its score deposits with LDS atomics (ds_add_u32);
-//   * phase 3: one lane per cell computes the 7x7 density stencil from the bit-planes with popcounts,
-//     decides compound patterns from per-cell counters, queues their counter-move rescans;
-//   * phase 4: one lane per queued compound component rescans a 13-symbol window;
+//   * one 64-lane wavefront per board, eight boards per 512-thread workgroup, persistent grid-stride loop:
+//     the automaton (dense DFA 556x4 words + emission records, ~14 KB) is staged into LDS ONCE per workgroup
+//     and reused for every board the workgroup evaluates; after that single barrier the waves never wait for
+//     each other (phases of one board are ordered by wavefront-scope fences only);
+//   * phase 0: the two bit-planes become 88 "line words" (rows, columns, both diagonals) with one LDS OR per stone;
+//   * phase 1: the 72 lines that can hold a pattern (>= 5 cells) are spread over the 64 lanes (the 8 shortest ride
+//     behind the shortest primaries: 19 steps per lane); a lane's lines are one stream of 2-bit symbols in a
+//     64-bit register, a step is one LDS lookup trans[row + sym]; emitting transitions are queued by ballot prefix;
+//   * phase 2: one lane per queued transition: one 16-byte record read gives the (<= 2) matches, each with a
+//     compact list of <= 4 score deposits (ds_add_u32);
+//   * phase 3: one lane per cell: the 7x7 density stencil for both colours from packed 7-bit row windows with
+//     popcounts, area bonus, compound decision from 2-bit saturating per-cell counters;
+//   * phase 4: one lane per compound component: 13-symbol window rescan for its counter-move cells;
 //   * phase 5: the 3.6 KB score block leaves LDS as coalesced 16-byte stores.
 // HBM traffic per board: 64 B in, 7 248 B out (7 312 B algorithmic); everything else stays on chip.
 #include <algorithm>
@@ -26,47 +29,27 @@
 
 namespace {
 
-constexpr int kBoardsPerBlock = 4;
+constexpr int kBoardsPerBlock = 8;
 constexpr int kThreads = 64 * kBoardsPerBlock;
 constexpr int kCells = 225;
-constexpr int kQueueCap = 316;
-constexpr int kMaxBlocksPerCu = 4;
+constexpr int kQueueCap = 512;
+constexpr int kMaxBlocksPerCu = 2;
 
 // per-board LDS region (32-bit words)
 constexpr int kScoreWords = 4 * kCells;          // 900, 16-byte aligned block
 constexpr int kCntWords = 2 * kCells;            // per cell 2 words: [LiveThree | DeadThree << 16], [LiveTwo]; 2-bit fields [colour][dir]: bit0 ">= 1", bit1 ">= 2"
-constexpr int kRowWords = 92;                    // line words, black | white << 16, bit = position along the line:
-                                                 // rows [0,15), columns [16,31), diagonals x-y+14 at [32,61), anti-diagonals x+y at [61,90)
-constexpr int kColBase = 16, kDiagBase = 32, kAntiBase = 61;
-constexpr int kMiscWords = 16;                   // [0] queue count, [1] winner bits, [2] error, [3] second queue count, [4..14] totals
-constexpr int kBoardWords = (kScoreWords + kCntWords + kRowWords + kQueueCap + kMiscWords + 3) & ~3;   // keeps each board's score block 16-byte aligned
+constexpr int kRowGuard = 4;                     // zero words in front of the rows: the 7x7 stencil reads rows y-3 .. y+3 unchecked
+constexpr int kRowWords = 96;                    // line words, black | white << 16, bit = position along the line:
+                                                 // rows [0,15), zeros [15,20), columns [20,35), diagonals x-y+14 at [36,65), anti-diagonals x+y at [65,94)
+constexpr int kColBase = 20, kDiagBase = 36, kAntiBase = 65;
+constexpr int kMiscWords = 16;                   // [1] winner bits, [2] error, [3] compound queue count, [4..14] totals
+constexpr int kBoardWords = (kScoreWords + kCntWords + kRowGuard + kRowWords + kQueueCap + kMiscWords + 3) & ~3;   // keeps each board's score block 16-byte aligned
 
 // Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
 __constant__ int c_scan_steps;
 
-__device__ __forceinline__ int dir_dx(int dir) { return dir == 1 ? 0 : dir == 3 ? -1 : 1; }
-__device__ __forceinline__ int dir_dy(int dir) { return dir == 0 ? 0 : 1; }
 __device__ __forceinline__ int dir_stride(int dir) { return dir == 0 ? 1 : dir == 1 ? 15 : dir == 2 ? 16 : 14; }
-
-// symbol codes on the device: 0 black stone 'x', 1 white stone 'o', 2 off-board '?', 3 blank
-__device__ __forceinline__ int cell_symbol(const uint32_t* rows, int x, int y) {
-    if (static_cast<unsigned>(x) >= 15u || static_cast<unsigned>(y) >= 15u) return 2;
-    const uint32_t w = rows[y] >> x;
-    return (w & 1u) ? 0 : (w & 0x10000u) ? 1 : 3;
-}
-
-// weights of the 7x7 block (core/lib/src/Pattern.cpp:601-607) for one colour at one cell.
-// win[k] = 7-bit window (bit i <-> column x-3+i) of row y-3+k.  Rows are symmetric in |dy|, so the two rows
-// of a pair are concatenated (low byte / high byte) and counted with one popcount.
-__device__ __forceinline__ void block_density(const uint32_t win[7], int& count, int& weight) {
-    const uint32_t p3 = win[0] | (win[6] << 8), p2 = win[1] | (win[5] << 8), p1 = win[2] | (win[4] << 8), p0 = win[3];
-    weight = 2 * __popc(p3 & 0x4141u) + __popc(p3 & 0x0808u)
-           + 4 * __popc(p2 & 0x2222u) + 3 * __popc(p2 & 0x1C1Cu)
-           + 3 * __popc(p1 & 0x2222u) + 5 * __popc(p1 & 0x1414u) + 4 * __popc(p1 & 0x0808u)
-           + __popc(p0 & 0x41u) + 3 * __popc(p0 & 0x22u) + 4 * __popc(p0 & 0x14u);
-    count = __popc(p3 & 0x4949u) + __popc(p2 & 0x3E3Eu) + __popc(p1 & 0x3E3Eu) + __popc(p0 & 0x77u);
-}
 
 // spreads the low 15 bits of v to the even bit positions
 __device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
@@ -77,75 +60,126 @@ __device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
     return v;
 }
 
-// A line word (black | white << 16, bit = position) -> the DFA's symbol stream, 2 bits per symbol, first symbol in
-// the low bits: '?' (2), the len cells (0 black, 1 white, 3 blank), '?', '?'  (1 leading + 2 trailing pads).
-__device__ __forceinline__ uint64_t line_symbols(uint32_t lw, int len) {
+// the len cells of a line word (black | white << 16, bit = position) as 2-bit DFA symbols, first cell in the low
+// bits: 0 black, 1 white, 3 blank ('?' = 2 is the off-board symbol)
+__device__ __forceinline__ uint64_t cell_symbols(uint32_t lw, int len) {
     const uint32_t in_line = (1u << len) - 1u;
     const uint32_t black = lw & 0x7FFFu, white = lw >> 16;
     const uint32_t lo = ~black & in_line, hi = ~(black | white) & in_line;      // blank 11, white 01, black 00
-    const uint64_t cells = static_cast<uint64_t>(spread_bits(lo) | (spread_bits(hi) << 1));
-    return 2ull | (cells << 2) | (0xAull << (2 * len + 2));
+    return static_cast<uint64_t>(spread_bits(lo) | (spread_bits(hi) << 1));
 }
 
-// queue entries carry dir << 10 | (cell + 16) << 12; the scan keeps the entry of the CURRENT symbol in a register
-__device__ __forceinline__ uint32_t queue_entry_step(uint32_t job) { return static_cast<uint32_t>(dir_stride((job >> 12) & 3)) << 12; }
-__device__ __forceinline__ uint32_t queue_entry_base(uint32_t job) {
-    const int x0 = (job >> 4) & 15, y0 = (job >> 8) & 15, dir = (job >> 12) & 3;
-    return (static_cast<uint32_t>(dir) << 10) | (static_cast<uint32_t>(y0 * 15 + x0 - dir_stride(dir) + 16) << 12);   // symbol 0 is the leading pad
+// '?' cells '?' '?': exactly 2 * (len + 3) bits (1 leading + 2 trailing pads instead of the reference's 6 + 6)
+__device__ __forceinline__ uint64_t line_symbols(uint32_t lw, int len) {
+    return 2ull | (cell_symbols(lw, len) << 2) | (0xAull << (2 * len + 2));
 }
 
 // Phases of one board only exchange data between lanes of the SAME wavefront through LDS.  LDS instructions of
 // one wave execute in issue order, so all that is needed between phases is that the compiler keeps the order:
-// a wavefront-scope fence (no instruction) instead of a workgroup barrier, which would make the four
-// independent boards of a block wait for each other at every phase.
+// a wavefront-scope fence (no instruction) instead of a workgroup barrier, which would make the independent
+// boards of a block wait for each other at every phase.
 __device__ __forceinline__ void wave_phase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Score deposits of one match (Evaluator::Updater::updatePatterns, Pattern.cpp:138-165).  w0 / w1: emission
+// record words (pattern_tables.h).  cell_at = cell of the symbol the transition consumed.
+__device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell_at, int dir, int stride,
+                                              uint32_t* s_scores, uint32_t* s_cnt, uint32_t* s_misc) {
+    const int type = w0 & 15, fav = (w0 >> 4) & 1;
+    if (type == 8) { atomicOr(&s_misc[1], fav ? 1u : 2u); return; }                 // Five: winner only (Pattern.cpp:140-145)
+    atomicAdd(&s_misc[4 + type], fav ? 0x10000u : 1u);                              // totals row (Pattern.cpp:147, 390-393)
+    const int endcell = cell_at - static_cast<int>((w0 >> 27) & 1u) * stride;
+    const uint32_t score = dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu);                  // int(1.2 * score) on diagonals (Pattern.cpp:151-152)
+    uint32_t* own = s_scores + (fav ? 3 : 0) * kCells;                              // Group(favour, favour) (Pattern.h:159-161)
+    uint32_t* opp = s_scores + (fav ? 2 : 1) * kCells;                              // Group(favour, -favour)
+    const int tslot = type == 5 ? 0 : type == 4 ? 1 : type == 3 ? 2 : -1;           // LiveThree, DeadThree, LiveTwo feed compounds
+    const int n_dep = (w0 >> 8) & 7;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d >= n_dep) break;
+        const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
+        const int c = endcell - static_cast<int>(f & 7u) * stride;
+        atomicAdd(&opp[c], score);                                                  // '_' and '^': the opponent's view
+        if (f & 8u) {                                                               // '_': the owner's view too
+            atomicAdd(&own[c], score);
+            if (tslot >= 0) {                                                       // saturating count 0 / 1 / >= 2
+                uint32_t* word = &s_cnt[c * 2 + (tslot >> 1)];
+                const uint32_t bit = 1u << (16 * (tslot & 1) + 2 * (fav * 4 + dir));
+                if (atomicOr(word, bit) & bit) atomicOr(word, bit << 1);
+            }
+        }
+    }
+}
+
+// Compound::updateAntis (Pattern.cpp:520-543) for one match met at window index k: if it is of the wanted type,
+// covers the centre cell q and has '_' there, its other scored blanks get +600 in the opponent's view.
+__device__ __forceinline__ bool try_counter_cells(uint32_t w0, int k, int want, int q, int stride, uint32_t* opp) {
+    const int type = w0 & 15, len = (w0 >> 5) & 7;
+    const int back = k - static_cast<int>((w0 >> 27) & 1u) - 6;                     // piece index (from the end) lying on q
+    if (type != want || back < 0 || back >= len) return false;
+    const int n_dep = (w0 >> 8) & 7;
+    bool on_q = false;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
+        on_q |= d < n_dep && f == (8u | static_cast<uint32_t>(back));               // '_' on q
+    }
+    if (!on_q) return false;
+    const int endcell = q + back * stride;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
+        if (d < n_dep && static_cast<int>(f & 7u) != back) atomicAdd(&opp[endcell - static_cast<int>(f & 7u) * stride], 600u);
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(kThreads)
 void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int iterations,
                            int32_t* __restrict__ out_scores, int32_t* __restrict__ out_density,
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
-                           const uint32_t* __restrict__ g_trans, const uint16_t* __restrict__ g_emit,
-                           const uint32_t* __restrict__ g_pinfo, int trans_words, int emit_words, int pinfo_words,
+                           const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
+                           int trans_words, int record_words,
                            int phase_mask /* profiling aid: bit p runs phase p; 0x3F in production */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // layout: [boards: kBoardsPerBlock * kBoardWords][trans][pinfo][emit (u16)]
+    // layout: [boards: kBoardsPerBlock * kBoardWords][trans][records (16-byte aligned)][lane jobs]
     uint32_t* s_trans = lds + kBoardsPerBlock * kBoardWords;
-    uint32_t* s_pinfo = s_trans + trans_words;
-    uint16_t* s_emit = reinterpret_cast<uint16_t*>(s_pinfo + pinfo_words);
+    const uint4* s_rec = reinterpret_cast<const uint4*>(s_trans + trans_words);
+    uint32_t* s_jobs = s_trans + trans_words + record_words;
 
     for (int i = threadIdx.x; i < trans_words; i += kThreads) s_trans[i] = g_trans[i];
-    for (int i = threadIdx.x; i < pinfo_words; i += kThreads) s_pinfo[i] = g_pinfo[i];
-    for (int i = threadIdx.x; i < emit_words; i += kThreads) s_emit[i] = g_emit[i];
+    for (int i = threadIdx.x; i < record_words; i += kThreads) s_trans[trans_words + i] = g_records[i];
+    if (threadIdx.x < 128) s_jobs[threadIdx.x] = c_lane_jobs[threadIdx.x];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* s_scores = lds + wave * kBoardWords;           // int32 scores, accumulated with ds_add
     uint32_t* s_cnt = s_scores + kScoreWords;
-    uint32_t* s_rows = s_cnt + kCntWords;
+    uint32_t* s_rows = s_cnt + kCntWords + kRowGuard;
     uint32_t* s_queue = s_rows + kRowWords;
     uint32_t* s_misc = s_queue + kQueueCap;
 
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
-    const uint32_t job_a = c_lane_jobs[lane * 2], job_b = c_lane_jobs[lane * 2 + 1];
+    const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
     const int scan_steps = c_scan_steps;
+    const char* trans_bytes = reinterpret_cast<const char*>(s_trans);
 
     for (int it = 0; it < iterations; ++it) {
         const int board = (it * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave;
         const bool live = board < n_boards;
 
         // ---- phase 0: clear accumulators, fetch the two bit-planes (64 B), transpose them into line words ----
-        for (int i = lane; i < kScoreWords + kCntWords; i += 64) s_scores[i] = 0;
+        for (int i = lane; i < kScoreWords + kCntWords + kRowGuard + kRowWords; i += 64) s_scores[i] = 0;
         if (lane < kMiscWords) s_misc[lane] = 0;
         uint32_t my_row = 0;
         if (lane < 16 && live) my_row = static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + lane]) |
                                         (static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + 16 + lane]) << 16);
-        for (int i = lane; i < kRowWords; i += 64) s_rows[i] = (i < 16) ? my_row : 0u;
         wave_phase_fence();
         if (lane < 15) {                                            // lane y owns row y: one OR per stone into the 3 other line words
             const int y = lane;
+            s_rows[y] = my_row;
             for (uint32_t m = (my_row | (my_row >> 16)) & 0x7FFFu; m; m &= m - 1u) {
                 const int x = __ffs(m) - 1;
                 const uint32_t cb = ((my_row >> x) & 1u) ? 0u : 16u;
@@ -157,81 +191,56 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         wave_phase_fence();
 
         // ---- phase 1: walk the DFA along this lane's lines; transitions that emit go to the queue ----
-        // Per job the line is turned once into a stream of 2-bit DFA symbols in a 64-bit register ('?', cells, '?', '?'),
-        // so a step is: take 2 bits, one LDS lookup trans[state][sym] (the word holds the next row's byte offset), done.
-        // The queue slot comes from a ballot prefix (this wave is the only producer): no returning atomic in the loop;
-        // emission lists are expanded in phase 2.
+        // The lane's one or two lines become ONE stream of 2-bit DFA symbols in a 64-bit register:
+        //   '?' cells '?' '?'  ['?' cells '?' '?']  '?' '?' ...
+        // (after "??" the automaton sits in its '?' self-loop state, which the next line's leading '?' keeps: no reset
+        // between the two lines).  A step is: take 2 bits, one LDS lookup trans[row + sym] whose word holds the next
+        // row's byte offset and the emission record number.  Emitting transitions are queued raw (record, lane, step);
+        // the slot is a ballot prefix (this wave is the only producer), the decoding happens in phase 2.
         int n_queued = 0;                                       // wave-uniform
         if (phase_mask & 2) {
-            uint32_t job = job_a;
-            bool second_done = false;
-            uint64_t syms = line_symbols(s_rows[(job >> 16) & 127u], job & 15);
-            int steps_left = (job & 0x4000u) ? static_cast<int>(job & 15u) + 3 : 0;
+            const int len_a = job_a & 15, len_b = job_b & 15;
+            uint64_t syms = line_symbols(s_rows[(job_a >> 16) & 127u], len_a);
+            syms |= line_symbols(s_rows[(job_b >> 16) & 127u], len_b) << (2 * len_a + 6);
+            syms |= 0xAAAAAAAAAAAAAAAAull << (2 * (len_a + len_b) + 12);
             uint32_t row_off = 0;                               // byte offset of the current state's row in trans[]
-            uint32_t entry = queue_entry_base(job);             // dir << 10 | (cell of the current symbol + 16) << 12
-            const char* trans_bytes = reinterpret_cast<const char*>(s_trans);
+            uint32_t tag = static_cast<uint32_t>(lane) << 10;   // | step << 16
             for (int step = 0; step < scan_steps; ++step) {
-                const uint32_t sym = static_cast<uint32_t>(syms) & 3u;
+                const uint32_t sym4 = (static_cast<uint32_t>(syms) & 3u) << 2;
                 syms >>= 2;
-                const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym * 4u);
+                const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym4);
                 row_off = tw & 0x3FFFu;
-                const uint32_t li = steps_left > 0 ? (tw >> 14) : 0u;
-                const unsigned long long emitters = __ballot(li != 0u);
+                const uint32_t rec = tw >> 14;
+                const unsigned long long emitters = __ballot(rec != 0u);
                 if (emitters) {
-                    if (li) {
+                    if (rec) {
                         const int slot = n_queued + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u)));
-                        if (slot < kQueueCap) s_queue[slot] = entry | li;
+                        if (slot < kQueueCap) s_queue[slot] = tag | rec;
                     }
                     n_queued += __popcll(emitters);
                 }
-                entry += queue_entry_step(job);
-                if (--steps_left == 0 && !second_done) {       // the short second line of this lane, if it has one
-                    second_done = true;
-                    job = job_b;
-                    syms = line_symbols(s_rows[(job >> 16) & 127u], job & 15);
-                    steps_left = (job & 0x4000u) ? static_cast<int>(job & 15u) + 3 : 0;
-                    row_off = 0;
-                    entry = queue_entry_base(job);
-                }
+                tag += 1u << 16;
             }
             if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
         }
         wave_phase_fence();
 
-        // ---- phase 2: one lane per emitting transition: its 1-2 matches' score deposits (Pattern.cpp:138-165) ----
+        // ---- phase 2: one lane per emitting transition: the score deposits of its 1-2 matches ----
         if (phase_mask & 4) {
             for (int m = lane; m < n_queued; m += 64) {
-              const uint32_t qe = s_queue[m];
-              const uint32_t li = qe & 1023u;
-              const int dir = (qe >> 10) & 3, cell_at = static_cast<int>(qe >> 12) - 16;
-              const int stride = dir_stride(dir);
-              const int n_emit = s_emit[li];
-              for (int e = 0; e < n_emit; ++e) {
-                const uint32_t v = s_emit[li + 1 + e];
-                const int pat = v & 0x1FF, endcell = cell_at - static_cast<int>(v >> 15) * stride;   // "back" emissions end one symbol earlier
-                const uint32_t w0 = s_pinfo[2 * pat], w1 = s_pinfo[2 * pat + 1];
-                const int type = w0 & 15, fav = (w0 >> 4) & 1, len = (w0 >> 5) & 7;
-                if (type == 8) { atomicOr(&s_misc[1], fav ? 1u : 2u); continue; }       // Five: winner only
-                atomicAdd(&s_misc[4 + type], fav ? 0x10000u : 1u);
-                const uint32_t score = dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu);
-                const int g_own = fav ? 3 : 0, g_opp = fav ? 2 : 1;                     // Pattern.h:159-161
-                const int tslot = type == 5 ? 0 : type == 4 ? 1 : type == 3 ? 2 : -1;   // LiveThree, DeadThree, LiveTwo
-                for (int j = 0; j < len; ++j) {
-                    const uint32_t kind = (w0 >> (8 + 2 * j)) & 3u;
-                    if (!kind) continue;
-                    const int c = endcell - j * stride;
-                    atomicAdd(&s_scores[g_opp * kCells + c], score);
-                    if (kind == 1) {
-                        atomicAdd(&s_scores[g_own * kCells + c], score);
-                        if (tslot >= 0) {                                                   // saturating count 0 / 1 / >= 2
-                            uint32_t* word = &s_cnt[c * 2 + (tslot >> 1)];
-                            const uint32_t bit = 1u << (16 * (tslot & 1) + 2 * (fav * 4 + dir));
-                            if (atomicOr(word, bit) & bit) atomicOr(word, bit << 1);
-                        }
-                    }
-                }
-              }
+                const uint32_t qe = s_queue[m];
+                // which line of which lane, and where on it (symbol 0 of a line is its leading pad)
+                const int src_lane = (qe >> 10) & 63, src_step = static_cast<int>(qe >> 16);
+                const uint4 rec = s_rec[qe & 1023u];
+                const uint32_t ja = s_jobs[src_lane * 2], jb = s_jobs[src_lane * 2 + 1];
+                const int first_len = static_cast<int>(ja & 15u) + 3;
+                const uint32_t job = src_step < first_len ? ja : jb;
+                const int pos = (src_step < first_len ? src_step : src_step - first_len) - 1;
+                const int dir = (job >> 12) & 3, stride = dir_stride(dir);
+                const int cell_at = static_cast<int>(((job >> 8) & 15u) * 15u + ((job >> 4) & 15u)) + pos * stride;
+                deposit_match(rec.x, rec.y, cell_at, dir, stride, s_scores, s_cnt, s_misc);
+                if (rec.z) deposit_match(rec.z, rec.w, cell_at, dir, stride, s_scores, s_cnt, s_misc);
             }
         }
         wave_phase_fence();
@@ -240,17 +249,27 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         if (phase_mask & 8)
         for (int q = lane; q < kCells; q += 64) {
             const int x = q % 15, y = q / 15;
-            uint32_t win_w[7], win_b[7];
+            // 7-bit windows (bit i <-> column x-3+i) of rows y-3 .. y+3 for BOTH colours at once: black in bits 0..6,
+            // white in bits 16..22.  One of the two shifts is by zero; col_mask removes what leaks across the halves.
+            const int sr = max(x - 3, 0), sl = max(3 - x, 0);
+            const uint32_t col_mask = (x >= 12 ? (0x7Fu >> (x - 11)) : 0x7Fu) | ((x < 3 ? (0x7Fu & ~((1u << (3 - x)) - 1u)) : 0x7Fu) << 16);
+            uint32_t win[7];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const int yy = y - 3 + k;
-                const uint32_t w = (static_cast<unsigned>(yy) < 15u) ? s_rows[yy] : 0u;
-                win_b[k] = (((w & 0x7FFFu) << 3) >> x) & 0x7Fu;
-                win_w[k] = (((w >> 16) << 3) >> x) & 0x7Fu;
-            }
+            for (int k = 0; k < 7; ++k) win[k] = ((s_rows[y - 3 + k] >> sr) << sl) & col_mask;
+            // rows are symmetric in |dy|: pair them in the two bytes of each half, count with one popcount per weight
+            const uint32_t p3 = win[0] | (win[6] << 8), p2 = win[1] | (win[5] << 8), p1 = win[2] | (win[4] << 8), p0 = win[3];
             int cnt_c[2], wgt_c[2];                         // [0] white, [1] black (Evaluator::Group, Pattern.h:154-156)
-            block_density(win_w, cnt_c[0], wgt_c[0]);
-            block_density(win_b, cnt_c[1], wgt_c[1]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int h = c ? 0 : 16;                   // black half is bits 0..15, white half bits 16..31
+                const int w1 = __popc(p3 & (0x0808u << h)) + __popc(p0 & (0x41u << h));
+                const int w2 = __popc(p3 & (0x4141u << h));
+                const int w3 = __popc(p2 & (0x1C1Cu << h)) + __popc(p1 & (0x2222u << h)) + __popc(p0 & (0x22u << h));
+                const int w4 = __popc(p2 & (0x2222u << h)) + __popc(p1 & (0x0808u << h)) + __popc(p0 & (0x14u << h));
+                const int w5 = __popc(p1 & (0x1414u << h));
+                wgt_c[c] = w1 + 2 * w2 + 3 * w3 + 4 * w4 + 5 * w5;                       // Pattern.cpp:601-607
+                cnt_c[c] = __popc(p3 & (0x4949u << h)) + __popc(p2 & (0x3E3Eu << h)) + __popc(p1 & (0x3E3Eu << h)) + __popc(p0 & (0x77u << h));
+            }
             const uint32_t here = s_rows[y] >> x;
             const bool occupied = (here & 0x10001u) != 0;
             if (!occupied) {
@@ -309,7 +328,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         wave_phase_fence();
 
         // ---- phase 4: one lane per compound component: first match of its type through the cell
-        //      (Compound::updateAntis, Pattern.cpp:520-543) ----
+        //      (Compound::updateAntis, Pattern.cpp:520-543): DFA over the 13-symbol window centred on the cell ----
         if (phase_mask & 16) {
             const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap);
             for (int m = lane; m < n_comp; m += 64) {
@@ -322,35 +341,21 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
                 const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
                 const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
-                const uint32_t lw = s_rows[line];
+                // six '?' | cells | six '?', then the 13 symbols starting six before q
+                uint64_t syms = (0xAAAull | (cell_symbols(s_rows[line], len) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
+                uint32_t* opp = s_scores + (c ? 2 : 1) * kCells;
                 uint32_t row_off = 0;
                 bool found = false;
-                for (int k = 0; k < 13 && !found; ++k) {
-                    const int p = at + k - 6;
-                    int sym = 2;
-                    if (static_cast<unsigned>(p) < static_cast<unsigned>(len)) {
-                        const uint32_t t = lw >> p;
-                        sym = (t & 1u) ? 0 : (t & 0x10000u) ? 1 : 3;
-                    }
-                    const uint32_t tw = s_trans[(row_off >> 2) + sym];
+                for (int k = 0; k < 13; ++k) {
+                    const uint32_t sym4 = (static_cast<uint32_t>(syms) & 3u) << 2;
+                    syms >>= 2;
+                    const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym4);
                     row_off = tw & 0x3FFFu;
-                    const uint32_t li = tw >> 14;
-                    if (!li || k < 6) continue;                              // a match covering q ends at window index >= 6
-                    const int cnt = s_emit[li];
-                    for (int e = 0; e < cnt && !found; ++e) {
-                        const uint32_t v = s_emit[li + 1 + e];
-                        const int off = k - static_cast<int>(v >> 15);
-                        const uint32_t w0 = s_pinfo[2 * (v & 0x1FFu)];
-                        const int type = w0 & 15, len = (w0 >> 5) & 7;
-                        const int back = off - 6;                                      // piece index (from the end) lying on q
-                        if (type != want || back < 0 || back >= len) continue;
-                        if (((w0 >> (8 + 2 * back)) & 3u) != 1u) continue;             // must be '_' on q
-                        found = true;
-                        const int endcell = q + back * stride;
-                        for (int j = 0; j < len; ++j) {
-                            if (j == back || !((w0 >> (8 + 2 * j)) & 3u)) continue;
-                            atomicAdd(&s_scores[(c ? 2 : 1) * kCells + endcell - j * stride], 600u);
-                        }
+                    const uint32_t rid = tw >> 14;
+                    if (rid && k >= 6 && !found) {                                     // a match covering q ends at window index >= 6
+                        const uint4 rec = s_rec[rid];
+                        found = try_counter_cells(rec.x, k, want, q, stride, opp);
+                        if (!found && rec.z) found = try_counter_cells(rec.z, k, want, q, stride, opp);
                     }
                 }
             }
@@ -403,8 +408,8 @@ int upload_lane_jobs() {
         if (extra < static_cast<int>(lines.size())) { jobs[lane * 2 + 1] = pack(lines[extra]); total += lines[extra].len + 3; }
         steps = std::max(steps, total);
     }
-    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lane_jobs), jobs, sizeof jobs));
     if (const char* env = std::getenv("GMK_EVAL_SCAN_STEPS")) steps = std::atoi(env);      // profiling aid only: wrong results
+    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lane_jobs), jobs, sizeof jobs));
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_scan_steps), &steps, sizeof steps));
     return GMK_OK;
 }
@@ -417,8 +422,7 @@ Launch plan_launch(int n, const gmk::DeviceState& st) {
     Launch l;
     l.iterations = std::max(1, (tiles + max_grid - 1) / max_grid);
     l.grid = std::max(1, (tiles + l.iterations - 1) / l.iterations);
-    const int pinfo_words = st.n_patterns * 2;
-    l.lds = static_cast<size_t>(kBoardsPerBlock * kBoardWords + st.n_states * 4 + pinfo_words) * 4 + static_cast<size_t>((st.emit_words + 1) & ~1) * 2;
+    l.lds = static_cast<size_t>(kBoardsPerBlock * kBoardWords + st.n_states * 4 + st.n_records * 4 + 128) * 4;
     return l;
 }
 
@@ -435,13 +439,14 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
     if (!g_jobs_uploaded) {
         const int rc = upload_lane_jobs();
         if (rc != GMK_OK) return rc;
+        GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_positions_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_jobs_uploaded = true;
     }
     const Launch l = plan_launch(n, st);
     static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x3F;
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
                        d_planes, n, l.iterations, d_scores, d_density, d_totals, d_status,
-                       st.d_trans, st.d_emit, st.d_pattern_info, st.n_states * 4, st.emit_words, st.n_patterns * 2, phase_mask);
+                       st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, phase_mask);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }

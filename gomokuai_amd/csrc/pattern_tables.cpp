@@ -300,6 +300,47 @@ void PatternAutomaton::flatten() {
         dev_.pattern_info[2 * p] = w0;
         dev_.pattern_info[2 * p + 1] = static_cast<uint32_t>(pr.score) | (diag << 16);
     }
+
+    // device form: dense record numbers instead of list offsets, next-row byte offsets instead of state ids
+    if (dev_.max_emissions > 2) throw std::runtime_error("pattern automaton: a transition reports more than two matches");
+    std::map<int, int> record_of_list;                           // emit_lists offset -> record number
+    dev_.dev_records.assign(4, 0u);                              // record 0 = nothing
+    dev_.dev_trans.resize(dev_.trans.size());
+    for (size_t i = 0; i < dev_.trans.size(); ++i) {
+        const uint32_t next = dev_.trans[i] & 1023u, list = dev_.trans[i] >> 10;
+        uint32_t rec = 0;
+        if (list) {
+            auto it = record_of_list.find(static_cast<int>(list));
+            if (it == record_of_list.end()) {
+                it = record_of_list.emplace(static_cast<int>(list), static_cast<int>(dev_.dev_records.size() / 4)).first;
+                uint32_t words[4] = {0, 0, 0, 0};
+                for (int e = 0; e < dev_.emit_lists[list]; ++e) {
+                    const uint16_t v = dev_.emit_lists[list + 1 + e];
+                    const PatternRec& pr = patterns_[v & 0x7FFF];
+                    const int len = static_cast<int>(pr.rich.size());
+                    uint32_t w0 = static_cast<uint32_t>(pr.type) | (pr.favour == 1 ? 16u : 0u) | (static_cast<uint32_t>(len) << 5);
+                    int n_dep = 0;
+                    if (pr.type != Five)
+                        for (int j = 0; j < len; ++j) {
+                            const char piece = pr.rich[len - 1 - j];
+                            if (piece != '_' && piece != '^') continue;
+                            if (n_dep == 4) throw std::runtime_error("pattern automaton: a pattern has more than four scored blanks");
+                            w0 |= (static_cast<uint32_t>(j) | (piece == '_' ? 8u : 0u)) << (11 + 4 * n_dep);
+                            ++n_dep;
+                        }
+                    w0 |= static_cast<uint32_t>(n_dep) << 8;
+                    if (v >> 15) w0 |= 1u << 27;
+                    words[2 * e] = w0;
+                    words[2 * e + 1] = dev_.pattern_info[2 * (v & 0x7FFF) + 1];
+                }
+                dev_.dev_records.insert(dev_.dev_records.end(), words, words + 4);
+            }
+            rec = static_cast<uint32_t>(it->second);
+        }
+        if (rec >= 1024) throw std::runtime_error("pattern automaton: too many emission records");
+        dev_.dev_trans[i] = (next * 16u) | (rec << 14);
+    }
+    dev_.n_records = static_cast<int>(dev_.dev_records.size() / 4);
 }
 
 std::vector<std::pair<int, int>> PatternAutomaton::scan(const uint8_t* codes, int n) const {

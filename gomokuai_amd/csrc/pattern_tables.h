@@ -41,6 +41,16 @@ struct DeviceTables {
     //       counted from the LAST symbol backwards (0 none, 1 '_', 2 '^')
     //   w1: bits 0..15 score on rows/columns | bits 16..31 score on diagonals (= int(1.2*score))
     std::vector<uint32_t> pattern_info;
+    // ---- what the kernels stage into LDS ----
+    // dev_trans[state*4 + sym]: bits 0..13 byte offset of the next state's row (state * 16), bits 14..23 emission record number (0 = none)
+    std::vector<uint32_t> dev_trans;
+    // dev_records[4*r .. 4*r+3], r >= 1: the (at most two) matches one transition reports, two words each, second pair 0 if absent:
+    //   w0: bits 0..3 type | bit 4 favour-is-black | bits 5..7 len | bits 8..10 number of deposits |
+    //       bits 11..26 four deposits of 4 bits (bits 0..2 piece index counted from the LAST symbol, bit 3 set for '_', clear for '^') |
+    //       bit 27 the match ends one symbol before the one just consumed
+    //   w1: as pattern_info w1
+    std::vector<uint32_t> dev_records;
+    int n_records = 0;
     int n_states = 0;
     int n_patterns = 0;
     int max_emissions = 0;
