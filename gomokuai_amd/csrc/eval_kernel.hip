@@ -166,16 +166,25 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     const int scan_steps = c_scan_steps;
     const char* trans_bytes = reinterpret_cast<const char*>(s_trans);
 
+    // the next board's 64 B are fetched while the current board is evaluated (one dependent HBM round trip per board otherwise)
+    auto fetch_row = [&](int b) -> uint32_t {
+        if (lane >= 16 || b >= n_boards) return 0u;
+        return static_cast<uint32_t>(planes[static_cast<size_t>(b) * 32 + lane]) | (static_cast<uint32_t>(planes[static_cast<size_t>(b) * 32 + 16 + lane]) << 16);
+    };
+    uint32_t next_row = fetch_row(blockIdx.x * kBoardsPerBlock + wave);
+
     for (int it = 0; it < iterations; ++it) {
         const int board = (it * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave;
         const bool live = board < n_boards;
 
-        // ---- phase 0: clear accumulators, fetch the two bit-planes (64 B), transpose them into line words ----
-        for (int i = lane; i < kScoreWords + kCntWords + kRowGuard + kRowWords; i += 64) s_scores[i] = 0;
+        // ---- phase 0: clear accumulators, take the two bit-planes (64 B), transpose them into line words ----
+        {
+            uint4* z = reinterpret_cast<uint4*>(s_scores);
+            for (int i = lane; i < (kScoreWords + kCntWords + kRowGuard + kRowWords + 3) / 4; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
         if (lane < kMiscWords) s_misc[lane] = 0;
-        uint32_t my_row = 0;
-        if (lane < 16 && live) my_row = static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + lane]) |
-                                        (static_cast<uint32_t>(planes[static_cast<size_t>(board) * 32 + 16 + lane]) << 16);
+        const uint32_t my_row = next_row;
+        next_row = fetch_row(((it + 1) * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave);
         wave_phase_fence();
         if (lane < 15) {                                            // lane y owns row y: one OR per stone into the 3 other line words
             const int y = lane;
@@ -245,9 +254,12 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         }
         wave_phase_fence();
 
-        // ---- phase 3: one lane per cell: density stencil, area bonus, compound decision ----
+        // ---- phase 3: one lane per cell: density stencil, area bonus, compound candidates ----
+        int n_cand = 0;                                         // wave-uniform
         if (phase_mask & 8)
-        for (int q = lane; q < kCells; q += 64) {
+        for (int q0 = 0; q0 < kCells; q0 += 64) {
+            const int q = min(q0 + lane, kCells - 1);           // the last pass has 33 cells; spare lanes redo cell 224 harmlessly
+            const bool spare = q0 + lane >= kCells;
             const int x = q % 15, y = q / 15;
             // 7-bit windows (bit i <-> column x-3+i) of rows y-3 .. y+3 for BOTH colours at once: black in bits 0..6,
             // white in bits 16..22.  One of the two shifts is by zero; col_mask removes what leaks across the halves.
@@ -272,28 +284,53 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             }
             const uint32_t here = s_rows[y] >> x;
             const bool occupied = (here & 0x10001u) != 0;
-            if (!occupied) {
+            if (!occupied && !spare) {
                 if (wgt_c[0] > 0) atomicAdd(&s_scores[0 * kCells + q], 160u);           // Pattern.cpp:268
                 if (wgt_c[1] > 0) atomicAdd(&s_scores[3 * kCells + q], 160u);
             }
-            if (live && out_density) {
+            if (live && out_density && !spare) {
                 int32_t* d = out_density + static_cast<size_t>(board) * 4 * kCells + q;
                 d[0 * kCells] = occupied ? -cnt_c[0] - 1 : cnt_c[0];
                 d[1 * kCells] = occupied ? -wgt_c[0] - 1 : wgt_c[0];
                 d[2 * kCells] = occupied ? -cnt_c[1] - 1 : cnt_c[1];
                 d[3 * kCells] = occupied ? -wgt_c[1] - 1 : wgt_c[1];
             }
-            if (occupied) continue;
-            // compound patterns (Pattern.cpp:167-197, 420-486): per colour, counters of '_' pieces of
-            // LiveThree / DeadThree / LiveTwo on this cell per direction, saturated at 2
+            // compound candidates (Compound::Test, Pattern.cpp:424-433, and the density gate, Pattern.cpp:182): cells whose
+            // LiveThree / DeadThree / LiveTwo '_' flags cover two or more direction bits; decided in phase 3b by one lane each
+            uint32_t cand = 0;
+            if (!occupied && !spare) {
+                const uint32_t cw0 = s_cnt[q * 2], cw1 = s_cnt[q * 2 + 1];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t flags = ((cw0 >> (8 * c)) | (cw0 >> (16 + 8 * c)) | (cw1 >> (8 * c))) & 0xFFu;
+                    if (__popc(flags) >= 2 && cnt_c[c] >= 2) cand |= 1u << c;
+                }
+            }
+            const unsigned long long pushers = __ballot(cand != 0u);
+            if (pushers) {
+                if (cand) {
+                    const int slot = n_cand + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pushers >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pushers), 0u)));
+                    if (slot < kQueueCap / 2) s_queue[slot] = static_cast<uint32_t>(q) | (cand << 8);
+                }
+                n_cand += __popcll(pushers);
+            }
+        }
+        wave_phase_fence();
+
+        // ---- phase 3b: one lane per candidate cell: compound state machine (Pattern.cpp:440-486), critical-point deposits,
+        //      counter-move rescans queued in the upper half of the queue ----
+        if (n_cand > kQueueCap / 2) { s_misc[2] = 1; n_cand = kQueueCap / 2; }
+        if (phase_mask & 8)
+        for (int m = lane; m < n_cand; m += 64) {
+            const uint32_t ce = s_queue[m];
+            const int q = ce & 255;
             const uint32_t cw0 = s_cnt[q * 2], cw1 = s_cnt[q * 2 + 1];
-            if (!(cw0 | cw1)) continue;
             for (int c = 0; c < 2; ++c) {
+                if (!((ce >> (8 + c)) & 1u)) continue;
                 // 2-bit fields per direction: 00 none, 01 one, 11 two or more (= the reference's flag encoding, Pattern.cpp:395-400)
                 const uint32_t f_l3 = (cw0 >> (8 * c)) & 0xFFu, f_d3 = (cw0 >> (16 + 8 * c)) & 0xFFu, f_l2 = (cw1 >> (8 * c)) & 0xFFu;
-                if (!(f_l3 | f_d3 | f_l2) || cnt_c[c] < 2) continue;
-                if (__popc(f_l3 | f_d3 | f_l2) < 2) continue;       // Compound::Test (Pattern.cpp:424-433)
-                // state machine S0,L2,LD3,To33,To43,To44 = 0..5 (Pattern.cpp:440-486)
+                // state machine S0,L2,LD3,To33,To43,To44 = 0..5
                 int state = 0, l3 = 0, triple = 0, n_comp = 0;
                 uint32_t comps = 0;                         // 4 bits per component: dir | tslot << 2
                 for (int d = 0; d < 4; ++d) {
@@ -320,7 +357,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 for (int i = 0; i < n_comp; ++i) {                                     // queue the counter-move rescans
                     const uint32_t cd = (comps >> (4 * i)) & 15u;
                     const uint32_t slot = atomicAdd(&s_misc[3], 1u);
-                    if (slot < kQueueCap) s_queue[slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(c) << 8) | (cd << 9);
+                    if (slot < kQueueCap / 2) s_queue[kQueueCap / 2 + slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(c) << 8) | (cd << 9);
                     else s_misc[2] = 1;
                 }
             }
@@ -330,9 +367,9 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         // ---- phase 4: one lane per compound component: first match of its type through the cell
         //      (Compound::updateAntis, Pattern.cpp:520-543): DFA over the 13-symbol window centred on the cell ----
         if (phase_mask & 16) {
-            const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap);
+            const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap / 2);
             for (int m = lane; m < n_comp; m += 64) {
-                const uint32_t ent = s_queue[m];
+                const uint32_t ent = s_queue[kQueueCap / 2 + m];
                 const int q = ent & 255, c = (ent >> 8) & 1, dir = (ent >> 9) & 3, tslot = (ent >> 11) & 3;
                 const int want = tslot == 0 ? 5 : tslot == 1 ? 4 : 3;
                 const int x = q % 15, y = q / 15, stride = dir_stride(dir);
