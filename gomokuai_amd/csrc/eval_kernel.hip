@@ -219,7 +219,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 syms >>= 2;
                 const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym4);
                 row_off = tw & 0x3FFFu;
-                const uint32_t rec = tw >> 14;
+                const uint32_t rec = (tw >> 14) & 1023u;
                 const unsigned long long emitters = __ballot(rec != 0u);
                 if (emitters) {
                     if (rec) {
@@ -388,9 +388,9 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     syms >>= 2;
                     const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym4);
                     row_off = tw & 0x3FFFu;
-                    const uint32_t rid = tw >> 14;
-                    if (rid && k >= 6 && !found) {                                     // a match covering q ends at window index >= 6
-                        const uint4 rec = s_rec[rid];
+                    // a match covering q ends at window index >= 6; bits 24.. say whether the record holds the wanted type
+                    if (k >= 6 && !found && ((tw >> (24 + tslot)) & 1u)) {
+                        const uint4 rec = s_rec[(tw >> 14) & 1023u];
                         found = try_counter_cells(rec.x, k, want, q, stride, opp);
                         if (!found && rec.z) found = try_counter_cells(rec.z, k, want, q, stride, opp);
                     }

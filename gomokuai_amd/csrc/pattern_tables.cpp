@@ -338,7 +338,12 @@ void PatternAutomaton::flatten() {
             rec = static_cast<uint32_t>(it->second);
         }
         if (rec >= 1024) throw std::runtime_error("pattern automaton: too many emission records");
-        dev_.dev_trans[i] = (next * 16u) | (rec << 14);
+        uint32_t kinds = 0;                                       // which compound-feeding types the record holds
+        for (int e = 0; list && e < dev_.emit_lists[list]; ++e) {
+            const int type = patterns_[dev_.emit_lists[list + 1 + e] & 0x7FFF].type;
+            kinds |= type == LiveThree ? 1u : type == DeadThree ? 2u : type == LiveTwo ? 4u : 0u;
+        }
+        dev_.dev_trans[i] = (next * 16u) | (rec << 14) | (kinds << 24);
     }
     dev_.n_records = static_cast<int>(dev_.dev_records.size() / 4);
 }

@@ -42,7 +42,8 @@ struct DeviceTables {
     //   w1: bits 0..15 score on rows/columns | bits 16..31 score on diagonals (= int(1.2*score))
     std::vector<uint32_t> pattern_info;
     // ---- what the kernels stage into LDS ----
-    // dev_trans[state*4 + sym]: bits 0..13 byte offset of the next state's row (state * 16), bits 14..23 emission record number (0 = none)
+    // dev_trans[state*4 + sym]: bits 0..13 byte offset of the next state's row (state * 16), bits 14..23 emission record number (0 = none),
+    //   bits 24..26 the record holds a LiveThree / DeadThree / LiveTwo match (filter for the compound rescans)
     std::vector<uint32_t> dev_trans;
     // dev_records[4*r .. 4*r+3], r >= 1: the (at most two) matches one transition reports, two words each, second pair 0 if absent:
     //   w0: bits 0..3 type | bit 4 favour-is-black | bits 5..7 len | bits 8..10 number of deposits |
