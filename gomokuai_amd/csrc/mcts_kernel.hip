@@ -88,8 +88,15 @@ __device__ __forceinline__ bool five_through(const uint32_t* rows, int x, int y,
     return run_of_five(v) || run_of_five(d1) || run_of_five(d2);
 }
 
-// Default::RandomRollout (MonteCarlo.hpp:37-47) on a lane-private board; returns the winner (+1 / -1 / 0).
-__device__ int random_rollout(uint32_t* rows /* [y * 64] */, int to_move, int stones,
+// Line words of a position (the layout of K1): word = black | white << 16, bit = position along the line.
+// rows [0,15), columns [16,31), diagonals x-y+14 at [32,61), anti-diagonals x+y at [61,90).
+constexpr int kLineWords = 92;
+constexpr int kColBase = 16, kDiagBase = 32, kAntiBase = 61;
+
+// Default::RandomRollout (MonteCarlo.hpp:37-47) on a lane-private set of line words; returns the winner (+1 / -1 / 0).
+// A move sets one bit in the four lines through its cell; five-in-a-row through the new stone
+// (Board::checkGameEnd, Game.cpp:88-136) is a run of five in the mover's half of one of those four words.
+__device__ int random_rollout(uint32_t* lines /* [word * 64] */, int to_move, int stones,
                               uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     for (uint32_t k = 0;; ++k) {
@@ -101,28 +108,46 @@ __device__ int random_rollout(uint32_t* rows /* [y * 64] */, int to_move, int st
         const uint32_t r = word % 225u;                               // Board::getRandomMove (Game.cpp:64-73)
         int y = static_cast<int>(r / 15u);
         int x = static_cast<int>(r - 15u * static_cast<uint32_t>(y));
-        uint32_t rw = rows[y * 64];
+        uint32_t rw = lines[y * 64];
         uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
         while (!open) {                                               // linear probe with wrap
             y = (y == 14) ? 0 : y + 1;
-            rw = rows[y * 64];
+            rw = lines[y * 64];
             open = ~(rw | (rw >> 16)) & 0x7FFFu;
         }
         x = __ffs(open) - 1;
         const int shift = to_move > 0 ? 0 : 16;
-        rows[y * 64] = rw | (1u << (x + shift));
+        uint32_t* col = lines + (kColBase + x) * 64;
+        uint32_t* dia = lines + (kDiagBase + x - y + 14) * 64;
+        uint32_t* ant = lines + (kAntiBase + x + y) * 64;
+        const uint32_t r_new = rw | (1u << (x + shift));
+        const uint32_t c_new = *col | (1u << (y + shift));
+        const uint32_t d_new = *dia | (1u << (min(x, y) + shift));
+        const uint32_t a_new = *ant | (1u << (min(14 - x, y) + shift));
+        lines[y * 64] = r_new; *col = c_new; *dia = d_new; *ant = a_new;
         ++stones;
-        if (five_through<64>(rows, x, y, shift)) return to_move;
+        // two 15-bit lines per register (bit 15 and 31 are gaps), one run test each
+        const uint32_t rc = ((r_new >> shift) & 0x7FFFu) | (((c_new >> shift) & 0x7FFFu) << 16);
+        const uint32_t da = ((d_new >> shift) & 0x7FFFu) | (((a_new >> shift) & 0x7FFFu) << 16);
+        if (run_of_five(rc) || run_of_five(da)) return to_move;
         if (stones == 225) return 0;
         to_move = -to_move;
     }
 }
 
+// five or more through cell (x, y) for the colour in bits [shift, shift+15), from line words at lines[word * Stride]
+template <int Stride>
+__device__ __forceinline__ bool five_on_lines(const uint32_t* lines, int x, int y, int shift) {
+    const uint32_t rc = ((lines[y * Stride] >> shift) & 0x7FFFu) | (((lines[(kColBase + x) * Stride] >> shift) & 0x7FFFu) << 16);
+    const uint32_t da = ((lines[(kDiagBase + x - y + 14) * Stride] >> shift) & 0x7FFFu) | (((lines[(kAntiBase + x + y) * Stride] >> shift) & 0x7FFFu) << 16);
+    return run_of_five(rc) || run_of_five(da);
+}
+
 __global__ __launch_bounds__(64)
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
                           uint32_t* __restrict__ parent, const float* __restrict__ root_prior, SearchParams prm) {
-    __shared__ uint32_t s_lane_board[16 * 64];                   // rollout boards, [row][lane]
-    __shared__ uint32_t s_leaf[kMaxGamesPerBlock][16];           // leaf position of each game
+    __shared__ uint32_t s_lane_lines[kLineWords * 64];           // rollout positions as line words, [word][lane]
+    __shared__ uint32_t s_leaf[kMaxGamesPerBlock][kLineWords];   // leaf position of each game as line words (rows first)
     __shared__ uint32_t s_cur[kMaxGamesPerBlock], s_ply[kMaxGamesPerBlock], s_last[kMaxGamesPerBlock];
     __shared__ uint32_t s_need[kMaxGamesPerBlock];               // 1: leaf needs rollouts, 0: terminal
     __shared__ float s_term_value[kMaxGamesPerBlock];
@@ -188,7 +213,21 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     if (l16 == static_cast<int>(last / 15u)) row |= 1u << ((last % 15u) + ((ply & 1u) ? 16u : 0u));   // Policy::applyMove, no victory check
                     ++ply;
                 }
-                s_leaf[gs][l16] = (l16 < 15) ? row : 0u;
+                // leaf position -> line words: rows as they are, one OR per stone into column / diagonal / anti-diagonal
+                for (int w = l16; w < kLineWords; w += 16) s_leaf[gs][w] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (l16 < 15) {
+                    s_leaf[gs][l16] = row;
+                    for (uint32_t m = (row | (row >> 16)) & 0x7FFFu; m; m &= m - 1u) {
+                        const int x = __ffs(m) - 1, y = l16;
+                        const uint32_t cb = ((row >> x) & 1u) ? 0u : 16u;
+                        atomicOr(&s_leaf[gs][kColBase + x], 1u << (y + cb));
+                        atomicOr(&s_leaf[gs][kDiagBase + x - y + 14], 1u << (min(x, y) + cb));
+                        atomicOr(&s_leaf[gs][kAntiBase + x + y], 1u << (min(14 - x, y) + cb));
+                    }
+                }
                 if (l16 == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; }
             }
         }
@@ -198,7 +237,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         if (lane < games_here && s_active[lane]) {
             const uint32_t ply = s_ply[lane], last = s_last[lane];
             bool five = false;
-            if (ply > 0 && last < 225u) five = five_through<1>(s_leaf[lane], static_cast<int>(last % 15u), static_cast<int>(last / 15u), (ply & 1u) ? 0 : 16);
+            if (ply > 0 && last < 225u) five = five_on_lines<1>(s_leaf[lane], static_cast<int>(last % 15u), static_cast<int>(last / 15u), (ply & 1u) ? 0 : 16);
             const bool over = five || ply == 225u;
             s_need[lane] = over ? 0u : 1u;
             s_term_value[lane] = five ? 1.0f : 0.0f;                 // CalcScore(node->player, winner): the mover won, or a tie
@@ -209,12 +248,11 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         {
             const int gs = lane / R, r = lane - gs * R;
             if (gs < games_here && gs < G && s_active[gs] && s_need[gs]) {
-#pragma unroll
-                for (int y = 0; y < 15; ++y) s_lane_board[y * 64 + lane] = s_leaf[gs][y];
+                for (int w = 0; w < kLineWords; ++w) s_lane_lines[w * 64 + lane] = s_leaf[gs][w];
                 const uint32_t ply = s_ply[gs];
                 const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
                 const GameHeader& hdr = headers[game0 + gs];
-                const int winner = random_rollout(&s_lane_board[lane], init_player, static_cast<int>(ply), hdr.game_id,
+                const int winner = random_rollout(&s_lane_lines[lane], init_player, static_cast<int>(ply), hdr.game_id,
                                                   hdr.playouts_done + static_cast<uint32_t>(playout), (hdr.stones << 8) | static_cast<uint32_t>(r),
                                                   prm.seed_lo, prm.seed_hi);
                 atomicAdd(&s_sum[gs], init_player * winner);         // CalcScore(init_player, winner)
