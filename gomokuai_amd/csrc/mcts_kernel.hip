@@ -31,6 +31,7 @@ namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kMaxGamesPerBlock = 16;
+constexpr int kPathCap = 32;           // deeper descents fall back to walking parent[] with loads
 
 struct GameHeader {                 // 128 B per game, in HBM
     uint32_t rows[16];              // root position: black | white << 16 per row
@@ -56,6 +57,8 @@ struct SearchParams {
     int node_capacity;
     int n_games;
     int playouts;
+    int rollout_stride_log2;
+    int profile;                    // GMK_MCTS_PROFILE=1: per-phase shader-clock sums into GameHeader::pad (diagnostic runs only)
 };
 
 __constant__ float c_prior[226];          // 1.0f / float(n) evaluated on the host (MonteCarlo.hpp:50-55)
@@ -96,7 +99,7 @@ constexpr int kColBase = 16, kDiagBase = 32, kAntiBase = 61;
 // Default::RandomRollout (MonteCarlo.hpp:37-47) on a lane-private set of line words; returns the winner (+1 / -1 / 0).
 // A move sets one bit in the four lines through its cell; five-in-a-row through the new stone
 // (Board::checkGameEnd, Game.cpp:88-136) is a run of five in the mover's half of one of those four words.
-__device__ int random_rollout(uint32_t* lines /* [word * 64] */, int to_move, int stones,
+__device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int stride_log2, int to_move, int stones,
                               uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     for (uint32_t k = 0;; ++k) {
@@ -108,23 +111,23 @@ __device__ int random_rollout(uint32_t* lines /* [word * 64] */, int to_move, in
         const uint32_t r = word % 225u;                               // Board::getRandomMove (Game.cpp:64-73)
         int y = static_cast<int>(r / 15u);
         int x = static_cast<int>(r - 15u * static_cast<uint32_t>(y));
-        uint32_t rw = lines[y * 64];
+        uint32_t rw = lines[y << stride_log2];
         uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
         while (!open) {                                               // linear probe with wrap
             y = (y == 14) ? 0 : y + 1;
-            rw = lines[y * 64];
+            rw = lines[y << stride_log2];
             open = ~(rw | (rw >> 16)) & 0x7FFFu;
         }
         x = __ffs(open) - 1;
         const int shift = to_move > 0 ? 0 : 16;
-        uint32_t* col = lines + (kColBase + x) * 64;
-        uint32_t* dia = lines + (kDiagBase + x - y + 14) * 64;
-        uint32_t* ant = lines + (kAntiBase + x + y) * 64;
+        uint32_t* col = lines + ((kColBase + x) << stride_log2);
+        uint32_t* dia = lines + ((kDiagBase + x - y + 14) << stride_log2);
+        uint32_t* ant = lines + ((kAntiBase + x + y) << stride_log2);
         const uint32_t r_new = rw | (1u << (x + shift));
         const uint32_t c_new = *col | (1u << (y + shift));
         const uint32_t d_new = *dia | (1u << (min(x, y) + shift));
         const uint32_t a_new = *ant | (1u << (min(14 - x, y) + shift));
-        lines[y * 64] = r_new; *col = c_new; *dia = d_new; *ant = a_new;
+        lines[y << stride_log2] = r_new; *col = c_new; *dia = d_new; *ant = a_new;
         ++stones;
         // two 15-bit lines per register (bit 15 and 31 are gaps), one run test each
         const uint32_t rc = ((r_new >> shift) & 0x7FFFu) | (((c_new >> shift) & 0x7FFFu) << 16);
@@ -146,7 +149,7 @@ __device__ __forceinline__ bool five_on_lines(const uint32_t* lines, int x, int 
 __global__ __launch_bounds__(64)
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
                           uint32_t* __restrict__ parent, const float* __restrict__ root_prior, SearchParams prm) {
-    __shared__ uint32_t s_lane_lines[kLineWords * 64];           // rollout positions as line words, [word][lane]
+    extern __shared__ uint32_t s_lane_lines[];                   // rollout positions as line words, [word][rollout lane]: kLineWords * G * R words
     __shared__ uint32_t s_leaf[kMaxGamesPerBlock][kLineWords];   // leaf position of each game as line words (rows first)
     __shared__ uint32_t s_cur[kMaxGamesPerBlock], s_ply[kMaxGamesPerBlock], s_last[kMaxGamesPerBlock];
     __shared__ uint32_t s_need[kMaxGamesPerBlock];               // 1: leaf needs rollouts, 0: terminal
@@ -154,7 +157,11 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     __shared__ int s_sum[kMaxGamesPerBlock];
     __shared__ uint32_t s_nodes[kMaxGamesPerBlock], s_status[kMaxGamesPerBlock];
     __shared__ unsigned long long s_bytes[kMaxGamesPerBlock];
-    __shared__ uint32_t s_active[kMaxGamesPerBlock];             // 0: the game is over (status bit 0), nothing to search
+    __shared__ uint32_t s_active[kMaxGamesPerBlock];
+    // the descent path with the statistics select already loaded: backup needs no loads (MonteCarlo.hpp:90-95)
+    __shared__ uint32_t s_path_node[kMaxGamesPerBlock][kPathCap], s_path_visits[kMaxGamesPerBlock][kPathCap];
+    __shared__ float s_path_value[kMaxGamesPerBlock][kPathCap];
+    __shared__ uint32_t s_depth[kMaxGamesPerBlock];             // 0: the game is over (status bit 0), nothing to search
 
     const int lane = threadIdx.x, quarter = lane >> 4, l16 = lane & 15;
     const int G = prm.games_per_block, R = prm.c_rollouts;
@@ -172,6 +179,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     }
     __syncthreads();
 
+    unsigned long long prof[4] = {0, 0, 0, 0}, t_mark = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;   // diagnostic build only
     for (int playout = 0; playout < prm.playouts; ++playout) {
         if (lane < kMaxGamesPerBlock) s_sum[lane] = 0;
 
@@ -184,22 +192,39 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                 uint32_t row = hdr.rows[l16];                        // lane y holds row y of the board
                 uint32_t cur = hdr.root, ply = hdr.stones, last = hdr.last_move;
                 unsigned long long bytes = 0;
+                uint2 cur_stats = stats[base + cur];
+                uint32_t depth = 0;
                 for (;;) {
+                    if (l16 == 0 && depth < kPathCap) { s_path_node[gs][depth] = cur; s_path_visits[gs][depth] = cur_stats.x; s_path_value[gs][depth] = __uint_as_float(cur_stats.y); }
                     const uint32_t first = link[base + cur] >> 8;
                     if (!first) break;                               // Node::isLeaf
                     const int n_child = 225 - static_cast<int>(ply);
-                    const double n_parent = static_cast<double>(stats[base + cur].x);
+                    const double n_parent = static_cast<double>(cur_stats.x);
                     const double root_n = sqrt(n_parent);
                     const double explore = prm.c_puct * static_cast<double>(c_prior[n_child]) * root_n;   // MonteCarlo.hpp:23-28
                     const bool noisy = hdr.noise && cur == hdr.root;  // only the root's children ever carry non-uniform priors
-                    double best = -1.0;
+                    // Default::Select starts from max_score = -1.0 with index 0 and takes strictly greater scores; every
+                    // score is >= -1 (Q in [-1,1], bonus >= 0), so that equals "first maximum", which -2.0 yields lane-locally
+                    double best = -2.0;
                     int best_i = 0;
-                    for (int i = l16; i < n_child; i += 16) {
-                        const uint2 st = stats[base + first + i];
-                        double bonus = explore;
-                        if (noisy) bonus = prm.c_puct * static_cast<double>(root_prior[static_cast<size_t>(game0 + gs) * 225 + i]) * root_n;
-                        const double score = static_cast<double>(__uint_as_float(st.y)) + bonus / static_cast<double>(st.x + 1u);
-                        if (score > best) { best = score; best_i = i; }
+                    uint2 best_st = make_uint2(0u, 0u);
+                    // all of this lane's children (i = l16, l16 + 16, ...: at most 15) are fetched before any is scored, so
+                    // the loads overlap instead of queueing behind each other's f64 divide
+                    uint2 st[15];
+#pragma unroll
+                    for (int j = 0; j < 15; ++j) {
+                        const int i = l16 + 16 * j;
+                        st[j] = (i < n_child) ? stats[base + first + i] : make_uint2(0u, 0u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 15; ++j) {
+                        const int i = l16 + 16 * j;
+                        if (i < n_child) {
+                            double bonus = explore;
+                            if (noisy) bonus = prm.c_puct * static_cast<double>(root_prior[static_cast<size_t>(game0 + gs) * 225 + i]) * root_n;
+                            const double score = static_cast<double>(__uint_as_float(st[j].y)) + bonus / static_cast<double>(st[j].x + 1u);
+                            if (score > best) { best = score; best_i = i; best_st = st[j]; }
+                        }
                     }
 #pragma unroll
                     for (int m = 8; m >= 1; m >>= 1) {               // first maximum wins (strict > in ascending order)
@@ -209,9 +234,31 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     }
                     bytes += static_cast<unsigned long long>(n_child) * 8ull;
                     cur = first + static_cast<uint32_t>(best_i);
-                    last = link[base + cur] & 0xFFu;
-                    if (l16 == static_cast<int>(last / 15u)) row |= 1u << ((last % 15u) + ((ply & 1u) ? 16u : 0u));   // Policy::applyMove, no victory check
+                    // the statistics of the chosen child sit in the lane that scored it (children i = l16 mod 16)
+                    cur_stats.x = __shfl(best_st.x, best_i & 15, 16);
+                    cur_stats.y = __shfl(best_st.y, best_i & 15, 16);
+                    // its cell = the best_i-th empty cell of the current position in ascending order (children are created
+                    // that way, MonteCarlo.hpp:71-80): no dependent load of link[]
+                    {
+                        const uint32_t open = (l16 < 15) ? (~(row | (row >> 16)) & 0x7FFFu) : 0u;
+                        const int mine = __popc(open);
+                        int incl = mine;
+#pragma unroll
+                        for (int d = 1; d < 16; d <<= 1) {
+                            const int t = __shfl_up(incl, d, 16);
+                            if (l16 >= d) incl += t;
+                        }
+                        const int skip = best_i - (incl - mine);
+                        const bool owner = skip >= 0 && skip < mine;
+                        uint32_t m = open;
+                        for (int t = 0; t < skip && owner; ++t) m &= m - 1u;
+                        const uint32_t cell = static_cast<uint32_t>(l16) * 15u + static_cast<uint32_t>(__ffs(m) - 1);
+                        const unsigned long long who = __ballot(owner) >> (quarter * 16);
+                        last = __shfl(cell, __ffsll(static_cast<long long>(who & 0xFFFFull)) - 1, 16);
+                        if (owner) row |= 1u << ((cell % 15u) + ((ply & 1u) ? 16u : 0u));       // Policy::applyMove, no victory check
+                    }
                     ++ply;
+                    ++depth;
                 }
                 // leaf position -> line words: rows as they are, one OR per stone into column / diagonal / anti-diagonal
                 for (int w = l16; w < kLineWords; w += 16) s_leaf[gs][w] = 0u;
@@ -228,10 +275,11 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         atomicOr(&s_leaf[gs][kAntiBase + x + y], 1u << (min(14 - x, y) + cb));
                     }
                 }
-                if (l16 == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; }
+                if (l16 == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; s_depth[gs] = depth; }
             }
         }
         __syncthreads();
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[0] += t - t_mark; t_mark = t; }
 
         // ---- terminal test at the leaf (Policy::checkGameEnd, MCTS.cpp:166) ----
         if (lane < games_here && s_active[lane]) {
@@ -243,22 +291,25 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
             s_term_value[lane] = five ? 1.0f : 0.0f;                 // CalcScore(node->player, winner): the mover won, or a tie
         }
         __syncthreads();
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[1] += t - t_mark; t_mark = t; }
 
         // ---- simulate: one lane per rollout (Random.h:22-35) ----
         {
             const int gs = lane / R, r = lane - gs * R;
             if (gs < games_here && gs < G && s_active[gs] && s_need[gs]) {
-                for (int w = 0; w < kLineWords; ++w) s_lane_lines[w * 64 + lane] = s_leaf[gs][w];
+                const int rl_log2 = prm.rollout_stride_log2;         // rollout lanes of this block, rounded up to a power of two
+                for (int w = 0; w < kLineWords; ++w) s_lane_lines[(w << rl_log2) + lane] = s_leaf[gs][w];
                 const uint32_t ply = s_ply[gs];
                 const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
                 const GameHeader& hdr = headers[game0 + gs];
-                const int winner = random_rollout(&s_lane_lines[lane], init_player, static_cast<int>(ply), hdr.game_id,
+                const int winner = random_rollout(&s_lane_lines[lane], rl_log2, init_player, static_cast<int>(ply), hdr.game_id,
                                                   hdr.playouts_done + static_cast<uint32_t>(playout), (hdr.stones << 8) | static_cast<uint32_t>(r),
                                                   prm.seed_lo, prm.seed_hi);
                 atomicAdd(&s_sum[gs], init_player * winner);         // CalcScore(init_player, winner)
             }
         }
         __syncthreads();
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[2] += t - t_mark; t_mark = t; }
 
         // ---- expand + backup: quarter-wave per game (MonteCarlo.hpp:71-95) ----
         for (int round = 0; round < rounds; ++round) {
@@ -302,7 +353,19 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                 } else {
                     value = s_term_value[gs];                        // MCTS.cpp:172
                 }
-                if (l16 == 0) {                                      // Default::BackPropogate
+                // Default::BackPropogate: level d of the path gets value * (-1)^(depth - d); the old statistics came with
+                // select, so every level is one independent store (one lane per level)
+                const uint32_t depth = s_depth[gs];
+                if (depth < kPathCap) {
+                    for (uint32_t d = l16; d <= depth; d += 16) {
+                        const uint32_t visits = s_path_visits[gs][d] + 1u;
+                        float q = s_path_value[gs][d];
+                        const float v = ((depth - d) & 1u) ? -value : value;
+                        q += (v - q) / static_cast<float>(visits);
+                        stats[base + s_path_node[gs][d]] = make_uint2(visits, __float_as_uint(q));
+                    }
+                    bytes += 16ull * (depth + 1u);
+                } else if (l16 == 0) {                               // very deep path: walk parent[] (loads)
                     for (uint32_t node = cur; node != kNone; node = parent[base + node], value = -value) {
                         uint2 st = stats[base + node];
                         st.x += 1u;
@@ -312,11 +375,14 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         stats[base + node] = st;
                         bytes += 16ull;
                     }
+                }
+                if (l16 == 0) {
                     s_bytes[gs] += bytes;
                 }
             }
         }
         __syncthreads();
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[3] += t - t_mark; t_mark = t; }
     }
 
     if (lane < games_here) {
@@ -324,6 +390,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         headers[game0 + lane].status = s_status[lane];
         headers[game0 + lane].alg_bytes = s_bytes[lane];
         if (s_active[lane]) headers[game0 + lane].playouts_done += static_cast<uint32_t>(prm.playouts);
+        if (prm.profile) for (int k = 0; k < 4; ++k) headers[game0 + lane].pad[k] = static_cast<uint32_t>(prof[k] >> 10);
     }
 }
 
@@ -572,8 +639,12 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     prm.c_rollouts = m->c_rollouts; prm.games_per_block = m->games_per_block;
     prm.node_capacity = m->node_capacity; prm.n_games = m->n_games; prm.playouts = playouts;
     const int grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
+    int stride_log2 = 0;
+    while ((1 << stride_log2) < m->games_per_block * m->c_rollouts) ++stride_log2;
+    prm.rollout_stride_log2 = stride_log2;
+    prm.profile = std::getenv("GMK_MCTS_PROFILE") ? 1 : 0;
     m->last_stream = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
+    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), (static_cast<size_t>(kLineWords) << stride_log2) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
                        m->d_root_prior, prm);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
@@ -653,7 +724,7 @@ extern "C" int gmk_mcts_launch_info(gmk_mcts* m, int* grid, int* block, int* lds
     if (!m) return GMK_ERR_ARG;
     if (grid) *grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
     if (block) *block = 64;
-    if (lds_bytes) *lds_bytes = 16 * 64 * 4 + kMaxGamesPerBlock * (16 * 4 + 4 * 8 + 8);
+    if (lds_bytes) *lds_bytes = kLineWords * m->games_per_block * m->c_rollouts * 4 + kMaxGamesPerBlock * (kLineWords * 4 + kPathCap * 12 + 48);
     return GMK_OK;
 }
 
@@ -692,6 +763,12 @@ extern "C" int gmk_mcts_alg_bytes(gmk_mcts* m, uint64_t* bytes) {
     GMK_HIP_CHECK(hipMemcpy(hdr.data(), m->d_headers, sizeof(GameHeader) * hdr.size(), hipMemcpyDeviceToHost));
     uint64_t total = 0;
     for (const GameHeader& h : hdr) total += h.alg_bytes;
+    if (std::getenv("GMK_MCTS_PROFILE")) {
+        double p[4] = {0, 0, 0, 0};
+        for (const GameHeader& h : hdr) for (int k = 0; k < 4; ++k) p[k] += h.pad[k];
+        std::fprintf(stderr, "[gmk profile] mean kilo-cycles per game-slot: select %.0f terminal %.0f rollout %.0f expand+backup %.0f\n",
+                     p[0] / hdr.size(), p[1] / hdr.size(), p[2] / hdr.size(), p[3] / hdr.size());
+    }
     *bytes = total;
     return GMK_OK;
 }

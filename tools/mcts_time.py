@@ -1,4 +1,4 @@
-import time, numpy as np, sys
+import time, numpy as np, sys, os
 sys.path.insert(0,'.')
 from gomokuai_amd import lib as G
 import torch
@@ -7,8 +7,8 @@ moves,lens,_=G.synth_boards(n,0)
 lens=np.minimum(lens,4).astype(np.int32)
 planes=G.moves_to_planes(moves,lens)
 last=np.array([moves[i,lens[i]-1] for i in range(n)],dtype=np.int16)
-import os
-t=G.BatchedMCTS(n,playouts_capacity=P)
+R=int(os.environ.get('ROLLOUTS','5'))
+t=G.BatchedMCTS(n,playouts_capacity=P,c_rollouts=R)
 print('gpb env',os.environ.get('GMK_MCTS_GAMES_PER_BLOCK'),t.launch_info())
 for rep in range(2):
     t.set_roots(planes,last,0)
