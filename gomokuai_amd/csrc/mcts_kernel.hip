@@ -14,7 +14,7 @@
 //     games proceed concurrently per wave so that their dependent HBM loads overlap;
 //   * the simulate phase gives every ROLLOUT a lane: lane = (game, rollout); each lane plays its random
 //     game on a private bit-board kept in LDS (column layout [row][lane]: conflict-free), draws come from
-//     Philox4x32-10 keyed by (seed; game, playout, root stones << 8 | rollout, ply >> 2);
+//     Philox4x32-10 keyed by (seed; game, playout, root stones << 8 | rollout, ply >> 3), eight 16-bit draws per block;
 //   * the tree lives in HBM, one arena per game, structure-of-arrays: stats {visits u32, value f32} (8 B,
 //     what select reads per child), link {first child << 8 | cell} and parent (4 B each).
 #include <algorithm>
@@ -103,12 +103,13 @@ __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int s
                               uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     for (uint32_t k = 0;; ++k) {
-        if ((k & 3u) == 0u) {
-            const gmk::Philox4 p = gmk::philox4x32_10(game_id, playout, c2, k >> 2, k0, k1);
+        if ((k & 7u) == 0u) {                                         // one Philox block = eight 16-bit draws
+            const gmk::Philox4 p = gmk::philox4x32_10(game_id, playout, c2, k >> 3, k0, k1);
             w0 = p.v[0]; w1 = p.v[1]; w2 = p.v[2]; w3 = p.v[3];
         }
-        const uint32_t word = (k & 2u) ? ((k & 1u) ? w3 : w2) : ((k & 1u) ? w1 : w0);
-        const uint32_t r = word % 225u;                               // Board::getRandomMove (Game.cpp:64-73)
+        const uint32_t word = (k & 4u) ? ((k & 2u) ? w3 : w2) : ((k & 2u) ? w1 : w0);
+        const uint32_t half = (k & 1u) ? (word >> 16) : (word & 0xFFFFu);
+        const uint32_t r = (half * 225u) >> 16;                       // uniform cell draw of Board::getRandomMove (Game.cpp:64-73)
         int y = static_cast<int>(r / 15u);
         int x = static_cast<int>(r - 15u * static_cast<uint32_t>(y));
         uint32_t rw = lines[y << stride_log2];

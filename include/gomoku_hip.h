@@ -106,8 +106,8 @@ int gmk_eval_launch_info(int n, int *grid, int *block, int *lds_bytes);
  *   simulate c_rollouts uniform-probe random games (Game.cpp:64-73), value = float(sum / c_rollouts)
  *   backup   visits += 1; value += (v - value) / float(visits); v = -v, up to the root
  * The reference's random_device-seeded mt19937 is replaced by Philox4x32-10 with
- *   key = seed, counter = (global game id, playout index, (stones on the root board << 8) | rollout, ply >> 2),
- *   word ply & 3, move draw = word % 225
+ *   key = seed, counter = (global game id, playout index, (stones on the root board << 8) | rollout, ply >> 3);
+ *   ply p uses the 16-bit half (p & 1) of output word (p >> 1) & 3, cell draw = (half * 225) >> 16
  * so results do not depend on how games are spread over GPUs.
  * Node capacity per game: at most 225 - stones new nodes per playout; exceeding it sets bit 1 of status. */
 typedef struct gmk_mcts gmk_mcts;

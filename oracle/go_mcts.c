@@ -172,8 +172,9 @@ static size_t default_expand(go_mcts *m, int32_t ni, const go_board *b) {
     return (size_t)count;
 }
 
-/* Random.h:22-35 + MonteCarlo.hpp:37-47.  RNG: counter = (game, playout, search<<8 | rollout, ply>>2),
-   word ply&3, key = seed; draw = word % 225 then the probe rule (Game.cpp:68-72). */
+/* Random.h:22-35 + MonteCarlo.hpp:37-47.  RNG: Philox counter = (game, playout, search<<8 | rollout, ply>>3), key = seed;
+   ply p takes the 16-bit half (p&1) of word (p>>1)&3; cell draw = (half * 225) >> 16, then the probe rule (Game.cpp:68-72).
+   (The KAT hook keeps the survey's recipe: id = mt19937() % 225.) */
 static float averaged_simulate(go_mcts *m, go_board *b, uint32_t playout) {
     int init_player = b->cur_player;
     double score = 0;
@@ -182,13 +183,18 @@ static float averaged_simulate(go_mcts *m, go_board *b, uint32_t playout) {
         int total_moves = 0;
         uint32_t words[4] = { 0, 0, 0, 0 };
         for (int result = b->cur_player; result != GO_NONE; ++total_moves) {
+            unsigned draw;
             if (m->use_mt) {
-                words[total_moves & 3] = go_mt_next(&m->mt);
-            } else if ((total_moves & 3) == 0) {
-                uint32_t ctr[4] = { m->game_id, playout, ((uint32_t)m->init_acts << 8) | (uint32_t)i, (uint32_t)total_moves >> 2 };
-                go_philox4x32(ctr, key, words);
+                draw = go_mt_next(&m->mt) % GO_N;
+            } else {
+                if ((total_moves & 7) == 0) {
+                    uint32_t ctr[4] = { m->game_id, playout, ((uint32_t)m->init_acts << 8) | (uint32_t)i, (uint32_t)total_moves >> 3 };
+                    go_philox4x32(ctr, key, words);
+                }
+                uint32_t half = (words[(total_moves >> 1) & 3] >> (16 * (total_moves & 1))) & 0xFFFFu;
+                draw = (half * 225u) >> 16;
             }
-            result = go_board_apply(b, go_board_random_move(b, words[total_moves & 3] % GO_N), 1);
+            result = go_board_apply(b, go_board_random_move(b, draw), 1);
         }
         score += (double)((float)init_player * (float)b->winner);   /* CalcScore (Game.h:34-36) */
         go_board_revert(b, total_moves);
