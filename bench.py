@@ -15,6 +15,15 @@ ALG_BYTES_PER_EVAL = 64 + 3600 + 3600 + 44 + 4      # planes in;
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(kernel, units_key, units):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), scaled to this launch."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel]
+        return t["hbm_bytes_per_launch"] * units / t[units_key]
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_sample, kind):
     """The CPU oracle (restatement of the reference's incremental evaluator: replay of each move list)
     timed single-threaded on this host, on a bounded sample of the same workload."""
@@ -72,7 +81,8 @@ def bench_mcts(args, G, torch, dev, rank, world, distributed):
     return {"metric": "mcts-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms,
             "config": {"workload": "batched MCTS (K3), %d games x %d playouts per GPU, RandomPolicy c_puct=5 c_rollouts=5, 4-ply openings, fresh roots" % (n, P)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mcts_playouts_kernel", "kernel_ms": ms, "alg_bytes_per_launch": alg,
+                         "traffic": measured_traffic("mcts_playouts_kernel", "playouts_per_launch", n * P),
+                         "kernel": "mcts_playouts_kernel", "kernel_ms": ms, "alg_bytes_per_launch": alg,
                          "note": "tree bytes only (select 8 B/child, expand 16 B/node, backup 16 B/level); rollouts run in LDS/registers, the kernel is latency/issue bound"}}
 
 
@@ -82,17 +92,18 @@ def cpu_baseline_mcts(playouts):
     import numpy as np
     from gomokuai_amd import lib as G
     from oracle import oracle as O
-    moves, lens, _, _ = mcts_openings(G, np, 16, 0)
+    n_max = 2048
+    moves, lens, _, _ = mcts_openings(G, np, n_max, 0)
     L = O.lib()
     t0 = time.perf_counter()
     done = 0
-    for g in range(16):
+    for g in range(n_max):
         b = O.new_board()
         for i in range(int(lens[g])):
             L.go_board_apply(C.byref(b), int(moves[g, i]), 1)
         O.MCTS(playouts, 5.0, 5, G.DEFAULT_SEED, g).run_playouts(b)
         done += playouts
-        if time.perf_counter() - t0 > 15:
+        if time.perf_counter() - t0 > 10:
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "playouts/s", "cores": 1, "kind": "port",
@@ -191,7 +202,8 @@ def main():
                                    % (n, "random-opening" if args.kind == 0 else "clustered"),
                        "boards_per_gpu": n, "parallelism": "boards sharded by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("eval_positions_kernel", "boards_per_launch", n),
                          "kernel": "eval_positions_kernel", "kernel_ms": kernel_ms,
                          "alg_bytes_per_launch": ALG_BYTES_PER_EVAL * n},
         }
