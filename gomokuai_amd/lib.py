@@ -29,7 +29,7 @@ EXPORTS = [
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
-    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_add_root_noise",
+    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
 ]
 
 
@@ -80,6 +80,7 @@ def load():
     L.gmk_visits_to_pi.argtypes = [vp, C.c_int, vp]
     L.gmk_mcts_advance.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.gmk_mcts_add_root_noise.argtypes = [vp, C.c_float, C.c_float, vp]
+    L.gmk_samples_from_records.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -251,3 +252,10 @@ def visits_to_pi(visits, stones):
     pi = np.zeros(N, dtype=np.float32)
     _check(load().gmk_visits_to_pi(v.ctypes.data, int(stones), pi.ctypes.data))
     return pi
+
+
+def samples_from_records(d_moves, d_lens, d_visits, d_winner, d_sample_game, d_sample_move, n_samples, augment,
+                         d_states, d_values, d_pi, stream=None):
+    """Device-pointer form of gmk_samples_from_records (K4 + K5)."""
+    _check(load().gmk_samples_from_records(d_moves, d_lens, d_visits, d_winner, d_sample_game, d_sample_move, n_samples,
+                                           int(augment), d_states, d_values, d_pi, stream))

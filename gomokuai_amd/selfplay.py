@@ -28,6 +28,27 @@ class GameRecords:
         return GameRecords(self.moves.cpu(), self.lens.cpu(), self.winner.cpu(),
                            None if self.visits is None else self.visits.cpu(), self.first_game_id, self.overflow)
 
+    def to_samples(self, augment=False, first_move=0):
+        """All training tuples of all games, built ON THE GPU (K4 + K5, optionally with the eight-fold augmentation of
+        network/data_helper.py:36-55): -> (states uint8[S,6,15,15], values float32[S], pi float32[S,225]) as torch
+        tensors on the records' device, samples ordered by (game, move[, symmetry]).  first_move skips opening plies
+        that were not searched."""
+        assert self.visits is not None and self.moves.is_cuda
+        dev = self.moves.device
+        lens = self.lens.cpu().numpy()
+        game = np.concatenate([np.full(max(int(l) - first_move, 0), g, dtype=np.int32) for g, l in enumerate(lens)] or [np.zeros(0, np.int32)])
+        move = np.concatenate([np.arange(first_move, int(l), dtype=np.int32) for l in lens] or [np.zeros(0, np.int32)])
+        n = int(game.shape[0])
+        copies = 8 if augment else 1
+        d_game, d_move = torch.from_numpy(game).to(dev), torch.from_numpy(move).to(dev)
+        states = torch.empty((n * copies, 6, 15, 15), dtype=torch.uint8, device=dev)
+        values = torch.empty(n * copies, dtype=torch.float32, device=dev)
+        pi = torch.empty((n * copies, N), dtype=torch.float32, device=dev)
+        G.samples_from_records(self.moves.data_ptr(), self.lens.data_ptr(), self.visits.data_ptr(), self.winner.data_ptr(),
+                               d_game.data_ptr(), d_move.data_ptr(), n, augment, states.data_ptr(), values.data_ptr(), pi.data_ptr(),
+                               torch.cuda.current_stream(dev).cuda_stream)
+        return states, values, pi
+
     def samples(self, game):
         """The training tuples of one game as `dual_play(verbose=True)` returns them (agents/utils.py:36-40, 55-59):
         [(uint8[6,15,15] encoded states, float score for the player to move, float32[225] pi)]."""

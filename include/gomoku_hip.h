@@ -146,6 +146,17 @@ int gmk_mcts_launch_info(gmk_mcts *m, int *grid, int *block, int *lds_bytes);
  * visits uint32[225], stones = moves on the board (temperature 1 below 15 stones, else 0.01). */
 int gmk_visits_to_pi(const uint32_t *visits, int stones, float *pi);
 
+/* ---- K4 + K5: game records -> training tuples, on the device ----
+ * Sample s = move d_sample_move[s] of game d_sample_game[s] of the records written by gmk_mcts_advance:
+ *   d_states uint8[S][6][225]  Board::encoded_states (core/py_ext/src/game_ext.hpp:87-104) of the position BEFORE that move,
+ *   d_values float[S]          Player::calc_score(player to move, winner) (agents/utils.py:55-59),
+ *   d_pi     float[S][225]     MCTS::evalState's action probabilities from the recorded visit counts (MCTS.cpp:104-117).
+ * augment != 0 writes the eight symmetric copies of every sample (network/data_helper.py:36-55: rot90^i, then fliplr of it):
+ * the outputs then hold 8*S samples, copy a of sample s at index 8*s + a.  All pointers are device pointers. */
+int gmk_samples_from_records(const uint8_t *d_moves, const int32_t *d_lens, const uint16_t *d_visits, const int8_t *d_winner,
+                             const int32_t *d_sample_game, const int32_t *d_sample_move, int n_samples, int augment,
+                             uint8_t *d_states, float *d_values, float *d_pi, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

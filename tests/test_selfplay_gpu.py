@@ -104,3 +104,24 @@ def test_root_noise_matches_oracle(oracle):
             assert (rec.visits[g, t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all()
         differs |= [int(x) for x in plain.moves[g, :int(plain.lens[g])]] != moves
     assert differs                      # the noise does change the games
+
+
+def test_device_samples_match_host_and_augmentation():
+    """K4 + K5 on the device == the host construction of the dual_play tuples (GameRecords.samples, itself checked
+    against Board.encoded_states in tests/test_selfplay.py), and the eight-fold copies == agents.augment_game_data."""
+    from gomokuai_amd import agents
+    rec = selfplay.play_games(3, 40, seed=21, first_game_id=5)
+    states, values, pi = (t.cpu().numpy() for t in rec.to_samples())
+    k = 0
+    for g in range(3):
+        host = rec.samples(g)
+        for st, val, p in host:
+            assert (states[k] == st).all() and values[k] == np.float32(val)
+            assert np.abs(pi[k] - p).max() <= 1e-6          # float32 log / double exp on device vs libm: tolerance
+            k += 1
+    assert k == states.shape[0]
+    a_states, a_values, a_pi = (t.cpu().numpy() for t in rec.to_samples(augment=True))
+    assert a_states.shape[0] == 8 * k
+    ref = agents.augment_game_data([(states[i], values[i], pi[i]) for i in range(k)])
+    for i, (st, val, p) in enumerate(ref):
+        assert (a_states[i] == st).all() and a_values[i] == val and (a_pi[i] == p).all()
