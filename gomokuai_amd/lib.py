@@ -30,6 +30,7 @@ EXPORTS = [
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
+    "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
 ]
 
 
@@ -80,6 +81,12 @@ def load():
     L.gmk_visits_to_pi.argtypes = [vp, C.c_int, vp]
     L.gmk_mcts_advance.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.gmk_mcts_add_root_noise.argtypes = [vp, C.c_float, C.c_float, vp]
+    L.gmk_evalstate_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.gmk_evalstate_destroy.argtypes = [vp]
+    L.gmk_evalstate_reset.argtypes = [vp]
+    L.gmk_evalstate_update.argtypes = [vp, vp, C.c_int, vp]
+    L.gmk_evalstate_update_host.argtypes = [vp, vp, C.c_int]
+    L.gmk_evalstate_read.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.gmk_samples_from_records.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
@@ -259,3 +266,41 @@ def samples_from_records(d_moves, d_lens, d_visits, d_winner, d_sample_game, d_s
     """Device-pointer form of gmk_samples_from_records (K4 + K5)."""
     _check(load().gmk_samples_from_records(d_moves, d_lens, d_visits, d_winner, d_sample_game, d_sample_move, n_samples,
                                            int(augment), d_states, d_values, d_pi, stream))
+
+
+# ---------------- K2: incrementally maintained evaluator states ----------------
+class EvaluatorStates:
+    """n_games device-resident Evaluator objects (gmk_evalstate_*): apply / revert moves, read the members back."""
+
+    APPLY_NONE, REVERT = -1, -2
+
+    def __init__(self, n_games):
+        init()
+        self.n = n_games
+        h = C.c_void_p()
+        _check(load().gmk_evalstate_create(n_games, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().gmk_evalstate_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(load().gmk_evalstate_reset(self.h))
+
+    def update(self, moves):
+        """moves int16[n, k]: per game k entries (cell >= 0 apply, -1 nothing, -2 revert the last move)."""
+        moves = np.ascontiguousarray(moves, dtype=np.int16)
+        assert moves.ndim == 2 and moves.shape[0] == self.n
+        _check(load().gmk_evalstate_update_host(self.h, moves.ctypes.data, moves.shape[1]))
+
+    def read(self):
+        out = {"scores": np.zeros((self.n, 4, N), np.int32), "density": np.zeros((self.n, 2, 2, N), np.int32),
+               "pattern_dist": np.zeros((self.n, 226, 8), np.uint32), "compound_dist": np.zeros((self.n, 226, 3), np.uint32),
+               "meta": np.zeros((self.n, 4), np.int32), "record": np.zeros((self.n, 228), np.uint8)}
+        _check(load().gmk_evalstate_read(self.h, out["scores"].ctypes.data, out["density"].ctypes.data, out["pattern_dist"].ctypes.data,
+                                         out["compound_dist"].ctypes.data, out["meta"].ctypes.data, out["record"].ctypes.data))
+        return out

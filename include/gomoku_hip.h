@@ -97,6 +97,26 @@ int gmk_eval_batch_host(const uint16_t *h_planes, int n,
 /* launch geometry the library chose for gmk_eval_batch (for profiling reports) */
 int gmk_eval_launch_info(int n, int *grid, int *block, int *lds_bytes);
 
+/* ---- K2: incrementally maintained evaluator states ----
+ * One handle = n_games Evaluator objects (core/lib/include/Pattern.h:142-220) living in HBM, 17 792 B each.  Unlike K1 it keeps
+ * everything the reference keeps, including the per-cell 2-bit flag words of m_patternDist / m_compoundDist, which are
+ * order-dependent shift registers (Pattern.cpp:395-400) and can only be reproduced by replaying the update rule.
+ * gmk_evalstate_update applies moves_per_game entries per game in one launch, entry m of game g at d_moves[g*moves_per_game+m]:
+ *   >= 0  Evaluator::applyMove(cell)   (Pattern.cpp:310-335; an illegal or post-game move is ignored, as there)
+ *   -1    nothing
+ *   -2    Evaluator::revertMove(1)     (Pattern.cpp:337-342)
+ * gmk_evalstate_read copies the members out: scores int32[n][4][225], density int32[n][2][2][225], pattern_dist uint32[n][226][8]
+ * (row 225 = totals), compound_dist uint32[n][226][3], meta int32[n][4] = {moves played, player to move, winner, error bits},
+ * record uint8[n][228] (m_moveRecord).  Any pointer may be NULL. */
+typedef struct gmk_evalstate gmk_evalstate;
+int gmk_evalstate_create(int n_games, gmk_evalstate **out);
+int gmk_evalstate_destroy(gmk_evalstate *e);
+int gmk_evalstate_reset(gmk_evalstate *e);                                   /* Evaluator::reset (Pattern.cpp:371-386) */
+int gmk_evalstate_update(gmk_evalstate *e, const int16_t *d_moves, int moves_per_game, void *stream);
+int gmk_evalstate_update_host(gmk_evalstate *e, const int16_t *h_moves, int moves_per_game);
+int gmk_evalstate_read(gmk_evalstate *e, int32_t *h_scores, int32_t *h_density, uint32_t *h_pattern_dist, uint32_t *h_compound_dist,
+                       int32_t *h_meta, uint8_t *h_record);
+
 /* ---- K3: batched MCTS with the reference's default RandomPolicy ----
  * One handle = n_games independent searches, each with its own tree arena in HBM.  Replaces, per game,
  * Gomoku::MCTS + Policies::RandomPolicy (core/lib/include/MCTS.h:135-180, core/lib/src/MCTS.cpp:99-198,
