@@ -5,19 +5,21 @@
 // scores[4][225], density[2][2][225], pattern / compound totals and winner.  The formulation is the one
 // validated against in-order replay in tests/test_formulation.py.
 //
-// Mapping onto CDNA4
-//   * one 64-lane wavefront per board, eight boards per 512-thread workgroup, persistent grid-stride loop:
-//     the automaton (dense DFA 556x4 words + emission records, ~14 KB) is staged into LDS ONCE per workgroup
-//     and reused for every board the workgroup evaluates; after that single barrier the waves never wait for
-//     each other (phases of one board are ordered by wavefront-scope fences only);
-//   * phase 0: the two bit-planes become 88 "line words" (rows, columns, both diagonals) with one LDS OR per stone;
+// The kernel is bound by VALU issue (PMC: ~85 % VALU busy, HBM traffic = the algorithmic bytes), so the design rule
+// below is "fewest wave-instructions per board":
+//   * one 64-lane wavefront per board, sixteen boards per 1024-thread workgroup (one workgroup per CU), persistent
+//     grid-stride loop: the automaton (dense DFA 556x4 words + emission records, ~14 KB) is staged at LDS address 0
+//     ONCE per workgroup, so a DFA step's address is just (next-row offset | symbol * 4); after that single barrier
+//     the waves never wait for each other (phases of one board are ordered by wavefront-scope fences only);
+//   * phase 0: the two bit-planes become 88 "line words" (rows, columns, both diagonals) that already hold the 2-bit
+//     DFA symbols of their cells (one LDS XOR per stone and line), plus the rows as 4-bit digits for phase 3;
 //   * phase 1: the 72 lines that can hold a pattern (>= 5 cells) are spread over the 64 lanes (the 8 shortest ride
-//     behind the shortest primaries: 19 steps per lane); a lane's lines are one stream of 2-bit symbols in a
-//     64-bit register, a step is one LDS lookup trans[row + sym]; emitting transitions are queued by ballot prefix;
+//     behind the shortest primaries: 19 steps per lane); a lane's lines are one stream of 2-bit symbols,
+//     a step is one LDS lookup; emitting transitions are queued by ballot prefix;
 //   * phase 2: one lane per queued transition: one 16-byte record read gives the (<= 2) matches, each with a
-//     compact list of <= 4 score deposits (ds_add_u32);
-//   * phase 3: one lane per cell: the 7x7 density stencil for both colours from packed 7-bit row windows with
-//     popcounts, area bonus, compound decision from 2-bit saturating per-cell counters;
+//     compact list of <= 4 score deposits (ds_add_u32) and 4-bit per-(cell, colour, direction, type) counters;
+//   * phase 3: one lane per cell: the 7x7 density stencil as v_dot8_u32_u4 dot products of digit windows with the
+//     block's weight rows, area bonus, compound decision from the counters;
 //   * phase 4: one lane per compound component: 13-symbol window rescan for its counter-move cells;
 //   * phase 5: the 3.6 KB score block leaves LDS as coalesced 16-byte stores.
 // HBM traffic per board: 64 B in, 7 248 B out (7 312 B algorithmic); everything else stays on chip.
@@ -29,49 +31,39 @@
 
 namespace {
 
-constexpr int kBoardsPerBlock = 8;
+constexpr int kBoardsPerBlock = 16;
 constexpr int kThreads = 64 * kBoardsPerBlock;
 constexpr int kCells = 225;
-constexpr int kQueueCap = 512;
-constexpr int kMaxBlocksPerCu = 2;
+constexpr int kQueueCap = 448;
+constexpr int kMaxBlocksPerCu = 1;
 
 // per-board LDS region (32-bit words)
 constexpr int kScoreWords = 4 * kCells;          // 900, 16-byte aligned block
-constexpr int kCntWords = 2 * kCells;            // per cell 2 words: [LiveThree | DeadThree << 16], [LiveTwo]; 2-bit fields [colour][dir]: bit0 ">= 1", bit1 ">= 2"
-constexpr int kRowGuard = 4;                     // zero words in front of the rows: the 7x7 stencil reads rows y-3 .. y+3 unchecked
-constexpr int kRowWords = 96;                    // line words, black | white << 16, bit = position along the line:
-                                                 // rows [0,15), zeros [15,20), columns [20,35), diagonals x-y+14 at [36,65), anti-diagonals x+y at [65,94)
+constexpr int kCntWords = 3 * kCells + 1;        // [LiveThree, DeadThree, LiveTwo][cell]: eight 4-bit counters per word, field = colour * 4 + direction:
+                                                 // how many '_' pieces of matches of that type lie on the cell (<= 15: at most 8 transitions x 2 matches reach a cell)
+constexpr int kNibWords = 21 * 6 + 2;            // stones as 4-bit digits for v_dot8_u32_u4: [row -3 .. 17][black, white][3 words]; a row is
+                                                 // 3 zero digits, 15 cells, 3 zero digits (+ 3 unused), so the 7 digits around column x start at digit x
+constexpr int kZeroWords = kNibWords + kScoreWords + kCntWords;      // cleared for every board (a multiple of 4); the digit rows come first:
+                                                                      // phase 3 reaches all 28 of its words from one base register with immediate offsets
+constexpr int kLineWords = 96;                   // line words, 2 bits per cell = its DFA symbol (0 black, 1 white, 3 blank), cell p of the line at bits 2p:
+                                                 // rows [0,15), columns [20,35), diagonals x-y+14 at [36,65), anti-diagonals x+y at [65,94)
 constexpr int kColBase = 20, kDiagBase = 36, kAntiBase = 65;
-constexpr int kMiscWords = 16;                   // [1] winner bits, [2] error, [3] compound queue count, [4..14] totals
-constexpr int kBoardWords = (kScoreWords + kCntWords + kRowGuard + kRowWords + kQueueCap + kMiscWords + 3) & ~3;   // keeps each board's score block 16-byte aligned
+constexpr int kMiscWords = 16;                   // [0] stones black | white << 16, [1] winner bits, [2] error, [3] compound queue count, [4..14] totals
+constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
+static_assert(kZeroWords % 4 == 0 && kBoardWords % 4 == 0, "16-byte alignment of the per-board blocks");
+constexpr int kStaticTableWords = 128 + kLineWords;   // lane jobs, initial line words
 
 // Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
+__constant__ uint32_t c_line_init[kLineWords];   // all cells blank: (1 << 2 len) - 1
 __constant__ int c_scan_steps;
 
 __device__ __forceinline__ int dir_stride(int dir) { return dir == 0 ? 1 : dir == 1 ? 15 : dir == 2 ? 16 : 14; }
 
-// spreads the low 15 bits of v to the even bit positions
-__device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
-    v = (v | (v << 8)) & 0x00FF00FFu;
-    v = (v | (v << 4)) & 0x0F0F0F0Fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
-    return v;
-}
-
-// the len cells of a line word (black | white << 16, bit = position) as 2-bit DFA symbols, first cell in the low
-// bits: 0 black, 1 white, 3 blank ('?' = 2 is the off-board symbol)
-__device__ __forceinline__ uint64_t cell_symbols(uint32_t lw, int len) {
-    const uint32_t in_line = (1u << len) - 1u;
-    const uint32_t black = lw & 0x7FFFu, white = lw >> 16;
-    const uint32_t lo = ~black & in_line, hi = ~(black | white) & in_line;      // blank 11, white 01, black 00
-    return static_cast<uint64_t>(spread_bits(lo) | (spread_bits(hi) << 1));
-}
-
-// '?' cells '?' '?': exactly 2 * (len + 3) bits (1 leading + 2 trailing pads instead of the reference's 6 + 6)
-__device__ __forceinline__ uint64_t line_symbols(uint32_t lw, int len) {
-    return 2ull | (cell_symbols(lw, len) << 2) | (0xAull << (2 * len + 2));
+// '?' cells '?' '?' of one line as a symbol stream, first symbol in the low bits: exactly 2 * (len + 3) bits
+// (1 leading + 2 trailing pads instead of the reference's 6 + 6; '?' = 2 is the off-board symbol)
+__device__ __forceinline__ uint64_t line_symbols(uint32_t line_word, int len) {
+    return 2ull | (static_cast<uint64_t>(line_word) << 2) | (0xAull << (2 * len + 2));
 }
 
 // Phases of one board only exchange data between lanes of the SAME wavefront through LDS.  LDS instructions of
@@ -96,6 +88,8 @@ __device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell
     uint32_t* own = s_scores + (fav ? 3 : 0) * kCells;                              // Group(favour, favour) (Pattern.h:159-161)
     uint32_t* opp = s_scores + (fav ? 2 : 1) * kCells;                              // Group(favour, -favour)
     const int tslot = type == 5 ? 0 : type == 4 ? 1 : type == 3 ? 2 : -1;           // LiveThree, DeadThree, LiveTwo feed compounds
+    uint32_t* cnt = s_cnt + (tslot < 0 ? 0 : tslot) * kCells;
+    const uint32_t one = tslot < 0 ? 0u : 1u << (4 * (fav * 4 + dir));
     const int n_dep = (w0 >> 8) & 7;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -105,11 +99,7 @@ __device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell
         atomicAdd(&opp[c], score);                                                  // '_' and '^': the opponent's view
         if (f & 8u) {                                                               // '_': the owner's view too
             atomicAdd(&own[c], score);
-            if (tslot >= 0) {                                                       // saturating count 0 / 1 / >= 2
-                uint32_t* word = &s_cnt[c * 2 + (tslot >> 1)];
-                const uint32_t bit = 1u << (16 * (tslot & 1) + 2 * (fav * 4 + dir));
-                if (atomicOr(word, bit) & bit) atomicOr(word, bit << 1);
-            }
+            if (one) atomicAdd(&cnt[c], one);
         }
     }
 }
@@ -145,26 +135,29 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                            int trans_words, int record_words,
                            int phase_mask /* profiling aid: bit p runs phase p; 0x3F in production */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // layout: [boards: kBoardsPerBlock * kBoardWords][trans][records (16-byte aligned)][lane jobs]
-    uint32_t* s_trans = lds + kBoardsPerBlock * kBoardWords;
-    const uint4* s_rec = reinterpret_cast<const uint4*>(s_trans + trans_words);
-    uint32_t* s_jobs = s_trans + trans_words + record_words;
+    // layout: [trans (LDS address 0)][records (16-byte aligned)][lane jobs 128][initial line words 96][boards: kBoardsPerBlock * kBoardWords]
+    const uint4* s_rec = reinterpret_cast<const uint4*>(lds + trans_words);
+    uint32_t* s_jobs = lds + trans_words + record_words;
+    const uint32_t* s_line_init = s_jobs + 128;
 
-    for (int i = threadIdx.x; i < trans_words; i += kThreads) s_trans[i] = g_trans[i];
-    for (int i = threadIdx.x; i < record_words; i += kThreads) s_trans[trans_words + i] = g_records[i];
+    for (int i = threadIdx.x; i < trans_words; i += kThreads) lds[i] = g_trans[i];
+    for (int i = threadIdx.x; i < record_words; i += kThreads) lds[trans_words + i] = g_records[i];
     if (threadIdx.x < 128) s_jobs[threadIdx.x] = c_lane_jobs[threadIdx.x];
+    if (threadIdx.x < kLineWords) s_jobs[128 + threadIdx.x] = c_line_init[threadIdx.x];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* s_scores = lds + wave * kBoardWords;           // int32 scores, accumulated with ds_add
+    uint32_t* s_nib = lds + trans_words + record_words + kStaticTableWords + wave * kBoardWords;
+    uint32_t* s_scores = s_nib + kNibWords;                  // int32 scores, accumulated with ds_add
     uint32_t* s_cnt = s_scores + kScoreWords;
-    uint32_t* s_rows = s_cnt + kCntWords + kRowGuard;
-    uint32_t* s_queue = s_rows + kRowWords;
+    uint32_t* s_lines = s_nib + kZeroWords;
+    uint32_t* s_queue = s_lines + kLineWords;
     uint32_t* s_misc = s_queue + kQueueCap;
 
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
     const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
     const int scan_steps = c_scan_steps;
-    const char* trans_bytes = reinterpret_cast<const char*>(s_trans);
+    const char* lds_bytes = reinterpret_cast<const char*>(lds);           // the transition table starts at LDS address 0
+    const uint32_t lane_tag = static_cast<uint32_t>(lane) << 10;
 
     // the next board's 64 B are fetched while the current board is evaluated (one dependent HBM round trip per board otherwise)
     auto fetch_row = [&](int b) -> uint32_t {
@@ -177,59 +170,77 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         const int board = (it * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave;
         const bool live = board < n_boards;
 
-        // ---- phase 0: clear accumulators, take the two bit-planes (64 B), transpose them into line words ----
+        // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words and digit rows ----
         {
-            uint4* z = reinterpret_cast<uint4*>(s_scores);
-            for (int i = lane; i < (kScoreWords + kCntWords + kRowGuard + kRowWords + 3) / 4; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
+            uint4* z = reinterpret_cast<uint4*>(s_nib) + lane;
+#pragma unroll
+            for (int i = 0; i < kZeroWords / 4; i += 64)
+                if (i + 64 <= kZeroWords / 4 || lane < kZeroWords / 4 - i) z[i] = make_uint4(0u, 0u, 0u, 0u);
         }
+        s_lines[lane] = s_line_init[lane];
+        if (lane < kLineWords - 64) s_lines[64 + lane] = s_line_init[64 + lane];
         if (lane < kMiscWords) s_misc[lane] = 0;
         const uint32_t my_row = next_row;
         next_row = fetch_row(((it + 1) * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave);
         wave_phase_fence();
-        if (lane < 15) {                                            // lane y owns row y: one OR per stone into the 3 other line words
-            const int y = lane;
-            s_rows[y] = my_row;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {                      // the rows as 4-bit digits (phase 3's dot products)
+            const int i = lane + 64 * pass, y = i / 6, part = i - 6 * y;      // part = colour * 3 + word
+            const uint32_t roww = __shfl(my_row, min(y, 14));
+            const uint32_t half = part >= 3 ? roww >> 16 : roww & 0x7FFFu;
+            uint32_t v = ((half << 3) >> (8 * (part >= 3 ? part - 3 : part))) & 0xFFu;
+            v = (v | (v << 12)) & 0x000F000Fu;
+            v = (v | (v << 6)) & 0x03030303u;
+            v = (v | (v << 3)) & 0x11111111u;
+            if (i < 90) s_nib[18 + i] = v;
+        }
+        if (lane < 15) {                                            // lane y owns row y: a stone turns its cell's blank (3) into black (0) or white (1)
+            const int y = lane;                                     // in the four lines through it: one XOR each
+            atomicAdd(&s_misc[0], static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16));
+            uint32_t row_sym = 0;
             for (uint32_t m = (my_row | (my_row >> 16)) & 0x7FFFu; m; m &= m - 1u) {
                 const int x = __ffs(m) - 1;
-                const uint32_t cb = ((my_row >> x) & 1u) ? 0u : 16u;
-                atomicOr(&s_rows[kColBase + x], 1u << (y + cb));
-                atomicOr(&s_rows[kDiagBase + x - y + 14], 1u << (min(x, y) + cb));
-                atomicOr(&s_rows[kAntiBase + x + y], 1u << (min(14 - x, y) + cb));
+                const uint32_t code = ((my_row >> x) & 1u) ? 3u : 2u;
+                row_sym |= code << (2 * x);
+                atomicXor(&s_lines[kColBase + x], code << (2 * y));
+                atomicXor(&s_lines[kDiagBase + x - y + 14], code << (2 * min(x, y)));
+                atomicXor(&s_lines[kAntiBase + x + y], code << (2 * min(14 - x, y)));
             }
+            s_lines[y] = 0x3FFFFFFFu ^ row_sym;
         }
         wave_phase_fence();
 
         // ---- phase 1: walk the DFA along this lane's lines; transitions that emit go to the queue ----
-        // The lane's one or two lines become ONE stream of 2-bit DFA symbols in a 64-bit register:
+        // The lane's one or two lines become ONE stream of 2-bit DFA symbols:
         //   '?' cells '?' '?'  ['?' cells '?' '?']  '?' '?' ...
         // (after "??" the automaton sits in its '?' self-loop state, which the next line's leading '?' keeps: no reset
-        // between the two lines).  A step is: take 2 bits, one LDS lookup trans[row + sym] whose word holds the next
-        // row's byte offset and the emission record number.  Emitting transitions are queued raw (record, lane, step);
-        // the slot is a ballot prefix (this wave is the only producer), the decoding happens in phase 2.
+        // between the two lines).  The stream is kept shifted left by 2, so a step is: symbol * 4 = low word & 12, LDS
+        // address = (previous word's next-row offset) | symbol * 4, one lookup.  Emitting transitions are queued raw
+        // (record, lane, step); the slot is a ballot prefix (this wave is the only producer), decoding happens in phase 2.
         int n_queued = 0;                                       // wave-uniform
         if (phase_mask & 2) {
             const int len_a = job_a & 15, len_b = job_b & 15;
-            uint64_t syms = line_symbols(s_rows[(job_a >> 16) & 127u], len_a);
-            syms |= line_symbols(s_rows[(job_b >> 16) & 127u], len_b) << (2 * len_a + 6);
+            uint64_t syms = line_symbols(s_lines[(job_a >> 16) & 127u], len_a);
+            syms |= line_symbols(s_lines[(job_b >> 16) & 127u], len_b) << (2 * len_a + 6);
             syms |= 0xAAAAAAAAAAAAAAAAull << (2 * (len_a + len_b) + 12);
-            uint32_t row_off = 0;                               // byte offset of the current state's row in trans[]
-            uint32_t tag = static_cast<uint32_t>(lane) << 10;   // | step << 16
+            uint32_t cur = static_cast<uint32_t>(syms) << 2;    // symbols 0..14 at bits 2..31
+            const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2..
+            uint32_t tw = 0;                                    // the previous step's table word (row 0 = root)
             for (int step = 0; step < scan_steps; ++step) {
-                const uint32_t sym4 = (static_cast<uint32_t>(syms) & 3u) << 2;
-                syms >>= 2;
-                const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym4);
-                row_off = tw & 0x3FFFu;
-                const uint32_t rec = (tw >> 14) & 1023u;
+                if (step == 15) cur = rest;
+                const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
+                cur >>= 2;
+                tw = *reinterpret_cast<const uint32_t*>(lds_bytes + addr);
+                const uint32_t rec = gmk::dev_trans_record(tw);
                 const unsigned long long emitters = __ballot(rec != 0u);
                 if (emitters) {
                     if (rec) {
                         const int slot = n_queued + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
                                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u)));
-                        if (slot < kQueueCap) s_queue[slot] = tag | rec;
+                        if (slot < kQueueCap) s_queue[slot] = rec | lane_tag | (static_cast<uint32_t>(step) << 16);
                     }
                     n_queued += __popcll(emitters);
                 }
-                tag += 1u << 16;
             }
             if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
         }
@@ -261,50 +272,56 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             const int q = min(q0 + lane, kCells - 1);           // the last pass has 33 cells; spare lanes redo cell 224 harmlessly
             const bool spare = q0 + lane >= kCells;
             const int x = q % 15, y = q / 15;
-            // 7-bit windows (bit i <-> column x-3+i) of rows y-3 .. y+3 for BOTH colours at once: black in bits 0..6,
-            // white in bits 16..22.  One of the two shifts is by zero; col_mask removes what leaks across the halves.
-            const int sr = max(x - 3, 0), sl = max(3 - x, 0);
-            const uint32_t col_mask = (x >= 12 ? (0x7Fu >> (x - 11)) : 0x7Fu) | ((x < 3 ? (0x7Fu & ~((1u << (3 - x)) - 1u)) : 0x7Fu) << 16);
-            uint32_t win[7];
-#pragma unroll
-            for (int k = 0; k < 7; ++k) win[k] = ((s_rows[y - 3 + k] >> sr) << sl) & col_mask;
-            // rows are symmetric in |dy|: pair them in the two bytes of each half, count with one popcount per weight
-            const uint32_t p3 = win[0] | (win[6] << 8), p2 = win[1] | (win[5] << 8), p1 = win[2] | (win[4] << 8), p0 = win[3];
-            int cnt_c[2], wgt_c[2];                         // [0] white, [1] black (Evaluator::Group, Pattern.h:154-156)
+            // rows y-3 .. y+3 as 4-bit digits: the 7 digits around column x start at digit x of the padded row, i.e. at bit
+            // 4 * (x & 7) of word x >> 3; v_alignbit takes them out of two words.  Rows y-k and y+k have the same weights
+            // (Pattern.cpp:601-607), so their digits are added first (<= 2, no carry); v_dot8_u32_u4 multiplies the
+            // digits with the row's weights (the eighth digit gets weight 0) and accumulates.
+            uint32_t nib_at = y * 6 + (x >> 3);
+            asm volatile("" : "+v"(nib_at));                    // one base register, the 28 reads use immediate offsets
+            const uint32_t* nib = s_nib + nib_at;
+            const uint32_t sh = (x & 7) * 4;
+            uint32_t cnt_c[2], wgt_c[2];                        // [0] white, [1] black (Evaluator::Group, Pattern.h:154-156)
+            uint32_t centre = 0;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int h = c ? 0 : 16;                   // black half is bits 0..15, white half bits 16..31
-                const int w1 = __popc(p3 & (0x0808u << h)) + __popc(p0 & (0x41u << h));
-                const int w2 = __popc(p3 & (0x4141u << h));
-                const int w3 = __popc(p2 & (0x1C1Cu << h)) + __popc(p1 & (0x2222u << h)) + __popc(p0 & (0x22u << h));
-                const int w4 = __popc(p2 & (0x2222u << h)) + __popc(p1 & (0x0808u << h)) + __popc(p0 & (0x14u << h));
-                const int w5 = __popc(p1 & (0x1414u << h));
-                wgt_c[c] = w1 + 2 * w2 + 3 * w3 + 4 * w4 + 5 * w5;                       // Pattern.cpp:601-607
-                cnt_c[c] = __popc(p3 & (0x4949u << h)) + __popc(p2 & (0x3E3Eu << h)) + __popc(p1 & (0x3E3Eu << h)) + __popc(p0 & (0x77u << h));
+                uint32_t w[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) w[k] = __builtin_amdgcn_alignbit(nib[k * 6 + c * 3 + 1], nib[k * 6 + c * 3], sh);
+                const uint32_t p3 = w[0] + w[6], p2 = w[1] + w[5], p1 = w[2] + w[4], p0 = w[3];
+                uint32_t wg = __builtin_amdgcn_udot8(p3, 0x2001002u, 0u, false);
+                wg = __builtin_amdgcn_udot8(p2, 0x0433340u, wg, false);
+                wg = __builtin_amdgcn_udot8(p1, 0x0354530u, wg, false);
+                wg = __builtin_amdgcn_udot8(p0, 0x1340431u, wg, false);
+                uint32_t cn = __builtin_amdgcn_udot8(p3, 0x1001001u, 0u, false);
+                cn = __builtin_amdgcn_udot8(p2 + p1, 0x0111110u, cn, false);
+                cn = __builtin_amdgcn_udot8(p0, 0x1110111u, cn, false);
+                wgt_c[1 - c] = wg;
+                cnt_c[1 - c] = cn;
+                centre |= p0;
             }
-            const uint32_t here = s_rows[y] >> x;
-            const bool occupied = (here & 0x10001u) != 0;
+            const bool occupied = (centre & 0x1000u) != 0;
             if (!occupied && !spare) {
                 if (wgt_c[0] > 0) atomicAdd(&s_scores[0 * kCells + q], 160u);           // Pattern.cpp:268
                 if (wgt_c[1] > 0) atomicAdd(&s_scores[3 * kCells + q], 160u);
             }
             if (live && out_density && !spare) {
                 int32_t* d = out_density + static_cast<size_t>(board) * 4 * kCells + q;
-                d[0 * kCells] = occupied ? -cnt_c[0] - 1 : cnt_c[0];
-                d[1 * kCells] = occupied ? -wgt_c[0] - 1 : wgt_c[0];
-                d[2 * kCells] = occupied ? -cnt_c[1] - 1 : cnt_c[1];
-                d[3 * kCells] = occupied ? -wgt_c[1] - 1 : wgt_c[1];
+                const uint32_t neg = occupied ? ~0u : 0u;       // occupied cells hold -v - 1 (Pattern.cpp:253-265)
+                d[0 * kCells] = static_cast<int32_t>(cnt_c[0] ^ neg);
+                d[1 * kCells] = static_cast<int32_t>(wgt_c[0] ^ neg);
+                d[2 * kCells] = static_cast<int32_t>(cnt_c[1] ^ neg);
+                d[3 * kCells] = static_cast<int32_t>(wgt_c[1] ^ neg);
             }
             // compound candidates (Compound::Test, Pattern.cpp:424-433, and the density gate, Pattern.cpp:182): cells whose
-            // LiveThree / DeadThree / LiveTwo '_' flags cover two or more direction bits; decided in phase 3b by one lane each
+            // LiveThree / DeadThree / LiveTwo '_' counters, each clipped to 2 (the reference's 2-bit shift flags), OR-ed over the
+            // types, sum to two or more over the directions; decided in phase 3b
             uint32_t cand = 0;
             if (!occupied && !spare) {
-                const uint32_t cw0 = s_cnt[q * 2], cw1 = s_cnt[q * 2 + 1];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const uint32_t flags = ((cw0 >> (8 * c)) | (cw0 >> (16 + 8 * c)) | (cw1 >> (8 * c))) & 0xFFu;
-                    if (__popc(flags) >= 2 && cnt_c[c] >= 2) cand |= 1u << c;
-                }
+                const uint32_t any = s_cnt[q] | s_cnt[kCells + q] | s_cnt[2 * kCells + q];
+                const uint32_t upper = (any >> 1) | (any >> 2) | (any >> 3);
+                const uint32_t ge2 = upper & 0x11111111u, ge1 = (any | upper) & 0x11111111u;         // one bit per field with count >= 2 / >= 1
+                if (__popc(ge1 & 0xFFFFu) + __popc(ge2 & 0xFFFFu) >= 2 && cnt_c[0] >= 2) cand |= 1u;
+                if (__popc(ge1 >> 16) + __popc(ge2 >> 16) >= 2 && cnt_c[1] >= 2) cand |= 2u;
             }
             const unsigned long long pushers = __ballot(cand != 0u);
             if (pushers) {
@@ -325,16 +342,15 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         for (int m = lane; m < n_cand; m += 64) {
             const uint32_t ce = s_queue[m];
             const int q = ce & 255;
-            const uint32_t cw0 = s_cnt[q * 2], cw1 = s_cnt[q * 2 + 1];
+            const uint32_t cw_l3 = s_cnt[q], cw_d3 = s_cnt[kCells + q], cw_l2 = s_cnt[2 * kCells + q];
             for (int c = 0; c < 2; ++c) {
                 if (!((ce >> (8 + c)) & 1u)) continue;
-                // 2-bit fields per direction: 00 none, 01 one, 11 two or more (= the reference's flag encoding, Pattern.cpp:395-400)
-                const uint32_t f_l3 = (cw0 >> (8 * c)) & 0xFFu, f_d3 = (cw0 >> (16 + 8 * c)) & 0xFFu, f_l2 = (cw1 >> (8 * c)) & 0xFFu;
-                // state machine S0,L2,LD3,To33,To43,To44 = 0..5
+                // state machine S0,L2,LD3,To33,To43,To44 = 0..5; a counter counts like the reference's 2-bit shift flags: 0, 1, 2 or more (Pattern.cpp:395-400)
                 int state = 0, l3 = 0, triple = 0, n_comp = 0;
                 uint32_t comps = 0;                         // 4 bits per component: dir | tslot << 2
                 for (int d = 0; d < 4; ++d) {
-                    const int k3 = __popc((f_l3 >> (2 * d)) & 3u), kd = __popc((f_d3 >> (2 * d)) & 3u), k2 = __popc((f_l2 >> (2 * d)) & 3u);
+                    const int f = 4 * (c * 4 + d);
+                    const int k3 = min((cw_l3 >> f) & 15u, 2u), kd = min((cw_d3 >> f) & 15u, 2u), k2 = min((cw_l2 >> f) & 15u, 2u);
                     const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
                     if (t < 0) continue;
                     const int k = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
@@ -378,19 +394,18 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
                 const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
                 const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
-                // six '?' | cells | six '?', then the 13 symbols starting six before q
-                uint64_t syms = (0xAAAull | (cell_symbols(s_rows[line], len) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
+                // six '?' | cells | six '?', then the 13 symbols starting six before q, kept shifted left by 2 as in phase 1
+                const uint64_t syms = ((0xAAAull | (static_cast<uint64_t>(s_lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at)) << 2;
                 uint32_t* opp = s_scores + (c ? 2 : 1) * kCells;
-                uint32_t row_off = 0;
+                uint32_t cur = static_cast<uint32_t>(syms), tw = 0;
                 bool found = false;
                 for (int k = 0; k < 13; ++k) {
-                    const uint32_t sym4 = (static_cast<uint32_t>(syms) & 3u) << 2;
-                    syms >>= 2;
-                    const uint32_t tw = *reinterpret_cast<const uint32_t*>(trans_bytes + row_off + sym4);
-                    row_off = tw & 0x3FFFu;
-                    // a match covering q ends at window index >= 6; bits 24.. say whether the record holds the wanted type
-                    if (k >= 6 && !found && ((tw >> (24 + tslot)) & 1u)) {
-                        const uint4 rec = s_rec[(tw >> 14) & 1023u];
+                    const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
+                    cur >>= 2;
+                    tw = *reinterpret_cast<const uint32_t*>(lds_bytes + addr);
+                    // a match covering q ends at window index >= 6; the kinds bits say whether the record holds the wanted type
+                    if (k >= 6 && !found && ((gmk::dev_trans_kinds(tw) >> tslot) & 1u)) {
+                        const uint4 rec = s_rec[gmk::dev_trans_record(tw)];
                         found = try_counter_cells(rec.x, k, want, q, stride, opp);
                         if (!found && rec.z) found = try_counter_cells(rec.z, k, want, q, stride, opp);
                     }
@@ -408,9 +423,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             }
             if (out_totals && lane < 11) out_totals[static_cast<size_t>(board) * 11 + lane] = s_misc[4 + lane];
             if (out_status && lane == 0) {
-                const uint32_t wbits = s_misc[1];
-                int stones_b = 0, stones_w = 0;
-                for (int r = 0; r < 15; ++r) { stones_b += __popc(s_rows[r] & 0x7FFFu); stones_w += __popc(s_rows[r] >> 16); }
+                const uint32_t wbits = s_misc[1], stones = s_misc[0];
+                const int stones_b = stones & 0xFFFFu, stones_w = stones >> 16;
                 // the side that completed five is the only one that can own a Five (the game stops there)
                 const int winner = (wbits & 1u) ? 1 : (wbits & 2u) ? -1 : 0;
                 const bool over = winner != 0 || stones_b + stones_w == kCells;
@@ -432,7 +446,8 @@ int upload_lane_jobs() {
     for (int d = -10; d <= 10; ++d) lines.push_back({15 - std::abs(d), d > 0 ? d : 0, d > 0 ? 0 : -d, 2});
     for (int k = 4; k <= 24; ++k) { const int x0 = std::min(k, 14); lines.push_back({std::min(k, 28 - k) + 1, x0, k - x0, 3}); }
     std::stable_sort(lines.begin(), lines.end(), [](const LineJob& a, const LineJob& b) { return a.len > b.len; });
-    uint32_t jobs[128] = {};
+    uint32_t jobs[128];
+    for (uint32_t& j : jobs) j = 15u << 16;                       // "no line": length 0 on a line word that stays zero
     auto pack = [](const LineJob& l) {
         const int line = l.dir == 0 ? l.y0 : l.dir == 1 ? kColBase + l.x0 : l.dir == 2 ? kDiagBase + l.x0 - l.y0 + 14 : kAntiBase + l.x0 + l.y0;
         return static_cast<uint32_t>(l.len | (l.x0 << 4) | (l.y0 << 8) | (l.dir << 12) | 0x4000 | (line << 16));
@@ -446,6 +461,10 @@ int upload_lane_jobs() {
         steps = std::max(steps, total);
     }
     if (const char* env = std::getenv("GMK_EVAL_SCAN_STEPS")) steps = std::atoi(env);      // profiling aid only: wrong results
+    uint32_t init[kLineWords] = {};                              // every cell of every line blank (symbol 3)
+    for (int i = 0; i < 15; ++i) init[i] = init[kColBase + i] = 0x3FFFFFFFu;
+    for (int d = 0; d <= 28; ++d) init[kDiagBase + d] = init[kAntiBase + d] = (1u << (2 * (15 - std::abs(d - 14)))) - 1u;
+    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_line_init), init, sizeof init));
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lane_jobs), jobs, sizeof jobs));
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_scan_steps), &steps, sizeof steps));
     return GMK_OK;
@@ -459,7 +478,7 @@ Launch plan_launch(int n, const gmk::DeviceState& st) {
     Launch l;
     l.iterations = std::max(1, (tiles + max_grid - 1) / max_grid);
     l.grid = std::max(1, (tiles + l.iterations - 1) / l.iterations);
-    l.lds = static_cast<size_t>(kBoardsPerBlock * kBoardWords + st.n_states * 4 + st.n_records * 4 + 128) * 4;
+    l.lds = static_cast<size_t>(kBoardsPerBlock * kBoardWords + st.n_states * 4 + st.n_records * 4 + kStaticTableWords) * 4;
     return l;
 }
 
@@ -480,6 +499,7 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
         g_jobs_uploaded = true;
     }
     const Launch l = plan_launch(n, st);
+    if (l.lds > 160u * 1024u) { gmk::set_error("gmk_eval_batch: tables do not fit in LDS (%zu bytes)", l.lds); return GMK_ERR_CAPACITY; }
     static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x3F;
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
                        d_planes, n, l.iterations, d_scores, d_density, d_totals, d_status,

@@ -90,8 +90,8 @@ __device__ void match_patterns(const Ctx& c, int move, int slot) {
         for (int k = 0; k < 13; ++k) {
             const uint32_t tw = *reinterpret_cast<const uint32_t*>(c.trans + row_off + ((static_cast<uint32_t>(syms) & 3u) << 2));
             syms >>= 2;
-            row_off = tw & 0x3FFFu;
-            const uint32_t rid = (tw >> 14) & 1023u;
+            row_off = gmk::dev_trans_row(tw);
+            const uint32_t rid = gmk::dev_trans_record(tw);
             if (!rid) continue;
             const uint4 r = c.rec[rid];
             const uint32_t w0s[2] = {r.x, r.z}, w1s[2] = {r.y, r.w};
@@ -181,9 +181,9 @@ __device__ void update_one_compound(const Ctx& c, int cell, int pb /* player is 
             for (int k = 0; k < 13 && !found; ++k) {
                 const uint32_t tw = *reinterpret_cast<const uint32_t*>(c.trans + row_off + ((static_cast<uint32_t>(syms) & 3u) << 2));
                 syms >>= 2;
-                row_off = tw & 0x3FFFu;
-                if (k < 6 || !((tw >> (24 + ct)) & 1u)) continue;
-                const uint4 r = c.rec[(tw >> 14) & 1023u];
+                row_off = gmk::dev_trans_row(tw);
+                if (k < 6 || !((gmk::dev_trans_kinds(tw) >> ct) & 1u)) continue;
+                const uint4 r = c.rec[gmk::dev_trans_record(tw)];
                 const uint32_t w0s[2] = {r.x, r.z};
                 for (int e = 0; e < 2 && !found; ++e) {
                     const uint32_t w0 = w0s[e];

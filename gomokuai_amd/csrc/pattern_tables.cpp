@@ -343,7 +343,7 @@ void PatternAutomaton::flatten() {
             const int type = patterns_[dev_.emit_lists[list + 1 + e] & 0x7FFF].type;
             kinds |= type == LiveThree ? 1u : type == DeadThree ? 2u : type == LiveTwo ? 4u : 0u;
         }
-        dev_.dev_trans[i] = (next * 16u) | (rec << 14) | (kinds << 24);
+        dev_.dev_trans[i] = (next * 16u) | (kinds << 14) | (rec << 17);
     }
     dev_.n_records = static_cast<int>(dev_.dev_records.size() / 4);
 }

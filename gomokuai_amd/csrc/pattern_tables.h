@@ -7,6 +7,9 @@
 // DFA with per-transition emission lists: one LDS lookup per symbol on the GPU, no fail-chain walks.
 #pragma once
 #include <cstdint>
+#if defined(__HIP__)
+#include <hip/hip_runtime.h>
+#endif
 #include <string>
 #include <vector>
 
@@ -31,6 +34,16 @@ inline int symbol_code(char ch) {
 // this transition (back = 0) or on the previous one (back = 1, produced while falling back).
 struct Emission { uint16_t pattern; uint8_t back; };
 
+// decoders of a dev_trans word (host and device)
+#if defined(__HIP__)
+#define GMK_TABLE_FN __host__ __device__ __forceinline__
+#else
+#define GMK_TABLE_FN inline
+#endif
+GMK_TABLE_FN uint32_t dev_trans_row(uint32_t tw) { return tw & 0x3FFFu; }
+GMK_TABLE_FN uint32_t dev_trans_kinds(uint32_t tw) { return (tw >> 14) & 7u; }
+GMK_TABLE_FN uint32_t dev_trans_record(uint32_t tw) { return tw >> 17; }
+
 struct DeviceTables {
     // trans[state*4 + sym] : bits 0..9 next state, bits 10..19 index into emit_lists (0 = nothing)
     std::vector<uint32_t> trans;
@@ -42,8 +55,9 @@ struct DeviceTables {
     //   w1: bits 0..15 score on rows/columns | bits 16..31 score on diagonals (= int(1.2*score))
     std::vector<uint32_t> pattern_info;
     // ---- what the kernels stage into LDS ----
-    // dev_trans[state*4 + sym]: bits 0..13 byte offset of the next state's row (state * 16), bits 14..23 emission record number (0 = none),
-    //   bits 24..26 the record holds a LiveThree / DeadThree / LiveTwo match (filter for the compound rescans)
+    // dev_trans[state*4 + sym]: bits 0..13 byte offset of the next state's row (state * 16), bits 14..16 the record holds a
+    //   LiveThree / DeadThree / LiveTwo match (filter for the compound rescans), bits 17..26 emission record number (0 = none),
+    //   nothing above it (the record number is one shift away); decoders: dev_trans_row / _kinds / _record below
     std::vector<uint32_t> dev_trans;
     // dev_records[4*r .. 4*r+3], r >= 1: the (at most two) matches one transition reports, two words each, second pair 0 if absent:
     //   w0: bits 0..3 type | bit 4 favour-is-black | bits 5..7 len | bits 8..10 number of deposits |
