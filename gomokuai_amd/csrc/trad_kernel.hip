@@ -1,0 +1,561 @@
+// trad_kernel.hip -- K6: the pattern-guided tree search (the reference's self-play supervisor) on the device.
+//
+// TraditionalPolicy (core/lib/include/policies/Traditional.h:17-69) = MCTS::playout (core/lib/src/MCTS.cpp:158-177) with
+//   select    RAVE::Select: the first child (MonteCarlo.hpp:149-152)
+//   simulate  Heuristic::EvaluationProbs -> DecisiveFilter -> EvaluationValue on the policy's own incremental Evaluator
+//             (Heuristic.hpp:16-45, 94-161), no rollout
+//   expand    Default::Expand without the legality check: one child per cell with a non-zero prior (MonteCarlo.hpp:71-80)
+//   backup    RAVE::BackPropogate<false>: per level, the child with the best PUCB + Q moves to the front (:160-184)
+//   moves     Heuristic::CachedApplyMove / CachedRevertMove: the evaluator stays at the last leaf and is rolled back
+//             (or rebuilt) only as far as the next path differs (Heuristic.hpp:165-200)
+// The search has no random numbers; it is a serial chain per game, so the GPU runs MANY games: one wavefront per
+// game, seven games per workgroup, the evaluator state (17.8 KB, evalstate_device.h) and the current path in LDS,
+// the tree in HBM (24 B per node: statistics, parent / cell / prior, child range, and one slot of the child ORDER
+// array that BackPropogate permutes).  Float reductions use one fixed order (sum225, the same as oracle/go_trad.c);
+// PUCB and tanh are evaluated in double like the reference.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "evalstate_device.h"
+
+namespace {
+
+using namespace gmk::evs;
+
+constexpr int kGamesPerBlock = 7;
+constexpr int kThreads = 64 * kGamesPerBlock;
+constexpr int kPathCap = 228;                    // a path has at most 226 nodes
+constexpr int kRecordWords = 57;
+constexpr int kMiscWords = 8;
+// per-game LDS: evaluator state | evaluator scratch | path node ids | path child ranges | record copy | misc
+constexpr int kPerGame = (kStateWords + kScratchWords + 2 * kPathCap + kRecordWords + kMiscWords + 3) & ~3;
+constexpr uint32_t kNoParent = 0xFFFFFFu;
+
+struct TradHeader {                              // 64 B per game in HBM
+    uint32_t n_nodes, init_acts, status, fresh;  // status: bit 0 node capacity reached, bit 1 evaluator error, bit 2 board-only revert met
+    uint32_t playouts_done, root_black, pad0, pad1;
+    unsigned long long evaluator_updates, pad2;
+    uint32_t pad3[4];
+};
+static_assert(sizeof(TradHeader) == 64, "TradHeader layout");
+
+struct TradParams {
+    uint32_t* states;                            // [n_games][kStateWords]
+    uint2* stat;                                 // [n_games][cap] {visits, value bits}
+    uint2* info;                                 // [n_games][cap] {parent | cell << 24, prior bits}
+    uint32_t* link;                              // [n_games][cap] first child | children << 24
+    uint32_t* kids;                              // [n_games][cap] child order: slot k belongs to the parent whose range covers node k + 1
+    TradHeader* hdr;
+    const uint8_t* moves;                        // [n_games][225] position to search from (read when hdr.fresh)
+    const int32_t* lens;
+    const uint32_t* g_trans;
+    const uint32_t* g_records;
+    int trans_words, record_words;
+    int n_games, cap, playouts;
+    double c_puct;
+};
+
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __shfl(v, src); }
+
+// the one summation order (oracle/go_trad.c: sum225): lane l first adds its cells l, l+64, l+128, l+192 in that order
+// (done by the caller into `p`), then a binary tree over the lanes; every lane gets the result
+__device__ __forceinline__ float tree_sum(float p) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) p += __shfl_down(p, s);
+    return __shfl(p, 0);
+}
+
+struct Cells {                                   // a per-cell float vector: lane l holds cells l + 64 j
+    float v[4];
+};
+
+__device__ __forceinline__ float sum225(const Cells& x, int lane) {
+    float p = x.v[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (lane + 64 * j < kCells) p += x.v[j];
+    return tree_sum(p);
+}
+
+// MatrixBase::normalized() / normalize() (Eigen 3.3+: a zero vector stays as it is)
+__device__ __forceinline__ void normalize225(Cells& x, int lane) {
+    Cells sq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sq.v[j] = x.v[j] * x.v[j];
+    const float z = sum225(sq, lane);
+    if (z > 0.0f) {
+        const float n = sqrtf(z);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x.v[j] = x.v[j] / n;
+    }
+}
+
+// Heuristic::DensityWeight (Heuristic.hpp:39-45)
+__device__ __forceinline__ Cells density_weight(const uint32_t* st, int black, int lane) {
+    const int32_t* counts = reinterpret_cast<const int32_t*>(st + oDensity) + (black * 2 + 0) * kCells;
+    const int32_t* weights = reinterpret_cast<const int32_t*>(st + oDensity) + (black * 2 + 1) * kCells;
+    Cells out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = min(lane + 64 * j, kCells - 1);
+        const float N = static_cast<float>(max(counts[q], 0)), W = static_cast<float>(max(weights[q], 0));
+        out.v[j] = (3.0f * W) / (1.0f + 2.0f * N);
+    }
+    normalize225(out, lane);
+    return out;
+}
+
+// Heuristic::DecisiveFilter (Heuristic.hpp:94-161).  Candidates are (pattern, player is black): pattern < 9 a
+// Pattern::Type, otherwise 9 + Compound::Type.  All lanes walk the same automaton; the mask is per cell.
+__device__ __forceinline__ void decisive_filter(const uint32_t* st, int cur_black, Cells& probs, int lane) {
+    enum { S4, SL3, STo44, STo43, STo33, SEnd };
+    constexpr int kNext[2][6] = {{S4, STo44, SL3, STo43, STo33, SEnd}, {SL3, STo44, STo43, STo33, SEnd, SEnd}};
+    constexpr int kAnti[2][6] = {{1, 0, 1, 1, 1, 0}, {0, 1, 0, 0, 0, 1}};
+    int state = S4, anti = 0;
+    while (state != SEnd) {
+        const uint32_t black = anti ? cur_black ^ 1 : cur_black;
+        // the std::deque as 16-bit entries of one register: pattern | black << 8, entry k at bits 16 k
+        uint64_t cands;
+        int n, head = 0;
+        if (state == S4) { cands = (7u | black << 8) | (static_cast<uint64_t>(6u | black << 8) << 16); n = 2; }           // LiveFour, DeadFour
+        else if (state == SL3) { cands = 5u | black << 8; n = 1; }                                                       // LiveThree
+        else { cands = static_cast<uint32_t>(9 + (STo33 - state)) | black << 8; n = 1; }
+        for (; head < n; ++head) {
+            const uint32_t pattern = (cands >> (16 * head)) & 0xFFu, pb = (cands >> (16 * head + 8)) & 1u;
+            const uint32_t total = pattern < 9 ? st[oPdist + 225 * 8 + pattern] : st[oCdist + 225 * 3 + pattern - 9];
+            if ((total >> (16 * pb)) & 0xFFFFu) {
+                if (anti && state != S4) { cands |= static_cast<uint64_t>(4u | (pb ^ 1u) << 8) << (16 * n); ++n; }       // the own DeadThree counts when answering
+                break;
+            }
+        }
+        if (head < n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = min(lane + 64 * j, kCells - 1);
+                bool keep = false;
+                for (int k = head; k < n; ++k) {
+                    const uint32_t pattern = (cands >> (16 * k)) & 0xFFu, pb = (cands >> (16 * k + 8)) & 1u;
+                    const uint32_t field = pattern < 9 ? st[oPdist + q * 8 + pattern] : st[oCdist + q * 3 + pattern - 9];
+                    keep |= ((field >> (8 * group2(pb, cur_black))) & 0xFFu) != 0u;
+                }
+                if (!keep) probs.v[j] = 0.0f;
+            }
+            normalize225(probs, lane);
+            state = SEnd;
+        } else {
+            const int s = kNext[anti][state], a = kAnti[anti][state];
+            state = s;
+            anti = a;
+        }
+    }
+}
+
+struct Game {
+    Ctx c;
+    uint32_t* path_node;
+    uint32_t* path_link;
+    uint8_t* record_copy;
+    uint2* stat;
+    uint2* info;
+    uint32_t* link;
+    uint32_t* kids;
+    int cached, init;
+    unsigned long long updates;
+};
+
+// Heuristic::CachedApplyMove (Heuristic.hpp:165-189)
+__device__ __forceinline__ void cached_apply_move(Game& g, int move) {
+    const int32_t* meta = reinterpret_cast<const int32_t*>(g.c.st + oMeta);
+    const uint8_t* record = reinterpret_cast<const uint8_t*>(g.c.st + oRecord);
+    const int nrec = meta[0];
+    if (g.cached == nrec || record[g.cached] != move) {
+        if (nrec - g.cached > g.cached) {                       // too little is cached: rebuild from the empty board
+            if (g.c.lane < kRecordWords) reinterpret_cast<uint32_t*>(g.record_copy)[g.c.lane] = g.c.st[oRecord + g.c.lane];
+            wave_phase_fence();
+            reset_state(g.c);
+            for (int i = 0; i < g.cached; ++i) { apply_move(g.c, g.record_copy[i]); wave_phase_fence(); }
+            g.updates += g.cached;
+        } else {
+            for (int k = nrec - g.cached; k > 0; --k) { revert_move(g.c); wave_phase_fence(); }
+            g.updates += nrec - g.cached;
+        }
+        apply_move(g.c, move);
+        wave_phase_fence();
+        g.updates += 1;
+        if (g.cached < meta[0]) ++g.cached;
+    } else {
+        ++g.cached;
+    }
+}
+
+__global__ __launch_bounds__(kThreads)
+void trad_playouts_kernel(TradParams prm) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // layout: [trans][records][games: kGamesPerBlock * kPerGame]
+    for (int i = threadIdx.x; i < prm.trans_words + prm.record_words; i += kThreads)
+        lds[i] = i < prm.trans_words ? prm.g_trans[i] : prm.g_records[i - prm.trans_words];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int game = blockIdx.x * kGamesPerBlock + wave;
+    uint32_t* base = lds + prm.trans_words + prm.record_words + wave * kPerGame;
+    if (game < prm.n_games) {
+        const uint4* src = reinterpret_cast<const uint4*>(prm.states + static_cast<size_t>(game) * kStateWords);
+        uint4* dst = reinterpret_cast<uint4*>(base);
+        for (int i = lane; i < kStateWords / 4; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();                                            // tables staged; the games of a block never wait for each other again
+    if (game >= prm.n_games) return;
+
+    Game g;
+    g.c = Ctx{base, base + kStateWords, reinterpret_cast<const char*>(lds), reinterpret_cast<const uint4*>(lds + prm.trans_words), lane};
+    g.path_node = base + kStateWords + kScratchWords;
+    g.path_link = g.path_node + kPathCap;
+    g.record_copy = reinterpret_cast<uint8_t*>(g.path_link + kPathCap);
+    const size_t arena = static_cast<size_t>(game) * prm.cap;
+    g.stat = prm.stat + arena;
+    g.info = prm.info + arena;
+    g.link = prm.link + arena;
+    g.kids = prm.kids + arena;
+    g.updates = 0;
+    TradHeader* hdr = prm.hdr + game;
+    int32_t* meta = reinterpret_cast<int32_t*>(g.c.st + oMeta);
+    const uint8_t* record = reinterpret_cast<const uint8_t*>(g.c.st + oRecord);
+    uint32_t n_nodes = hdr->n_nodes, status = hdr->status;
+    int root_black = hdr->root_black;
+    const bool fresh = hdr->fresh != 0u;
+
+    if (fresh) {
+        // Policy::prepare + TraditionalPolicy::prepare: Evaluator::syncWithBoard (Pattern.cpp:356-368), then a fresh root
+        const uint8_t* mv = prm.moves + static_cast<size_t>(game) * 225;
+        const int n = prm.lens[game];
+        int i = 0;
+        for (; i < n; ++i) {
+            if (i < meta[0]) {
+                if (record[i] == mv[i]) continue;
+                for (int k = meta[0] - i; k > 0; --k) { revert_move(g.c); wave_phase_fence(); ++g.updates; }
+            }
+            apply_move(g.c, mv[i]);
+            wave_phase_fence();
+            ++g.updates;
+        }
+        for (int k = meta[0] - i; k > 0; --k) { revert_move(g.c); wave_phase_fence(); ++g.updates; }
+        g.init = n;
+        root_black = n & 1;                                     // the player of the last move
+        if (lane == 0) {
+            g.stat[0] = make_uint2(0u, 0u);
+            g.info[0] = make_uint2(kNoParent | ((n ? mv[n - 1] : 255u) << 24), __float_as_uint(1.0f));
+            g.link[0] = 0u;
+        }
+        n_nodes = 1;
+        status = 0;
+    } else {
+        g.init = static_cast<int>(hdr->init_acts);
+    }
+    g.cached = g.init;
+
+    for (int it = 0; it < prm.playouts && !(status & 1u); ++it) {
+        // ---- select: always the first child in the current order; the evaluator follows ----
+        int depth = 0;
+        uint32_t node = 0, link = g.link[0];
+        g.path_node[0] = 0;
+        g.path_link[0] = link;
+        while (link >> 24) {
+            node = g.kids[(link & 0xFFFFFFu) - 1u];
+            const uint32_t cell = g.info[node].x >> 24;
+            link = g.link[node];
+            ++depth;
+            if (lane == 0) { g.path_node[depth] = node; g.path_link[depth] = link; }
+            cached_apply_move(g, static_cast<int>(cell));
+        }
+        wave_phase_fence();
+
+        // ---- TraditionalPolicy::checkGameEnd -> Evaluator::checkGameEnd (Pattern.cpp:344-354) ----
+        bool ended = meta[1] == 0;
+        if (!ended && meta[0] == kCells) {
+            if (lane == 0) { meta[1] = 0; meta[2] = 0; }
+            wave_phase_fence();
+            ended = true;
+        }
+        float value;                                            // for the player of `node`
+        if (!ended) {
+            // ---- hybridSimulate (Traditional.h:48-69) ----
+            const int cur_black = meta[1] > 0;
+            Cells probs;
+            const Cells dw_self = density_weight(g.c.st, cur_black, lane), dw_rival = density_weight(g.c.st, cur_black ^ 1, lane);
+            const int32_t* scores = reinterpret_cast<const int32_t*>(g.c.st + oScores);
+            Cells prod_self, prod_rival;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = min(lane + 64 * j, kCells - 1);
+                const float self_worthy = static_cast<float>(scores[group2(cur_black, cur_black) * kCells + q]) * dw_self.v[j];
+                const float rival_anti = static_cast<float>(scores[group2(cur_black ^ 1, cur_black) * kCells + q]) * dw_rival.v[j];
+                probs.v[j] = 0.6f * self_worthy + 0.4f * rival_anti;                   // EvaluationProbs (Heuristic.hpp:16-28)
+                prod_self.v[j] = self_worthy;
+                prod_rival.v[j] = static_cast<float>(scores[group2(cur_black ^ 1, cur_black ^ 1) * kCells + q]) * dw_rival.v[j];
+            }
+            if (meta[0] != 0) {
+                normalize225(probs, lane);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) probs.v[j] = (lane + 64 * j == 7 * 15 + 7) ? 1.0f : 0.0f;
+            }
+            decisive_filter(g.c.st, cur_black, probs, lane);
+            const float self_sum = sum225(prod_self, lane), rival_sum = sum225(prod_rival, lane);
+            const float state_value = static_cast<float>(tanh((1.2 * self_sum - rival_sum) / 500.0f));     // EvaluationValue (:33-37)
+            value = -state_value;
+
+            // ---- Default::Expand, extraCheck = false: children in ascending cell order ----
+            int total = 0, rank[4];
+            bool nz[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nz[j] = lane + 64 * j < kCells && probs.v[j] != 0.0f;
+                const unsigned long long b = __ballot(nz[j]);
+                rank[j] = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
+                total += __popcll(b);
+            }
+            if (total > 0) {
+                if (n_nodes + total > static_cast<uint32_t>(prm.cap)) {
+                    status |= 1u;                               // arena full: the search of this game stops here
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nz[j]) {
+                            const uint32_t child = n_nodes + rank[j];
+                            g.stat[child] = make_uint2(0u, 0u);
+                            g.info[child] = make_uint2(node | (static_cast<uint32_t>(lane + 64 * j) << 24), __float_as_uint(probs.v[j]));
+                            g.link[child] = 0u;
+                            g.kids[child - 1u] = child;
+                        }
+                    link = n_nodes | (static_cast<uint32_t>(total) << 24);
+                    if (lane == 0) { g.link[node] = link; g.path_link[depth] = link; }
+                    n_nodes += total;
+                }
+            }
+        } else {
+            const int node_player = ((depth & 1) ? !root_black : root_black) ? 1 : -1;
+            value = static_cast<float>(node_player * meta[2]);                          // CalcScore (Game.h:34-36)
+        }
+        wave_phase_fence();
+        if (status & 1u) break;
+
+        // ---- RAVE::BackPropogate<false> (MonteCarlo.hpp:160-184) ----
+        for (int d = depth; d >= 0; --d, value = -value) {
+            const uint32_t nd = g.path_node[d], lk = g.path_link[d];
+            const uint32_t first = lk & 0xFFFFFFu, n = lk >> 24;
+            const uint2 st = g.stat[nd];
+            const double sqrt_n = sqrt(static_cast<double>(st.x));
+            double best_score = -INFINITY;
+            uint32_t best_i = 0xFFFFFFFFu;
+            for (uint32_t i = lane; i < n; i += 64) {
+                const uint32_t kid = g.kids[first - 1u + i];
+                const uint2 cs = g.stat[kid];
+                const double p_i = __uint_as_float(g.info[kid].y), n_i = static_cast<double>(cs.x + 1u);
+                double score = prm.c_puct * p_i * sqrt_n / n_i;                        // Default::PUCB (:23-28)
+                score += __uint_as_float(cs.y);
+                if (score > best_score) { best_score = score; best_i = i; }
+            }
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) {                                         // first maximum in the current order
+                const double os = __shfl_down(best_score, s);
+                const uint32_t oi = __shfl_down(best_i, s);
+                if (os > best_score || (os == best_score && oi < best_i)) { best_score = os; best_i = oi; }
+            }
+            best_i = __shfl(best_i, 0);
+            if (lane == 0) {
+                if (n && best_i != 0xFFFFFFFFu && best_i != 0u) {                      // the best child moves to the front
+                    const uint32_t a = g.kids[first - 1u], b = g.kids[first - 1u + best_i];
+                    g.kids[first - 1u] = b;
+                    g.kids[first - 1u + best_i] = a;
+                }
+                const uint32_t visits = st.x + 1u;
+                const float q = __uint_as_float(st.y);
+                g.stat[nd] = make_uint2(visits, __float_as_uint(q + (value - q) / static_cast<float>(visits)));
+            }
+        }
+
+        // ---- Heuristic::CachedRevertMove (Heuristic.hpp:192-200) ----
+        if (meta[0] != g.cached) status |= 4u;                  // the reference would take stones off the inner board only: not reproduced
+        g.cached = g.init;
+    }
+
+    wave_phase_fence();
+    if (meta[3]) status |= 2u;
+    if (lane == 0) {
+        hdr->n_nodes = n_nodes;
+        hdr->init_acts = static_cast<uint32_t>(g.init);
+        hdr->status = status;
+        hdr->fresh = 0;
+        hdr->root_black = static_cast<uint32_t>(root_black);
+        hdr->playouts_done = (fresh ? 0u : hdr->playouts_done) + static_cast<uint32_t>(prm.playouts);
+        hdr->evaluator_updates += g.updates;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(prm.states + static_cast<size_t>(game) * kStateWords);
+    const uint4* src = reinterpret_cast<const uint4*>(g.c.st);
+    for (int i = lane; i < kStateWords / 4; i += 64) dst[i] = src[i];
+}
+
+// root statistics by cell and the child MCTS::stepForward would pick (most visited, first in the CURRENT order)
+__global__ __launch_bounds__(64)
+void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t* link, const uint32_t* kids, int cap,
+                            uint32_t* visits, float* values, float* priors, int32_t* best, uint32_t* root_visits, float* root_value) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    const size_t arena = static_cast<size_t>(game) * cap;
+    const uint32_t lk = link[arena], first = lk & 0xFFFFFFu, n = lk >> 24;
+    uint32_t best_visits = 0, best_i = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t kid = kids[arena + first - 1u + i];
+        const uint2 cs = stat[arena + kid], ci = info[arena + kid];
+        const uint32_t cell = ci.x >> 24;
+        if (visits) visits[static_cast<size_t>(game) * 225 + cell] = cs.x;
+        if (values) values[static_cast<size_t>(game) * 225 + cell] = __uint_as_float(cs.y);
+        if (priors) priors[static_cast<size_t>(game) * 225 + cell] = __uint_as_float(ci.y);
+        if (best_i == 0xFFFFFFFFu || cs.x > best_visits) { best_visits = cs.x; best_i = i; }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        const uint32_t ov = __shfl_down(best_visits, s), oi = __shfl_down(best_i, s);
+        if (oi != 0xFFFFFFFFu && (best_i == 0xFFFFFFFFu || ov > best_visits || (ov == best_visits && oi < best_i))) { best_visits = ov; best_i = oi; }
+    }
+    if (lane == 0) {
+        if (best) best[game] = best_i == 0xFFFFFFFFu ? -1 : static_cast<int32_t>(info[arena + kids[arena + first - 1u + best_i]].x >> 24);
+        if (root_visits) root_visits[game] = stat[arena].x;
+        if (root_value) root_value[game] = __uint_as_float(stat[arena].y);
+    }
+}
+
+}  // namespace
+
+struct gmk_trad {
+    int n_games = 0, cap = 0;
+    uint32_t* d_states = nullptr;
+    uint2 *d_stat = nullptr, *d_info = nullptr;
+    uint32_t *d_link = nullptr, *d_kids = nullptr;
+    TradHeader* d_hdr = nullptr;
+    uint8_t* d_moves = nullptr;
+    int32_t* d_lens = nullptr;
+    bool attr_set = false, positioned = false;
+};
+
+extern "C" int gmk_trad_destroy(gmk_trad* t) {
+    if (!t) return GMK_OK;
+    (void)hipFree(t->d_states); (void)hipFree(t->d_stat); (void)hipFree(t->d_info); (void)hipFree(t->d_link);
+    (void)hipFree(t->d_kids); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
+    delete t;
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_reset_evaluators(gmk_trad* t) {
+    if (!t) return GMK_ERR_ARG;
+    std::vector<uint32_t> all(static_cast<size_t>(t->n_games) * kStateWords, 0u);
+    for (int g = 0; g < t->n_games; ++g) all[static_cast<size_t>(g) * kStateWords + oMeta + 1] = 1u;       // black to move
+    GMK_HIP_CHECK(hipMemcpy(t->d_states, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_create(int n_games, int node_capacity, gmk_trad** out) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!out || n_games <= 0 || node_capacity < 256 || node_capacity >= (1 << 24)) { gmk::set_error("gmk_trad_create: bad arguments (256 <= node_capacity < 2^24)"); return GMK_ERR_ARG; }
+    gmk_trad* t = new gmk_trad;
+    t->n_games = n_games;
+    t->cap = node_capacity;
+    const size_t nodes = static_cast<size_t>(n_games) * node_capacity;
+    bool ok = hipMalloc(&t->d_states, static_cast<size_t>(n_games) * kStateWords * 4) == hipSuccess &&
+              hipMalloc(&t->d_stat, nodes * 8) == hipSuccess && hipMalloc(&t->d_info, nodes * 8) == hipSuccess &&
+              hipMalloc(&t->d_link, nodes * 4) == hipSuccess && hipMalloc(&t->d_kids, nodes * 4) == hipSuccess &&
+              hipMalloc(&t->d_hdr, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess &&
+              hipMalloc(&t->d_moves, static_cast<size_t>(n_games) * 225) == hipSuccess &&
+              hipMalloc(&t->d_lens, static_cast<size_t>(n_games) * 4) == hipSuccess;
+    if (ok) ok = hipMemset(t->d_hdr, 0, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess;
+    if (!ok || gmk_trad_reset_evaluators(t) != GMK_OK) { gmk_trad_destroy(t); gmk::set_error("gmk_trad_create: device allocation failed"); return GMK_ERR_HIP; }
+    *out = t;
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves, const int32_t* h_lens) {
+    if (!t || !h_moves || !h_lens) { gmk::set_error("gmk_trad_set_positions: bad arguments"); return GMK_ERR_ARG; }
+    for (int g = 0; g < t->n_games; ++g)
+        if (h_lens[g] < 0 || h_lens[g] > 225) { gmk::set_error("gmk_trad_set_positions: game %d has %d moves", g, h_lens[g]); return GMK_ERR_ARG; }
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    GMK_HIP_CHECK(hipMemcpy(t->d_moves, h_moves, static_cast<size_t>(t->n_games) * 225, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(t->d_lens, h_lens, static_cast<size_t>(t->n_games) * 4, hipMemcpyHostToDevice));
+    std::vector<TradHeader> hdr(t->n_games);
+    GMK_HIP_CHECK(hipMemcpy(hdr.data(), t->d_hdr, hdr.size() * sizeof(TradHeader), hipMemcpyDeviceToHost));
+    for (TradHeader& h : hdr) { h.fresh = 1; h.playouts_done = 0; }
+    GMK_HIP_CHECK(hipMemcpy(t->d_hdr, hdr.data(), hdr.size() * sizeof(TradHeader), hipMemcpyHostToDevice));
+    t->positioned = true;
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stream) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!t || playouts < 0) { gmk::set_error("gmk_trad_run: bad arguments"); return GMK_ERR_ARG; }
+    if (!t->positioned) { gmk::set_error("gmk_trad_run: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
+    const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4) * 4;
+    if (lds > 160u * 1024u) { gmk::set_error("gmk_trad_run: tables do not fit in LDS (%zu bytes)", lds); return GMK_ERR_CAPACITY; }
+    if (!t->attr_set) {
+        GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        t->attr_set = true;
+    }
+    TradParams prm;
+    prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.kids = t->d_kids; prm.hdr = t->d_hdr;
+    prm.moves = t->d_moves; prm.lens = t->d_lens;
+    prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
+    prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
+    const int grid = (t->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
+    hipLaunchKernelGGL(trad_playouts_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), prm);
+    GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float* h_priors, int32_t* h_best,
+                                   uint32_t* h_root_visits, float* h_root_value, int32_t* h_n_nodes, int32_t* h_status,
+                                   uint64_t* h_evaluator_updates) {
+    if (!t) { gmk::set_error("gmk_trad_root_stats: bad arguments"); return GMK_ERR_ARG; }
+    const size_t n = static_cast<size_t>(t->n_games);
+    uint32_t *d_visits = nullptr, *d_root_visits = nullptr;
+    float *d_values = nullptr, *d_priors = nullptr, *d_root_value = nullptr;
+    int32_t* d_best = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_values); (void)hipFree(d_priors); (void)hipFree(d_best); (void)hipFree(d_root_visits); (void)hipFree(d_root_value); };
+#define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
+    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4)); GMK_TRY(hipMalloc(&d_priors, n * 225 * 4));
+    GMK_TRY(hipMalloc(&d_best, n * 4)); GMK_TRY(hipMalloc(&d_root_visits, n * 4)); GMK_TRY(hipMalloc(&d_root_value, n * 4));
+    GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_priors, 0, n * 225 * 4));
+    hipLaunchKernelGGL(trad_root_stats_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->d_stat, t->d_info, t->d_link, t->d_kids, t->cap,
+                       d_visits, d_values, d_priors, d_best, d_root_visits, d_root_value);
+    GMK_TRY(hipGetLastError());
+    GMK_TRY(hipDeviceSynchronize());
+    if (h_visits) GMK_TRY(hipMemcpy(h_visits, d_visits, n * 225 * 4, hipMemcpyDeviceToHost));
+    if (h_values) GMK_TRY(hipMemcpy(h_values, d_values, n * 225 * 4, hipMemcpyDeviceToHost));
+    if (h_priors) GMK_TRY(hipMemcpy(h_priors, d_priors, n * 225 * 4, hipMemcpyDeviceToHost));
+    if (h_best) GMK_TRY(hipMemcpy(h_best, d_best, n * 4, hipMemcpyDeviceToHost));
+    if (h_root_visits) GMK_TRY(hipMemcpy(h_root_visits, d_root_visits, n * 4, hipMemcpyDeviceToHost));
+    if (h_root_value) GMK_TRY(hipMemcpy(h_root_value, d_root_value, n * 4, hipMemcpyDeviceToHost));
+    std::vector<TradHeader> hdr(n);
+    GMK_TRY(hipMemcpy(hdr.data(), t->d_hdr, n * sizeof(TradHeader), hipMemcpyDeviceToHost));
+#undef GMK_TRY
+    for (size_t g = 0; g < n; ++g) {
+        if (h_n_nodes) h_n_nodes[g] = static_cast<int32_t>(hdr[g].n_nodes);
+        if (h_status) h_status[g] = static_cast<int32_t>(hdr[g].status);
+        if (h_evaluator_updates) h_evaluator_updates[g] = hdr[g].evaluator_updates;
+    }
+    cleanup();
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density, uint32_t* h_pattern_dist, uint32_t* h_compound_dist,
+                                        int32_t* h_meta, uint8_t* h_record) {
+    if (!t) return GMK_ERR_ARG;
+    std::vector<uint32_t> all(static_cast<size_t>(t->n_games) * kStateWords);
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    GMK_HIP_CHECK(hipMemcpy(all.data(), t->d_states, all.size() * 4, hipMemcpyDeviceToHost));
+    for (int g = 0; g < t->n_games; ++g) {
+        const uint32_t* s = all.data() + static_cast<size_t>(g) * kStateWords;
+        if (h_scores) std::memcpy(h_scores + static_cast<size_t>(g) * 900, s + oScores, 3600);
+        if (h_density) std::memcpy(h_density + static_cast<size_t>(g) * 900, s + oDensity, 3600);
+        if (h_pattern_dist) std::memcpy(h_pattern_dist + static_cast<size_t>(g) * 226 * 8, s + oPdist, 226 * 8 * 4);
+        if (h_compound_dist) std::memcpy(h_compound_dist + static_cast<size_t>(g) * 226 * 3, s + oCdist, 226 * 3 * 4);
+        if (h_meta) std::memcpy(h_meta + static_cast<size_t>(g) * 4, s + oMeta, 16);
+        if (h_record) std::memcpy(h_record + static_cast<size_t>(g) * 228, s + oRecord, 228);
+    }
+    return GMK_OK;
+}

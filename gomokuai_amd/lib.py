@@ -31,6 +31,7 @@ EXPORTS = [
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
+    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_root_stats", "gmk_trad_read_evaluators",
 ]
 
 
@@ -87,6 +88,13 @@ def load():
     L.gmk_evalstate_update.argtypes = [vp, vp, C.c_int, vp]
     L.gmk_evalstate_update_host.argtypes = [vp, vp, C.c_int]
     L.gmk_evalstate_read.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.gmk_trad_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.gmk_trad_destroy.argtypes = [vp]
+    L.gmk_trad_reset_evaluators.argtypes = [vp]
+    L.gmk_trad_set_positions.argtypes = [vp, vp, vp]
+    L.gmk_trad_run.argtypes = [vp, C.c_int, C.c_double, vp]
+    L.gmk_trad_root_stats.argtypes = [vp] * 10
+    L.gmk_trad_read_evaluators.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.gmk_samples_from_records.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
@@ -303,4 +311,56 @@ class EvaluatorStates:
                "meta": np.zeros((self.n, 4), np.int32), "record": np.zeros((self.n, 228), np.uint8)}
         _check(load().gmk_evalstate_read(self.h, out["scores"].ctypes.data, out["density"].ctypes.data, out["pattern_dist"].ctypes.data,
                                          out["compound_dist"].ctypes.data, out["meta"].ctypes.data, out["record"].ctypes.data))
+        return out
+
+
+# ---------------- K6: pattern-guided search (TraditionalPolicy), one tree + one evaluator per game ----------------
+class TraditionalMCTS:
+    """n_games searches of MCTS(policy=TraditionalPolicy(c_puct)) run side by side on the GPU (gmk_trad_*).
+    set_positions(move lists) = a fresh root at that position (the games' evaluators persist and are synchronised, like
+    the reference's policy object); run(playouts) iterates MCTS::playout; root_stats() reads the roots."""
+
+    def __init__(self, n_games, node_capacity=1 << 20, c_puct=5.0):
+        init()
+        self.n, self.c_puct = n_games, float(c_puct)
+        h = C.c_void_p()
+        _check(load().gmk_trad_create(n_games, int(node_capacity), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().gmk_trad_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset_evaluators(self):
+        _check(load().gmk_trad_reset_evaluators(self.h))
+
+    def set_positions(self, move_lists):
+        moves = np.zeros((self.n, N), np.uint8)
+        lens = np.zeros(self.n, np.int32)
+        assert len(move_lists) == self.n
+        for g, ml in enumerate(move_lists):
+            lens[g] = len(ml)
+            moves[g, :len(ml)] = ml
+        _check(load().gmk_trad_set_positions(self.h, moves.ctypes.data, lens.ctypes.data))
+
+    def run(self, playouts, stream=0):
+        _check(load().gmk_trad_run(self.h, int(playouts), self.c_puct, stream))
+
+    def root_stats(self):
+        out = {"visits": np.zeros((self.n, N), np.uint32), "values": np.zeros((self.n, N), np.float32), "priors": np.zeros((self.n, N), np.float32),
+               "best": np.zeros(self.n, np.int32), "root_visits": np.zeros(self.n, np.uint32), "root_value": np.zeros(self.n, np.float32),
+               "n_nodes": np.zeros(self.n, np.int32), "status": np.zeros(self.n, np.int32), "evaluator_updates": np.zeros(self.n, np.uint64)}
+        _check(load().gmk_trad_root_stats(self.h, *[out[k].ctypes.data for k in
+               ("visits", "values", "priors", "best", "root_visits", "root_value", "n_nodes", "status", "evaluator_updates")]))
+        return out
+
+    def read_evaluators(self):
+        out = {"scores": np.zeros((self.n, 4, N), np.int32), "density": np.zeros((self.n, 2, 2, N), np.int32),
+               "pattern_dist": np.zeros((self.n, 226, 8), np.uint32), "compound_dist": np.zeros((self.n, 226, 3), np.uint32),
+               "meta": np.zeros((self.n, 4), np.int32), "record": np.zeros((self.n, 228), np.uint8)}
+        _check(load().gmk_trad_read_evaluators(self.h, out["scores"].ctypes.data, out["density"].ctypes.data, out["pattern_dist"].ctypes.data,
+                                               out["compound_dist"].ctypes.data, out["meta"].ctypes.data, out["record"].ctypes.data))
         return out

@@ -177,6 +177,30 @@ int gmk_samples_from_records(const uint8_t *d_moves, const int32_t *d_lens, cons
                              const int32_t *d_sample_game, const int32_t *d_sample_move, int n_samples, int augment,
                              uint8_t *d_states, float *d_values, float *d_pi, void *stream);
 
+/* ---- K6: pattern-guided tree search, the reference's self-play supervisor ("traditional_mcts", config.py:9-12) ----
+ * Replaces MCTS(policy = TraditionalPolicy(c_puct)) : core/lib/include/policies/Traditional.h:17-69 on top of
+ * Heuristic (core/lib/include/algorithms/Heuristic.hpp:16-45, 94-200), RAVE::Select / BackPropogate<false>
+ * (core/lib/include/algorithms/MonteCarlo.hpp:149-184), Default::Expand (:71-80), MCTS::playout (core/lib/src/MCTS.cpp:158-177).
+ * One search per game and launch, every game with its own tree and its own persistent Evaluator (the policy object's
+ * m_evaluator): gmk_trad_set_positions = MCTS(c_iterations, last_move, last_player) + Policy::prepare, gmk_trad_run =
+ * that many MCTS::playout iterations (further calls continue the same tree), gmk_trad_root_stats = what
+ * MCTS::stepForward / evalState read from the root. */
+typedef struct gmk_trad gmk_trad;
+int gmk_trad_create(int n_games, int node_capacity /* nodes per game, 256 .. 2^24-1 */, gmk_trad** out);
+int gmk_trad_destroy(gmk_trad* t);
+int gmk_trad_reset_evaluators(gmk_trad* t);                       /* Evaluator::reset for every game */
+int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves /* [n][225] */, const int32_t* h_lens /* [n] */);
+int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stream);
+/* host outputs, any may be NULL: per-cell root child visits / values / priors [n][225], the move stepForward() would
+ * play (-1 without children), root visits and value, nodes in the tree, status (bit 0 node capacity reached, bit 1
+ * evaluator error, bit 2 unsupported board-only revert), evaluator updates (applied + reverted moves) so far */
+int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float* h_priors, int32_t* h_best,
+                        uint32_t* h_root_visits, float* h_root_value, int32_t* h_n_nodes, int32_t* h_status,
+                        uint64_t* h_evaluator_updates);
+/* the games' evaluator states, laid out as gmk_evalstate_read */
+int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density, uint32_t* h_pattern_dist,
+                             uint32_t* h_compound_dist, int32_t* h_meta, uint8_t* h_record);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,22 @@ uint32_t go_mt_next(go_mt19937 *g);
 /* Stats::TempBasedProbs on normalized visits (MCTS.cpp:104-117, Statistical.hpp:37-42) */
 void go_visits_to_pi(const uint32_t *visits, int n_moves_on_board, float *pi);
 
+/* ---------------- Pattern-guided search (Traditional.h:17-69, Heuristic.hpp, MonteCarlo.hpp:149-184; go_trad.c) ---------------- */
+typedef struct go_trad go_trad;
+go_trad *go_trad_new(double c_puct);
+void go_trad_free(go_trad *t);
+/* fresh root at the position after `moves`, `playouts` iterations; the policy's evaluator persists across calls */
+void go_trad_search(go_trad *t, const uint8_t *moves, int n_moves, uint64_t playouts);
+/* per-cell root child statistics; returns the move MCTS::stepForward() would play (-1 without children) */
+int  go_trad_root_children(const go_trad *t, uint32_t *visits, float *values, float *priors);
+uint64_t go_trad_root_visits(const go_trad *t);
+float    go_trad_root_value(const go_trad *t);
+int      go_trad_n_nodes(const go_trad *t);
+uint64_t go_trad_evaluator_updates(const go_trad *t);
+const go_evaluator *go_trad_evaluator(const go_trad *t);
+/* EvaluationProbs + DecisiveFilter + EvaluationValue on a fresh in-order replay; returns the value */
+float go_trad_heuristic(const uint8_t *moves, int n_moves, float *probs /*[225]*/);
+
 #ifdef __cplusplus
 }
 #endif

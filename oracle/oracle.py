@@ -84,6 +84,23 @@ def lib():
     L.go_scratch_eval_batch.restype = None
     L.go_philox4x32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.go_philox4x32.restype = None
+    L.go_trad_new.argtypes = [C.c_double]
+    L.go_trad_new.restype = C.c_void_p
+    L.go_trad_free.argtypes = [C.c_void_p]
+    L.go_trad_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+    L.go_trad_search.restype = None
+    L.go_trad_root_children.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.go_trad_root_visits.argtypes = [C.c_void_p]
+    L.go_trad_root_visits.restype = C.c_uint64
+    L.go_trad_root_value.argtypes = [C.c_void_p]
+    L.go_trad_root_value.restype = C.c_float
+    L.go_trad_n_nodes.argtypes = [C.c_void_p]
+    L.go_trad_evaluator_updates.argtypes = [C.c_void_p]
+    L.go_trad_evaluator_updates.restype = C.c_uint64
+    L.go_trad_evaluator.argtypes = [C.c_void_p]
+    L.go_trad_evaluator.restype = C.c_void_p
+    L.go_trad_heuristic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.go_trad_heuristic.restype = C.c_float
     L.go_mcts_new.argtypes = [C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_uint32]
     L.go_mcts_new.restype = C.c_void_p
     L.go_mcts_free.argtypes = [C.c_void_p]
@@ -310,3 +327,50 @@ def visits_to_pi(visits, n_moves):
     pi = np.zeros(N, dtype=np.float32)
     lib().go_visits_to_pi(v.ctypes.data, int(n_moves), pi.ctypes.data)
     return pi
+
+
+class TraditionalMCTS:
+    """TraditionalPolicy search (go_trad.c): fresh root per search, the policy's evaluator persists across searches."""
+    def __init__(self, c_puct=5.0):
+        self.L = lib()
+        self.h = self.L.go_trad_new(c_puct)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.go_trad_free(self.h)
+            self.h = None
+
+    def search(self, moves, playouts):
+        m = np.ascontiguousarray(moves, dtype=np.uint8)
+        self.L.go_trad_search(self.h, m.ctypes.data, len(m), int(playouts))
+
+    def root_children(self):
+        v = np.zeros(N, dtype=np.uint32)
+        q = np.zeros(N, dtype=np.float32)
+        p = np.zeros(N, dtype=np.float32)
+        best = self.L.go_trad_root_children(self.h, v.ctypes.data, q.ctypes.data, p.ctypes.data)
+        return v, q, p, best
+
+    @property
+    def root_visits(self):
+        return self.L.go_trad_root_visits(self.h)
+
+    @property
+    def root_value(self):
+        return self.L.go_trad_root_value(self.h)
+
+    @property
+    def n_nodes(self):
+        return self.L.go_trad_n_nodes(self.h)
+
+    @property
+    def evaluator_updates(self):
+        return self.L.go_trad_evaluator_updates(self.h)
+
+
+def trad_heuristic(moves):
+    """(probs after DecisiveFilter, value) of TraditionalPolicy::hybridSimulate at the position after `moves`."""
+    m = np.ascontiguousarray(moves, dtype=np.uint8)
+    probs = np.zeros(N, dtype=np.float32)
+    value = lib().go_trad_heuristic(m.ctypes.data, len(m), probs.ctypes.data)
+    return probs, value
