@@ -99,6 +99,65 @@ def bench_mcts(args, G, torch, dev, rank, world, distributed):
                          "note": "tree bytes only (select 8 B/child, expand 16 B/node, backup 16 B/level); rollouts run in LDS/registers, the kernel is latency/issue bound"}}
 
 
+def trad_positions(G, n, first):
+    """K6 workload: every game starts from a 12-ply clustered opening of the synthetic generator (threats and compounds present)."""
+    moves, lens, _ = G.synth_boards(n, 1, first_board=first)
+    return [[int(m) for m in moves[g, :min(int(lens[g]), 12)]] for g in range(n)]
+
+
+def bench_trad(args, G, torch, dev, rank, world, distributed):
+    """the self-play supervisor, MCTS(TraditionalPolicy) (config.py:9-12), n games side by side (K6).
+    One step = one search of every game (one launch)."""
+    import numpy as np
+    n, P = args.trad_games, args.trad_playouts
+    pos = trad_positions(G, n, rank * n)
+    tree = G.TraditionalMCTS(n, node_capacity=args.trad_nodes, c_puct=5.0)
+    stream = torch.cuda.current_stream().cuda_stream
+    tree.set_positions(pos)
+    tree.run(20, stream)                                   # warm-up
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(2):
+        updates_before = tree.root_stats()["evaluator_updates"].astype(np.float64)
+        tree.reset_evaluators()
+        tree.set_positions(pos)
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tree.run(P, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    ms = min(times)
+    st = tree.root_stats()
+    if distributed:
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = float(t[0])
+    tree.close()
+    return {"metric": "supervisor-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms,
+            "config": {"workload": "pattern-guided MCTS (K6, TraditionalPolicy c_puct=5), %d games x %d playouts per GPU, 12-ply clustered openings, fresh roots" % (n, P),
+                       "nodes_per_game_mean": float(st["n_nodes"].mean()), "evaluator_updates_per_playout": float((st["evaluator_updates"].astype(np.float64) - updates_before).mean()) / P,
+                       "games_stopped_at_node_capacity": int((st["status"] & 1).sum())},
+            "note": "a serial chain per game (one wavefront each): bound by LDS / HBM latency, not by bandwidth; no roofline fraction is claimed"}
+
+
+def cpu_baseline_trad(G, playouts):
+    """The oracle's restatement of the same search (oracle/go_trad.c), single thread, ~5 s."""
+    from oracle import oracle as O
+    pos = trad_positions(G, 512, 0)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < 5 and k < len(pos):
+        O.TraditionalMCTS(5.0).search(pos[k], playouts)
+        k += 1
+    dt = time.perf_counter() - t0
+    return {"value": k * playouts / dt, "unit": "playouts/s", "cores": 1, "kind": "port",
+            "sample": "%d searches of %d playouts from the same openings, oracle TraditionalPolicy restatement, %.1f s" % (k, playouts, dt)}
+
+
 def cpu_baseline_mcts(playouts):
     """BASELINE configs[0]-style CPU point: the oracle's MCTS restatement, single thread, a few whole searches."""
     import ctypes as C
@@ -135,6 +194,9 @@ def main():
     ap.add_argument("--mcts-games", type=int, default=4096, help="games per GPU for the secondary MCTS measurement (BASELINE configs[2]); 0 = skip")
     ap.add_argument("--mcts-playouts", type=int, default=800)
     ap.add_argument("--mcts-reps", type=int, default=3)
+    ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
+    ap.add_argument("--trad-playouts", type=int, default=1000)
+    ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
     args = ap.parse_args()
 
     import numpy as np
@@ -196,6 +258,10 @@ def main():
     if args.mcts_games > 0:
         mcts = bench_mcts(args, G, torch, dev, rank, world, distributed)
 
+    trad = None
+    if args.trad_games > 0:
+        trad = bench_trad(args, G, torch, dev, rank, world, distributed)
+
     if rank == 0:
         achieved = ALG_BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -222,10 +288,14 @@ def main():
         }
         if mcts is not None:
             out["secondary"] = mcts
+        if trad is not None:
+            out["supervisor"] = trad
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.kind)
             if mcts is not None:
                 out["secondary"]["cpu_baseline"] = cpu_baseline_mcts(args.mcts_playouts)
+            if trad is not None:
+                out["supervisor"]["cpu_baseline"] = cpu_baseline_trad(G, args.trad_playouts)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -4,7 +4,7 @@ MI355X CorePyExt.  Written for this repo; the reference's own files run unchange
 (see tests/test_pyext.py and INTEGRATION.md)."""
 import numpy as np
 
-from .core import Board, GameConfig as Game, MCTS, Player, RandomPolicy
+from .core import Board, GameConfig as Game, MCTS, Player, RandomPolicy, TraditionalPolicy
 
 
 class Agent:
@@ -51,6 +51,11 @@ class MCTSAgent(Agent):
 
 def RandomMCTSAgent(c_puct, c_rollouts=5, **constraint):
     return MCTSAgent(policy=RandomPolicy(c_puct, c_rollouts), **constraint)
+
+
+def TraditionalAgent(c_puct, c_bias=0.0, use_rave=False, **constraint):
+    """agents/mcts.py:44-48 of the reference: the pattern-guided searcher ("traditional_mcts" in config.py:9-12)."""
+    return MCTSAgent(policy=TraditionalPolicy(c_puct, c_bias, use_rave), **constraint)
 
 
 def dual_play(agents, board=None, verbose=False):

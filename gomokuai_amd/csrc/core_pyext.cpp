@@ -196,7 +196,7 @@ public:
         : policy_(policy ? policy : std::make_shared<RandomPolicy>(5.0, 5)), duration_(duration), by_iterations_(false) { init(last_move, last_player); }
     MCTS(size_t iterations, Position last_move, Player last_player, std::shared_ptr<Policy> policy)
         : policy_(policy ? policy : std::make_shared<RandomPolicy>(5.0, 5)), iterations_(iterations), duration_(0), by_iterations_(true) { init(last_move, last_player); }
-    ~MCTS() { if (handle_) gmk_mcts_destroy(handle_); }
+    ~MCTS() { if (handle_) gmk_mcts_destroy(handle_); if (trad_handle_) gmk_trad_destroy(trad_handle_); }
 
     Position get_action(Board& board) {
         run_playouts(board);
@@ -214,12 +214,18 @@ public:
     Position step_forward_best() {
         std::shared_ptr<Node> best;
         for (auto& c : root_->children) if (!best || best->node_visits < c->node_visits) best = c;
+        // TraditionalPolicy reorders children while it searches (RAVE::BackPropogate, MonteCarlo.hpp:179-181): the device
+        // reports which of several equally visited children comes first in that order
+        if (best_in_order_ >= 0)
+            for (auto& c : root_->children) if (c->position.id == best_in_order_) best = c;
+        best_in_order_ = -1;
         if (best) { best->parent.reset(); root_ = best; }
         return root_->position;
     }
     // MCTS::stepForward(move) (MCTS.cpp:136-147)
     void step_forward(Position move) {
         std::shared_ptr<Node> next;
+        best_in_order_ = -1;
         for (auto& c : root_->children) if (c->position == move) { next = c; break; }
         if (!next) { next = std::make_shared<Node>(); next->position = move; next->player = -root_->player; next->action_prob = 1.0f; }
         next->parent.reset();
@@ -252,8 +258,10 @@ private:
     void run_playouts(Board& board) {
         const auto start = std::chrono::system_clock::now();
         auto* random = dynamic_cast<RandomPolicy*>(policy_.get());
+        auto* trad = dynamic_cast<TraditionalPolicy*>(policy_.get());
+        if (trad && !trad->use_rave && !policy_->has_python_stages()) { run_traditional(board, *trad, start); return; }
         if (!random || policy_->has_python_stages())
-            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy only in this build; ") +
+            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy and TraditionalPolicy(use_rave=False) in this build; ") +
                                      policy_->kind() + " with host-side stages is not available (no CPU search path)");
         throw_gmk(gmk_init(0));
         sync_with_board(board);
@@ -305,7 +313,64 @@ private:
         policy_->cleanup(board);
     }
 
+    // MCTS(policy = TraditionalPolicy) on the device (K6, gmk_trad_*): one game; the handle owns the policy's evaluator,
+    // which persists across searches like TraditionalPolicy::m_evaluator (Traditional.h:27-31)
+    void run_traditional(Board& board, TraditionalPolicy& trad, std::chrono::system_clock::time_point start) {
+        throw_gmk(gmk_init(0));
+        sync_with_board(board);
+        policy_->prepare(board);
+        const int chunk = by_iterations_ ? static_cast<int>(iterations_) : 256;
+        const long long want = by_iterations_ ? static_cast<long long>(chunk) * 226 + 1 : (1ll << 22);
+        const int capacity = static_cast<int>(std::min<long long>(std::max<long long>(want, 256), (1ll << 24) - 1));
+        if (!trad_handle_ || trad_capacity_ != capacity) {
+            if (trad_handle_) gmk_trad_destroy(trad_handle_);
+            trad_handle_ = nullptr;
+            throw_gmk(gmk_trad_create(1, capacity, &trad_handle_));
+            trad_capacity_ = capacity;
+        }
+        uint8_t moves[kN] = {};
+        const int32_t len = static_cast<int32_t>(board.record_.size());
+        for (int i = 0; i < len; ++i) moves[i] = static_cast<uint8_t>(board.record_[i].id);
+        throw_gmk(gmk_trad_set_positions(trad_handle_, moves, &len));
+        std::vector<float> values(kN), priors(kN);
+        uint32_t root_visits = 0;
+        float q = 0.0f;
+        int32_t best = -1, nodes = 1, status = 0;
+        visits_.assign(kN, 0);
+        auto read = [&]() { throw_gmk(gmk_trad_root_stats(trad_handle_, visits_.data(), values.data(), priors.data(), &best, &root_visits, &q, &nodes, &status, nullptr)); };
+        if (by_iterations_) {
+            throw_gmk(gmk_trad_run(trad_handle_, chunk, trad.c_puct, nullptr));
+            read();
+            duration_ = std::chrono::duration_cast<milliseconds>(std::chrono::system_clock::now() - start);
+        } else {
+            iterations_ = 0;
+            for (auto end = start; end - start < duration_; end = std::chrono::system_clock::now()) {
+                throw_gmk(gmk_trad_run(trad_handle_, chunk, trad.c_puct, nullptr));
+                read();
+                iterations_ += static_cast<size_t>(chunk);
+                if (status & 1) break;                              // node arena full
+            }
+        }
+        if (status & 6) throw std::runtime_error("CorePyExt (MI355X): the device evaluator reported an inconsistent state");
+        root_->state_value = q;
+        root_->node_visits = root_visits;
+        root_->children.clear();
+        for (int i = 0; i < kN; ++i)
+            if (priors[i] != 0.0f) {                                // Default::Expand: one child per cell with a non-zero prior
+                auto c = std::make_shared<Node>();
+                c->parent = root_; c->position = Position(i); c->player = -root_->player;
+                c->action_prob = priors[i]; c->state_value = values[i]; c->node_visits = visits_[i];
+                root_->children.push_back(c);
+            }
+        best_in_order_ = best;
+        size_ = static_cast<size_t>(nodes);
+        trad.cached_acts = policy_->init_acts;
+        policy_->cleanup(board);
+    }
+
     gmk_mcts* handle_ = nullptr;
+    gmk_trad* trad_handle_ = nullptr;
+    int trad_capacity_ = 0, best_in_order_ = -1;
     int capacity_ = 0;
     size_t c_rollouts_ = 0;
     double c_puct_ = 0;

@@ -50,7 +50,16 @@ struct Ctx {
     const char* trans;           // device transition words (pattern_tables.h)
     const uint4* rec;            // emission records
     int lane;
+    unsigned long long* prof = nullptr;      // profiling aid (GMK_EVS_PROFILE): cycles per phase of update_move, summed by lane 0
 };
+
+__device__ __forceinline__ void prof_mark(const Ctx& c, int slot, unsigned long long& t_last) {
+    if (c.prof) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        if (c.lane == 0) c.prof[slot] += now - t_last;
+        t_last = __builtin_amdgcn_s_memtime();
+    }
+}
 
 // Evaluator::Record::set(delta, favour, perspective, dir) (Pattern.cpp:395-400) as an atomic update of one LDS word
 __device__ __forceinline__ void set_flag(uint32_t* word, int delta, int group, int dir) {
@@ -266,12 +275,16 @@ __device__ inline void board_set(const Ctx& c, int move, bool place, int black) 
 __device__ inline void update_move(const Ctx& c, int move, int src) {
     int32_t* meta = reinterpret_cast<int32_t*>(c.st + oMeta);
     uint8_t* record = reinterpret_cast<uint8_t*>(c.st + oRecord);
+    unsigned long long t_last = c.prof ? __builtin_amdgcn_s_memtime() : 0ull;
     match_patterns(c, move, 0);
     wave_phase_fence();
+    prof_mark(c, 0, t_last);
     update_compounds(c, move, -1);
     wave_phase_fence();
+    prof_mark(c, 1, t_last);
     update_patterns(c, move, 0, -1);
     wave_phase_fence();
+    prof_mark(c, 2, t_last);
     int block_colour;
     if (src != 0) {
         board_set(c, move, true, src > 0);
@@ -290,12 +303,17 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     wave_phase_fence();
     update_block(c, move, src != 0 ? 1 : -1, block_colour);
     wave_phase_fence();
+    prof_mark(c, 3, t_last);
     match_patterns(c, move, 1);
     wave_phase_fence();
+    prof_mark(c, 4, t_last);
     update_patterns(c, move, 1, 1);
     wave_phase_fence();
+    prof_mark(c, 5, t_last);
     update_compounds(c, move, 1);
     wave_phase_fence();
+    prof_mark(c, 6, t_last);
+    if (c.prof && c.lane == 0) c.prof[7] += 1;
 }
 
 // Evaluator::reset (Pattern.cpp:370-386, Game.cpp:138-146): empty board, black to move

@@ -3,6 +3,7 @@
 // Evaluator::applyMove / revertMove scripts (core/lib/src/Pattern.cpp:274-342) over device-resident states; the update
 // itself lives in evalstate_device.h.  Mapping: one wavefront per game, six games per workgroup.  The 17.8 KB state
 // is copied into LDS, all moves of the launch are applied there, and it is written back once.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -16,10 +17,11 @@ constexpr int kThreads = 64 * kGamesPerBlock;
 
 __global__ __launch_bounds__(kThreads)
 void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __restrict__ moves, int moves_per_game, int n_games,
-                             const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records, int trans_words, int record_words) {
+                             const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records, int trans_words, int record_words,
+                             unsigned long long* prof /* profiling aid, normally null: 8 counters per game */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [games: kGamesPerBlock * (kStateWords + kScratchWords rounded)] [trans] [records]
-    constexpr int kPerGame = (kStateWords + kScratchWords + 3) & ~3;
+    constexpr int kPerGame = (kStateWords + kScratchWords + 16 + 3) & ~3;     // + 8 profiling counters
     uint32_t* s_trans = lds + kGamesPerBlock * kPerGame;
     for (int i = threadIdx.x; i < trans_words + record_words; i += kThreads) s_trans[i] = i < trans_words ? g_trans[i] : g_records[i - trans_words];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -32,7 +34,9 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
     }
     __syncthreads();
     if (game >= n_games) return;
-    Ctx c{st, st + kStateWords, reinterpret_cast<const char*>(s_trans), reinterpret_cast<const uint4*>(s_trans + trans_words), lane};
+    Ctx c{st, st + kStateWords, reinterpret_cast<const char*>(s_trans), reinterpret_cast<const uint4*>(s_trans + trans_words), lane,
+          prof ? reinterpret_cast<unsigned long long*>(st + kStateWords + kScratchWords) : nullptr};
+    if (prof && lane < 16) st[kStateWords + kScratchWords + lane] = 0u;
     for (int m = 0; m < moves_per_game; ++m) {
         const int mv = moves[static_cast<size_t>(game) * moves_per_game + m];
         if (mv >= 0) apply_move(c, mv);
@@ -42,6 +46,7 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
     uint4* dst = reinterpret_cast<uint4*>(states + static_cast<size_t>(game) * kStateWords);
     const uint4* src = reinterpret_cast<const uint4*>(st);
     for (int i = lane; i < kStateWords / 4; i += 64) dst[i] = src[i];
+    if (prof && lane < 8) prof[static_cast<size_t>(game) * 8 + lane] = c.prof[lane];
 }
 
 }  // namespace
@@ -86,16 +91,34 @@ extern "C" int gmk_evalstate_update(gmk_evalstate* e, const int16_t* d_moves, in
     gmk::DeviceState& st = gmk::device_state();
     if (!e || !d_moves || moves_per_game < 0) { gmk::set_error("gmk_evalstate_update: bad arguments"); return GMK_ERR_ARG; }
     if (moves_per_game == 0) return GMK_OK;
-    constexpr int kPerGame = (kStateWords + kScratchWords + 3) & ~3;
+    constexpr int kPerGame = (kStateWords + kScratchWords + 16 + 3) & ~3;
     const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4) * 4;
     if (!e->attr_set) {
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(evalstate_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e->attr_set = true;
     }
     const int grid = (e->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
+    unsigned long long* d_prof = nullptr;
+    static const bool profile = std::getenv("GMK_EVS_PROFILE") != nullptr;
+    if (profile) {
+        GMK_HIP_CHECK(hipMalloc(&d_prof, static_cast<size_t>(e->n_games) * 8 * sizeof(unsigned long long)));
+        GMK_HIP_CHECK(hipMemset(d_prof, 0, static_cast<size_t>(e->n_games) * 8 * sizeof(unsigned long long)));
+    }
     hipLaunchKernelGGL(evalstate_update_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), e->d_states, d_moves,
-                       moves_per_game, e->n_games, st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4);
+                       moves_per_game, e->n_games, st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, d_prof);
     GMK_HIP_CHECK(hipGetLastError());
+    if (profile) {                                              // cycles per phase of Updater::updateMove, mean over games
+        std::vector<unsigned long long> h(static_cast<size_t>(e->n_games) * 8);
+        GMK_HIP_CHECK(hipDeviceSynchronize());
+        GMK_HIP_CHECK(hipMemcpy(h.data(), d_prof, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d_prof);
+        double sum[8] = {};
+        for (size_t i = 0; i < h.size(); ++i) sum[i % 8] += static_cast<double>(h[i]);
+        const char* names[7] = {"match-", "compounds-", "patterns-", "board+block", "match+", "patterns+", "compounds+"};
+        std::fprintf(stderr, "[GMK_EVS_PROFILE] s_memtime ticks (100 MHz) per update:");
+        for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %s %.1f", names[k], sum[k] / (sum[7] > 0 ? sum[7] : 1));
+        std::fprintf(stderr, "\n");
+    }
     return GMK_OK;
 }
 

@@ -220,7 +220,7 @@ class BatchedMCTS:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and load is not None:
             load().gmk_mcts_destroy(self.h)
             self.h = None
 
@@ -290,7 +290,7 @@ class EvaluatorStates:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and load is not None:
             load().gmk_evalstate_destroy(self.h)
             self.h = None
 
@@ -328,7 +328,7 @@ class TraditionalMCTS:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and load is not None:       # (module globals are gone at interpreter shutdown)
             load().gmk_trad_destroy(self.h)
             self.h = None
 

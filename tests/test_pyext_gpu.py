@@ -55,3 +55,35 @@ def test_duration_constraint():
     m = core.MCTS(c_duration=datetime.timedelta(milliseconds=100))
     mv = m.get_action(core.Board())
     assert 0 <= mv.id < 225 and m.iterations >= 256 and m.size > 1
+
+
+def test_traditional_policy_matches_oracle(oracle):
+    """MCTS(policy=TraditionalPolicy) searches on the device (K6) and agrees with the oracle restatement, search after
+    search (the policy's evaluator persists), including which of several equally visited children is played."""
+    O = oracle
+    m = core.MCTS(c_iterations=400, policy=core.TraditionalPolicy(5.0))
+    om = O.TraditionalMCTS(5.0)
+    b = core.Board()
+    played = []
+    for mv in (112, 98, 127, 113):
+        b.apply_move(core.Position(mv)); played.append(mv)
+    for _ in range(3):
+        q, pi = m.eval_state(b)
+        om.search(played, 400)
+        v, oq, p, best = om.root_children()
+        assert np.float32(q).tobytes() == np.float32(om.root_value).tobytes()
+        kids = {c.position.id: c for c in m.root.children}
+        assert sorted(kids) == [int(i) for i in np.nonzero(p)[0]]
+        assert all(kids[i].node_visits == int(v[i]) and np.float32(kids[i].action_prob).tobytes() == p[i].tobytes() for i in kids)
+        assert abs(float(pi.sum()) - 1.0) < 1e-3
+        m.step_forward()
+        assert m.root.position.id == best
+        b.apply_move(m.root.position); played.append(best)
+
+
+def test_traditional_agent_plays_a_game():
+    agent = agents.TraditionalAgent(5.0, c_iterations=150)
+    data = agents.dual_play({core.Player.black: agent, core.Player.white: agent}, verbose=True)
+    assert len(data) >= 9 and data[0][0][2].sum() == 225
+    with pytest.raises(RuntimeError):
+        agents.TraditionalAgent(5.0, use_rave=True, c_iterations=10).get_action(core.Board())

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""K2 timing aid: time per evaluator update (apply) per game-wavefront."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gomokuai_amd import lib as G
+torch.cuda.set_device(0); G.init(0)
+n, k = 1536, 40
+moves, lens, _ = G.synth_boards(n, 1)
+scr = np.full((n, k), -1, np.int16)
+for g in range(n):
+    m = min(int(lens[g]), k); scr[g, :m] = moves[g, :m]
+d = torch.from_numpy(scr).cuda()
+e = G.EvaluatorStates(n)
+L = G.load()
+L.gmk_evalstate_update(e.h, d.data_ptr(), k, 0); torch.cuda.synchronize()
+e.reset()
+t0 = time.perf_counter(); L.gmk_evalstate_update(e.h, d.data_ptr(), k, 0); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+ups = (scr >= 0).sum(1).mean()
+print("K2: %d games x %.1f applies in %.3f ms -> %.2f us per update per game (6 waves/CU), %.1f M updates/s" % (n, ups, dt * 1e3, dt * 1e6 / ups, n * ups / dt / 1e6))
