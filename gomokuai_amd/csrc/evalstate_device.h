@@ -19,24 +19,19 @@ namespace gmk::evs {
 
 constexpr int kCells = 225;
 // state layout, 32-bit words (the host mirrors it in gmk_evalstate_read)
-constexpr int kLineWords = 96, kColBase = 20, kDiagBase = 36, kAntiBase = 65;     // line words as in eval_kernel.hip
+constexpr int kLineWords = 96, kColBase = 20, kDiagBase = 36, kAntiBase = 65;     // line words as in eval_kernel.hip: 2 bits per cell = its DFA
+                                                                                 // symbol (0 black, 1 white, 3 blank), cell p of the line at bits 2p
 constexpr int oLines = 0, oScores = oLines + kLineWords, oDensity = oScores + 4 * kCells, oPdist = oDensity + 4 * kCells,
               oCdist = oPdist + 226 * 8, oRecord = oCdist + 226 * 3, oMeta = oRecord + 57;
 constexpr int kStateWords = (oMeta + 4 + 3) & ~3;                                // 4448 words = 17 792 B
 // meta: [0] moves played, [1] player to move (+1 black, -1 white, 0 game over), [2] winner, [3] error bits
 constexpr int kResultCap = 16;                                                   // matches covering the centre, per direction
-constexpr int kScratchWords = 2 * 4 * kResultCap * 2 + 8;                        // two result sets + counters
+constexpr int kCompoundCap = 64;                                                 // compound components handled in one pass
+constexpr int oResultCount = 2 * 4 * kResultCap * 2, oItemCount = oResultCount + 8, oItems = oItemCount + 4;
+constexpr int kScratchWords = oItems + kCompoundCap;                             // two result sets + their counters + the component queue
 
 __device__ __forceinline__ int dir_stride(int dir) { return dir == 0 ? 1 : dir == 1 ? 15 : dir == 2 ? 16 : 14; }
 __device__ __forceinline__ int group2(int favour_black, int perspective_black) { return (favour_black << 1) | perspective_black; }   // Pattern.h:159-161
-
-__device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
-    v = (v | (v << 8)) & 0x00FF00FFu;
-    v = (v | (v << 4)) & 0x0F0F0F0Fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
-    return v;
-}
 
 __device__ __forceinline__ void wave_phase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -61,15 +56,31 @@ __device__ __forceinline__ void prof_mark(const Ctx& c, int slot, unsigned long 
     }
 }
 
-// Evaluator::Record::set(delta, favour, perspective, dir) (Pattern.cpp:395-400) as an atomic update of one LDS word
+// Evaluator::Record::set(delta, favour, perspective, dir) (Pattern.cpp:395-400) for one or more 2-bit fields of one LDS
+// word (`lowers` = the low bit of every field to update).  The field is a saturating shift register: +1 takes
+// 00 -> 01 -> 11 -> 11, -1 takes 11 -> 01 -> 00 -> 00.  Two atomics without a compare-and-swap loop do that, and
+// lanes that update the same field in the same pass still compose like the reference's sequential updates:
+//   +1: set the low bits; where the low bit was already set, set the high bit
+//   -1: clear the high bits; where the high bit was already clear, clear the low bit
+__device__ __forceinline__ uint32_t set_flags_begin(uint32_t* word, int delta, uint32_t lowers) {
+    return delta == 1 ? atomicOr(word, lowers) : atomicAnd(word, ~(lowers << 1));
+}
+__device__ __forceinline__ void set_flags_end(uint32_t* word, int delta, uint32_t lowers, uint32_t old) {
+    if (delta == 1) { const uint32_t up = (old & lowers) << 1; if (up) atomicOr(word, up); }
+    else { const uint32_t down = lowers & ~(old >> 1); if (down) atomicAnd(word, ~down); }
+}
 __device__ __forceinline__ void set_flag(uint32_t* word, int delta, int group, int dir) {
-    const uint32_t offset = static_cast<uint32_t>(4 * group + dir) * 2u, lower = 1u << offset, higher = lower << 1, mask = lower | higher;
-    uint32_t old = *word, assumed;
-    do {
-        assumed = old;
-        const uint32_t value = delta == 1 ? ((assumed << 1) | lower) : ((assumed >> 1) & ~higher);
-        old = atomicCAS(word, assumed, (assumed & ~mask) | (value & mask));
-    } while (old != assumed);
+    const uint32_t lower = 1u << (static_cast<uint32_t>(4 * group + dir) * 2u);
+    set_flags_end(word, delta, lower, set_flags_begin(word, delta, lower));
+}
+
+// a line word with every cell blank
+__host__ __device__ __forceinline__ uint32_t blank_line_word(int index) {
+    if (index < 15 || (index >= kColBase && index < kColBase + 15)) return 0x3FFFFFFFu;
+    const int d = index >= kAntiBase ? index - kAntiBase : index - kDiagBase;
+    if (index < kDiagBase || d > 28) return 0u;
+    const int len = 15 - (d > 14 ? d - 14 : 14 - d);
+    return (1u << (2 * len)) - 1u;
 }
 
 // the 13 symbols centred on `cell` along `dir` (BoardMap::lineView, Mapping.cpp:31-34) as a 2-bit stream
@@ -78,26 +89,26 @@ __device__ __forceinline__ uint64_t window_symbols(const uint32_t* lines, int ce
     const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
     const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
     const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
-    const uint32_t lw = lines[line], in_line = (1u << len) - 1u;
-    const uint32_t black = lw & 0x7FFFu, white = lw >> 16;
-    const uint64_t cells = static_cast<uint64_t>(spread_bits(~black & in_line) | (spread_bits(~(black | white) & in_line) << 1));
-    return (0xAAAull | (cells << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);       // six '?' | cells | six '?'
+    return (0xAAAull | (static_cast<uint64_t>(lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);       // six '?' | cells | six '?'
 }
 
-// Updater::matchPatterns (Pattern.cpp:128-136) for the four directions: lanes 0..3
-__device__ inline void match_patterns(const Ctx& c, int move, int slot) {
-    if (c.lane < 4) {
-        const int dir = c.lane;
+// Updater::matchPatterns (Pattern.cpp:128-136).  The reference matches twice per update, before and after the stone
+// changes; the two 13-symbol windows differ in the centre symbol only and do not depend on anything else the update
+// touches, so both are walked at once: lane = window * 4 + direction, window 0 = the board as it is (result set 0),
+// window 1 = `new_sym` in the centre (result set 1).
+__device__ inline void match_patterns_both(const Ctx& c, int move, uint32_t new_sym) {
+    if (c.lane < 8) {
+        const int dir = c.lane & 3, w = c.lane >> 2;
         uint64_t syms = window_symbols(c.st + oLines, move, dir);
-        uint32_t* out = c.scratch + (slot * 4 + dir) * kResultCap * 2;
-        uint32_t row_off = 0;
+        if (w) syms = (syms & ~(3ull << 12)) | (static_cast<uint64_t>(new_sym) << 12);
+        uint32_t* out = c.scratch + (w * 4 + dir) * kResultCap * 2;
+        uint32_t cur = static_cast<uint32_t>(syms) << 2, tw = 0;                       // symbol * 4 in bits 2..3, as in eval_kernel.hip
         int n = 0;
         for (int k = 0; k < 13; ++k) {
-            const uint32_t tw = *reinterpret_cast<const uint32_t*>(c.trans + row_off + ((static_cast<uint32_t>(syms) & 3u) << 2));
-            syms >>= 2;
-            row_off = gmk::dev_trans_row(tw);
+            tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
+            cur >>= 2;
             const uint32_t rid = gmk::dev_trans_record(tw);
-            if (!rid) continue;
+            if (k < 6 || !rid) continue;                         // a match that covers the centre ends at window index >= 6
             const uint4 r = c.rec[rid];
             const uint32_t w0s[2] = {r.x, r.z}, w1s[2] = {r.y, r.w};
             for (int e = 0; e < 2; ++e) {
@@ -109,14 +120,14 @@ __device__ inline void match_patterns(const Ctx& c, int move, int slot) {
                 else c.st[oMeta + 3] |= 4u;
             }
         }
-        c.scratch[2 * 4 * kResultCap * 2 + slot * 4 + dir] = static_cast<uint32_t>(n);
+        c.scratch[oResultCount + w * 4 + dir] = static_cast<uint32_t>(n);
     }
 }
 
 // Updater::updatePatterns (Pattern.cpp:138-165): lane = direction * 16 + result slot
 __device__ inline void update_patterns(const Ctx& c, int move, int slot, int delta) {
     const int dir = c.lane >> 4, r = c.lane & 15;
-    if (r >= static_cast<int>(c.scratch[2 * 4 * kResultCap * 2 + slot * 4 + dir])) return;
+    if (r >= static_cast<int>(c.scratch[oResultCount + slot * 4 + dir])) return;
     const uint32_t* res = c.scratch + ((slot * 4 + dir) * kResultCap + r) * 2;
     const uint32_t w0 = res[0], w1 = res[1];
     const int type = w0 & 15, fav = (w0 >> 4) & 1, back = static_cast<int>(w0 >> 28);
@@ -128,36 +139,49 @@ __device__ inline void update_patterns(const Ctx& c, int move, int slot, int del
     const int score = delta * static_cast<int>(dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu));
     uint32_t* scores = c.st + oScores;
     const int n_dep = (w0 >> 8) & 7;
-    for (int d = 0; d < n_dep; ++d) {
+    // per scored blank: the flag fields of both views live in one word (one returning atomic starts them all), the score adds
+    // need no answer; the second half of the flag updates follows once the answers are back
+    uint32_t* words[4];
+    uint32_t lowers[4], olds[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d >= n_dep) break;
         const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
         const int cell = last_cell - static_cast<int>(f & 7u) * stride;
-        uint32_t* word = &c.st[oPdist + cell * 8 + type];
-        if (f & 8u) {                                                                  // '_': the owner's view, then falls through
-            set_flag(word, delta, group2(fav, fav), dir);
-            atomicAdd(&scores[group2(fav, fav) * kCells + cell], static_cast<uint32_t>(score));
-        }
-        set_flag(word, delta, group2(fav, fav ^ 1), dir);                              // '_' and '^': the opponent's view
+        words[d] = &c.st[oPdist + cell * 8 + type];
+        lowers[d] = 1u << ((4 * group2(fav, fav ^ 1) + dir) * 2);                      // '_' and '^': the opponent's view
+        if (f & 8u) lowers[d] |= 1u << ((4 * group2(fav, fav) + dir) * 2);             // '_': the owner's view too
+        olds[d] = set_flags_begin(words[d], delta, lowers[d]);
+        if (f & 8u) atomicAdd(&scores[group2(fav, fav) * kCells + cell], static_cast<uint32_t>(score));
         atomicAdd(&scores[group2(fav, fav ^ 1) * kCells + cell], static_cast<uint32_t>(score));
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d >= n_dep) break;
+        set_flags_end(words[d], delta, lowers[d], olds[d]);
     }
 }
 
-// One compound at (cell, player): Compound::Compound / locate / update (Pattern.cpp:435-550)
-__device__ inline void update_one_compound(const Ctx& c, int cell, int pb /* player is black */, int delta) {
+// One compound at (cell, player): Compound::Compound / locate (Pattern.cpp:435-486) and the bookkeeping of
+// Compound::update (:488-518).  update() walks the components one after the other, but what it does for component i
+// only depends on i and on the count the compound had before (count_i = count + i * delta): the components are
+// queued here and handled side by side by apply_compound_items().
+// Item: cell | black << 8 | compound type << 9 | direction << 11 | component type (0 L3, 1 D3, 2 L2) << 13 |
+//       look for counter moves << 15 | bump the compound total << 16
+__device__ inline void queue_compound(const Ctx& c, int cell, int pb /* player is black */, int delta) {
     const uint32_t* pd = c.st + oPdist + cell * 8;
-    const int g_own = group2(pb, pb), g_opp = group2(pb, pb ^ 1);
+    const int g_own = group2(pb, pb);
     // locate(): state machine S0,L2,LD3,To33,To43,To44 = 0..5 over the directions; first present of L3, D3, L2 per direction
     int state = 0, l3 = 0, triple = 0, n_comp = 0;
     uint32_t comps = 0;                                         // 4 bits per component: dir | (0 L3, 1 D3, 2 L2) << 2
+    const uint32_t f_l3 = pd[5] >> (8 * g_own), f_d3 = pd[4] >> (8 * g_own), f_l2 = pd[3] >> (8 * g_own);
     for (int d = 0; d < 4; ++d) {
-        const int shift = (4 * g_own + d) * 2;
-        int count = 0, t = -1;
-        const uint32_t flags[3] = {(pd[5] >> shift) & 3u, (pd[4] >> shift) & 3u, (pd[3] >> shift) & 3u};      // LiveThree, DeadThree, LiveTwo
-        for (int k = 0; k < 3; ++k) {
-            count = flags[k] == 1u ? 1 : flags[k] == 3u ? 2 : flags[k] == 0u ? 0 : count;
-            if (count) { t = k; break; }
-        }
+        // a 2-bit flag field counts 0, 1, 2-or-more as 00, 01, 11 (10 does not occur and counts as nothing, Pattern.cpp:457-462)
+        auto count_of = [](uint32_t f) { return (f & 1u) ? static_cast<int>((f >> 1) & 1u) + 1 : 0; };
+        const int k3 = count_of(f_l3 >> (2 * d)), kd = count_of(f_d3 >> (2 * d)), k2 = count_of(f_l2 >> (2 * d));
+        const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
         if (t < 0) continue;
-        const int cond = t == 2 ? 1 : 2;
+        const int count = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
         if (t == 0) ++l3;
         for (int r = 0; r < count; ++r) {
             if (n_comp < 8) { comps |= static_cast<uint32_t>(d | (t << 2)) << (4 * n_comp); ++n_comp; }
@@ -168,25 +192,41 @@ __device__ inline void update_one_compound(const Ctx& c, int cell, int pb /* pla
     }
     const int ctype = state - 3;
     if (ctype < 0 || ctype > 2) { c.st[oMeta + 3] |= 2u; return; }                     // the reference indexes out of bounds here
-    uint32_t* cd = c.st + oCdist;
-    uint32_t* scores = c.st + oScores;
-    int count = __popc((cd[cell * 3 + ctype] >> (8 * g_own)) & 0xFFu);
-    for (int i = 0; i < n_comp; ++i) {                                                 // update(delta)
-        const int cdir = (comps >> (4 * i)) & 3, ct = (comps >> (4 * i + 2)) & 3;
-        if (2 * count + delta == -1) return;
-        set_flag(&cd[cell * 3 + ctype], delta, g_own, cdir);                           // updateCritical
+    const int count0 = __popc((c.st[oCdist + cell * 3 + ctype] >> (8 * g_own)) & 0xFFu);
+    const int todo = delta == 1 ? n_comp : min(n_comp, count0);                        // update(-1) stops at "2 * count + delta == -1", i.e. at count 0
+    if (todo == 0) return;
+    const uint32_t slot0 = atomicAdd(&c.scratch[oItemCount], static_cast<uint32_t>(todo));
+    for (int i = 0; i < todo; ++i) {
+        const int count_i = count0 + i * delta;
+        const uint32_t item = static_cast<uint32_t>(cell) | (static_cast<uint32_t>(pb) << 8) | (static_cast<uint32_t>(ctype) << 9) |
+                              (((comps >> (4 * i)) & 15u) << 11) | ((!triple && l3 == 0) ? 1u << 15 : 0u) | ((2 * count_i + delta == 3) ? 1u << 16 : 0u);
+        if (slot0 + i < static_cast<uint32_t>(kCompoundCap)) c.scratch[oItems + slot0 + i] = item;
+        else c.st[oMeta + 3] |= 8u;
+    }
+}
+
+// One queued component: updateCritical, updateAntis, the compound total (Pattern.cpp:488-550)
+__device__ inline void apply_compound_items(const Ctx& c, int delta) {
+    const int n = min(static_cast<int>(c.scratch[oItemCount]), kCompoundCap);
+    for (int m = c.lane; m < n; m += 64) {
+        const uint32_t item = c.scratch[oItems + m];
+        const int cell = item & 255, pb = (item >> 8) & 1, ctype = (item >> 9) & 3, cdir = (item >> 11) & 3, ct = (item >> 13) & 3;
+        const int g_own = group2(pb, pb), g_opp = group2(pb, pb ^ 1);
+        uint32_t* cd = c.st + oCdist;
+        uint32_t* scores = c.st + oScores;
+        // updateCritical: the cell itself, both views (the two flag fields share a word)
+        const uint32_t lowers = (1u << ((4 * g_own + cdir) * 2)) | (1u << ((4 * g_opp + cdir) * 2));
+        const uint32_t old = set_flags_begin(&cd[cell * 3 + ctype], delta, lowers);
         atomicAdd(&scores[g_own * kCells + cell], static_cast<uint32_t>(delta * 600));
-        set_flag(&cd[cell * 3 + ctype], delta, g_opp, cdir);
         atomicAdd(&scores[g_opp * kCells + cell], static_cast<uint32_t>(delta * 600));
-        if (!triple && l3 == 0) {                                                      // updateAntis: first match of the component's type through the cell
+        if (item & (1u << 16)) atomicAdd(&cd[225 * 3 + ctype], static_cast<uint32_t>(delta) << (16 * pb));
+        if (item & (1u << 15)) {                                                       // updateAntis: first match of the component's type through the cell
             const int want = ct == 0 ? 5 : ct == 1 ? 4 : 3, stride = dir_stride(cdir);
-            uint64_t syms = window_symbols(c.st + oLines, cell, cdir);
-            uint32_t row_off = 0;
+            uint32_t cur = static_cast<uint32_t>(window_symbols(c.st + oLines, cell, cdir)) << 2, tw = 0;
             bool found = false;
             for (int k = 0; k < 13 && !found; ++k) {
-                const uint32_t tw = *reinterpret_cast<const uint32_t*>(c.trans + row_off + ((static_cast<uint32_t>(syms) & 3u) << 2));
-                syms >>= 2;
-                row_off = gmk::dev_trans_row(tw);
+                tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
+                cur >>= 2;
                 if (k < 6 || !((gmk::dev_trans_kinds(tw) >> ct) & 1u)) continue;
                 const uint4 r = c.rec[gmk::dev_trans_record(tw)];
                 const uint32_t w0s[2] = {r.x, r.z};
@@ -210,28 +250,34 @@ __device__ inline void update_one_compound(const Ctx& c, int cell, int pb /* pla
                 }
             }
         }
-        if (2 * count + delta == 3) atomicAdd(&cd[225 * 3 + ctype], static_cast<uint32_t>(delta) << (16 * pb));
-        count += delta;
+        set_flags_end(&cd[cell * 3 + ctype], delta, lowers, old);
     }
 }
 
-// Updater::updateCompound for the four directions (Pattern.cpp:167-197): lane = direction * 13 + window index
+// Updater::updateCompound for the four directions (Pattern.cpp:167-197): lane = direction * 13 + window index finds the
+// compounds, then one lane per component applies them
 __device__ inline void update_compounds(const Ctx& c, int move, int delta) {
-    if (c.lane >= 52) return;
-    const int dir = c.lane / 13, i = c.lane % 13;
-    if (i == 6 && dir != 0) return;                             // the centre lies on all four lines: handled once (findCompound)
-    const uint64_t syms = window_symbols(c.st + oLines, move, dir);
-    if (((syms >> (2 * i)) & 3u) != 3u) return;                 // only blanks
-    const int cell = move + (i - 6) * dir_stride(dir);
-    const int32_t* density = reinterpret_cast<const int32_t*>(c.st + oDensity);
-    const uint32_t* pd = c.st + oPdist + cell * 8;
-    for (int pb = 0; pb < 2; ++pb) {                            // { White, Black }
-        if (density[(pb * 2 + 0) * kCells + cell] < 2) continue;
-        const int g = group2(pb, pb);
-        const uint32_t bits = ((pd[5] | pd[4] | pd[3]) >> (8 * g)) & 0xFFu;           // Compound::Test (Pattern.cpp:424-433)
-        if (!(bits & (bits - 1u))) continue;
-        update_one_compound(c, cell, pb, delta);
+    if (c.lane == 0) c.scratch[oItemCount] = 0u;
+    wave_phase_fence();
+    if (c.lane < 52) {
+        const int dir = c.lane / 13, i = c.lane % 13;
+        const uint64_t syms = window_symbols(c.st + oLines, move, dir);
+        // only blanks; the centre lies on all four lines and is handled once (findCompound)
+        if (!(i == 6 && dir != 0) && ((syms >> (2 * i)) & 3u) == 3u) {
+            const int cell = move + (i - 6) * dir_stride(dir);
+            const int32_t* density = reinterpret_cast<const int32_t*>(c.st + oDensity);
+            const uint32_t* pd = c.st + oPdist + cell * 8;
+            const uint32_t any = pd[5] | pd[4] | pd[3];
+            for (int pb = 0; pb < 2; ++pb) {                    // { White, Black }
+                if (density[(pb * 2 + 0) * kCells + cell] < 2) continue;
+                const uint32_t bits = (any >> (8 * group2(pb, pb))) & 0xFFu;           // Compound::Test (Pattern.cpp:424-433)
+                if (!(bits & (bits - 1u))) continue;
+                queue_compound(c, cell, pb, delta);
+            }
+        }
     }
+    wave_phase_fence();
+    apply_compound_items(c, delta);
 }
 
 // Updater::updateBlock (Pattern.cpp:236-272): lanes 0..48 = the 7x7 block around the move
@@ -243,32 +289,40 @@ __device__ inline void update_block(const Ctx& c, int move, int delta, int src_b
     if (static_cast<unsigned>(x) >= 15u || static_cast<unsigned>(y) >= 15u) return;
     const int q = y * 15 + x, w = static_cast<int>((kW[dy + 3] >> (4 * (6 - (dx + 3)))) & 15u);
     int32_t* density = reinterpret_cast<int32_t*>(c.st + oDensity);
+    int32_t* scores = reinterpret_cast<int32_t*>(c.st + oScores);
     int32_t* count = density + (src_black * 2 + 0) * kCells;
     int32_t* weight = density + (src_black * 2 + 1) * kCells;
-    const int before = weight[q] > 0;
-    weight[q] += (weight[q] < 0 ? -1 : 1) * delta * w;
-    count[q] += (weight[q] < 0 ? -1 : 1) * delta * (w > 0 ? 1 : 0);
-    if (q == move)
-        for (int k = 0; k < 4; ++k) {                           // both colours, count and weight: occupied cells hold -v-1
-            int32_t& v = density[k * kCells + move];
-            v = delta == 1 ? -v - 1 : -(v + 1);
-        }
-    int32_t* scores = reinterpret_cast<int32_t*>(c.st + oScores);
-    scores[group2(src_black, src_black) * kCells + q] += 160 * ((weight[q] > 0) - before);
-    if (q == move) {
-        const int other = density[((src_black ^ 1) * 2 + 0) * kCells + move];
-        if (other != 0 && other != -1) scores[group2(src_black ^ 1, src_black ^ 1) * kCells + move] -= delta * 160;
+    int32_t* score = scores + group2(src_black, src_black) * kCells;
+    const bool centre = q == move;
+    int32_t* o_count = density + ((src_black ^ 1) * 2 + 0) * kCells + move;             // the other colour's entries of the centre cell
+    int32_t* o_weight = density + ((src_black ^ 1) * 2 + 1) * kCells + move;
+    int32_t* o_score = scores + group2(src_black ^ 1, src_black ^ 1) * kCells + move;
+    // everything is read first (one LDS round trip), updated in registers in the reference's order, then stored
+    int wv = weight[q], cv = count[q], sv = score[q];
+    int ocv = centre ? *o_count : 0, owv = centre ? *o_weight : 0, osv = centre ? *o_score : 0;
+    const int before = wv > 0;
+    wv += (wv < 0 ? -1 : 1) * delta * w;
+    cv += (wv < 0 ? -1 : 1) * delta * (w > 0 ? 1 : 0);          // the sign of the UPDATED weight (a lazily evaluated expression in the reference)
+    if (centre) {                                               // both colours, count and weight: occupied cells hold -v-1
+        wv = delta == 1 ? -wv - 1 : -(wv + 1);
+        cv = delta == 1 ? -cv - 1 : -(cv + 1);
+        owv = delta == 1 ? -owv - 1 : -(owv + 1);
+        ocv = delta == 1 ? -ocv - 1 : -(ocv + 1);
     }
+    sv += 160 * ((wv > 0) - before);
+    if (centre && ocv != 0 && ocv != -1) osv -= delta * 160;
+    weight[q] = wv; count[q] = cv; score[q] = sv;
+    if (centre) { *o_count = ocv; *o_weight = owv; *o_score = osv; }
 }
 
-// BoardMap::applyMove / revertMove (Mapping.cpp:37-59) + Board bookkeeping (Game.cpp:37-62): lane 0
-__device__ inline void board_set(const Ctx& c, int move, bool place, int black) {
-    if (c.lane != 0) return;
-    const int x = move % 15, y = move / 15, cb = black ? 0 : 16;
-    uint32_t* lines = c.st + oLines;
-    const uint32_t bits[4] = {1u << (x + cb), 1u << (y + cb), 1u << (min(x, y) + cb), 1u << (min(14 - x, y) + cb)};
-    const int idx[4] = {y, kColBase + x, kDiagBase + x - y + 14, kAntiBase + x + y};
-    for (int k = 0; k < 4; ++k) lines[idx[k]] = place ? (lines[idx[k]] | bits[k]) : (lines[idx[k]] & ~bits[k]);
+// BoardMap::applyMove / revertMove (Mapping.cpp:37-59): lanes 0..3, one line word each.  Placing a stone turns the cell's
+// blank (3) into black (0) or white (1); taking it back is the same XOR.
+__device__ inline void board_set(const Ctx& c, int move, int black) {
+    if (c.lane >= 4) return;
+    const int x = move % 15, y = move / 15, k = c.lane;
+    const int at = k == 0 ? x : k == 1 ? y : k == 2 ? min(x, y) : min(14 - x, y);
+    const int idx = k == 0 ? y : k == 1 ? kColBase + x : k == 2 ? kDiagBase + x - y + 14 : kAntiBase + x + y;
+    atomicXor(&c.st[oLines + idx], (black ? 3u : 2u) << (2 * at));
 }
 
 // Updater::updateMove (Pattern.cpp:274-302).  src: +1 / -1 = the mover of an applied move, 0 = revert the last move
@@ -276,7 +330,8 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     int32_t* meta = reinterpret_cast<int32_t*>(c.st + oMeta);
     uint8_t* record = reinterpret_cast<uint8_t*>(c.st + oRecord);
     unsigned long long t_last = c.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-    match_patterns(c, move, 0);
+    // symbol the centre takes: the mover's stone (0 black, 1 white) when a move is applied, blank (3) when it is taken back
+    match_patterns_both(c, move, src != 0 ? (src > 0 ? 0u : 1u) : 3u);
     wave_phase_fence();
     prof_mark(c, 0, t_last);
     update_compounds(c, move, -1);
@@ -287,7 +342,7 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     prof_mark(c, 2, t_last);
     int block_colour;
     if (src != 0) {
-        board_set(c, move, true, src > 0);
+        board_set(c, move, src > 0);
         if (c.lane == 0) { record[meta[0]] = static_cast<uint8_t>(move); meta[0] += 1; meta[1] = -src; }          // Board::applyMove(move, false)
         block_colour = src > 0;
     } else {
@@ -295,7 +350,7 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
         int cur = meta[1];
         if (cur == 0) cur = (n % 2 == 0) ? 1 : -1;              // Board::revertMove: back from a finished game (Game.cpp:51-54)
         const int mover = -cur;                                 // the player whose stone is taken back
-        board_set(c, move, false, mover > 0);
+        board_set(c, move, mover > 0);
         wave_phase_fence();
         if (c.lane == 0) { meta[0] = n - 1; meta[1] = mover; meta[2] = 0; }
         block_colour = mover > 0;
@@ -304,9 +359,6 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     update_block(c, move, src != 0 ? 1 : -1, block_colour);
     wave_phase_fence();
     prof_mark(c, 3, t_last);
-    match_patterns(c, move, 1);
-    wave_phase_fence();
-    prof_mark(c, 4, t_last);
     update_patterns(c, move, 1, 1);
     wave_phase_fence();
     prof_mark(c, 5, t_last);
@@ -318,7 +370,7 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
 
 // Evaluator::reset (Pattern.cpp:370-386, Game.cpp:138-146): empty board, black to move
 __device__ __forceinline__ void reset_state(const Ctx& c) {
-    for (int i = c.lane; i < kStateWords; i += 64) c.st[i] = 0u;
+    for (int i = c.lane; i < kStateWords; i += 64) c.st[i] = i < kLineWords ? blank_line_word(i) : 0u;
     wave_phase_fence();
     if (c.lane == 0) c.st[oMeta + 1] = 1u;
     wave_phase_fence();
@@ -328,7 +380,7 @@ __device__ __forceinline__ void reset_state(const Ctx& c) {
 __device__ __forceinline__ void apply_move(const Ctx& c, int mv) {
     const int32_t* meta = reinterpret_cast<const int32_t*>(c.st + oMeta);
     const int cur = meta[1];
-    const bool empty = mv >= 0 && mv < kCells && !((c.st[oLines + mv / 15] >> (mv % 15)) & 0x10001u);
+    const bool empty = mv >= 0 && mv < kCells && ((c.st[oLines + mv / 15] >> (2 * (mv % 15))) & 3u) == 3u;
     if (cur != 0 && empty) update_move(c, mv, cur);
 }
 
@@ -337,6 +389,12 @@ __device__ __forceinline__ void revert_move(const Ctx& c) {
     const int32_t* meta = reinterpret_cast<const int32_t*>(c.st + oMeta);
     const uint8_t* record = reinterpret_cast<const uint8_t*>(c.st + oRecord);
     if (meta[0] > 0) update_move(c, record[meta[0] - 1], 0);
+}
+
+// the state of a fresh Evaluator, for the host-side resets
+inline void fill_initial_state(uint32_t* st) {
+    for (int i = 0; i < kStateWords; ++i) st[i] = i < kLineWords ? blank_line_word(i) : 0u;
+    st[oMeta + 1] = 1u;                                          // black to move (Board::reset, Game.cpp:138-146)
 }
 
 }  // namespace gmk::evs

@@ -60,7 +60,7 @@ struct gmk_evalstate {
 extern "C" int gmk_evalstate_reset(gmk_evalstate* e) {
     if (!e) return GMK_ERR_ARG;
     std::vector<uint32_t> one(kStateWords, 0u);
-    reinterpret_cast<int32_t*>(one.data() + oMeta)[1] = 1;                           // black to move (Board::reset, Game.cpp:138-146)
+    fill_initial_state(one.data());
     std::vector<uint32_t> all(static_cast<size_t>(e->n_games) * kStateWords);
     for (int g = 0; g < e->n_games; ++g) std::memcpy(all.data() + static_cast<size_t>(g) * kStateWords, one.data(), kStateWords * 4);
     GMK_HIP_CHECK(hipMemcpy(e->d_states, all.data(), all.size() * 4, hipMemcpyHostToDevice));

@@ -446,7 +446,7 @@ extern "C" int gmk_trad_destroy(gmk_trad* t) {
 extern "C" int gmk_trad_reset_evaluators(gmk_trad* t) {
     if (!t) return GMK_ERR_ARG;
     std::vector<uint32_t> all(static_cast<size_t>(t->n_games) * kStateWords, 0u);
-    for (int g = 0; g < t->n_games; ++g) all[static_cast<size_t>(g) * kStateWords + oMeta + 1] = 1u;       // black to move
+    for (int g = 0; g < t->n_games; ++g) fill_initial_state(all.data() + static_cast<size_t>(g) * kStateWords);
     GMK_HIP_CHECK(hipMemcpy(t->d_states, all.data(), all.size() * 4, hipMemcpyHostToDevice));
     return GMK_OK;
 }
