@@ -10,9 +10,12 @@
 //             (or rebuilt) only as far as the next path differs (Heuristic.hpp:165-200)
 // The search has no random numbers; it is a serial chain per game, so the GPU runs MANY games: one wavefront per
 // game, seven games per workgroup, the evaluator state (17.8 KB, evalstate_device.h) and the current path in LDS,
-// the tree in HBM (24 B per node: statistics, parent / cell / prior, child range, and one slot of the child ORDER
-// array that BackPropogate permutes).  Float reductions use one fixed order (sum225, the same as oracle/go_trad.c);
-// PUCB and tanh are evaluated in double like the reference.
+// the tree in HBM (29 B per node: statistics, parent / cell / prior, child range, the record of its FIRST child, and
+// its own position in the parent's child order, which is all that BackPropogate's swaps change).  The search walks
+// first children only, so the path of the previous playout stays valid down to the shallowest level whose first
+// child changed: select re-reads nothing above it, and backup reads every level's children in one round of
+// independent loads, the next level's issued before the current one is reduced.  Float reductions use one fixed
+// order (sum225, the same as oracle/go_trad.c); PUCB and tanh are evaluated in double like the reference.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -27,9 +30,8 @@ constexpr int kGamesPerBlock = 7;
 constexpr int kThreads = 64 * kGamesPerBlock;
 constexpr int kPathCap = 228;                    // a path has at most 226 nodes
 constexpr int kRecordWords = 57;
-constexpr int kMiscWords = 8;
-// per-game LDS: evaluator state | evaluator scratch | path node ids | path child ranges | record copy | misc
-constexpr int kPerGame = (kStateWords + kScratchWords + 2 * kPathCap + kRecordWords + kMiscWords + 3) & ~3;
+// per-game LDS: evaluator state | evaluator scratch | path nodes (id | cell << 24) | path child ranges | record copy
+constexpr int kPerGame = (kStateWords + kScratchWords + 2 * kPathCap + kRecordWords + 3) & ~3;
 constexpr uint32_t kNoParent = 0xFFFFFFu;
 
 struct TradHeader {                              // 64 B per game in HBM
@@ -44,8 +46,9 @@ struct TradParams {
     uint32_t* states;                            // [n_games][kStateWords]
     uint2* stat;                                 // [n_games][cap] {visits, value bits}
     uint2* info;                                 // [n_games][cap] {parent | cell << 24, prior bits}
-    uint32_t* link;                              // [n_games][cap] first child | children << 24
-    uint32_t* kids;                              // [n_games][cap] child order: slot k belongs to the parent whose range covers node k + 1
+    uint32_t* link;                              // [n_games][cap] first child | children << 24 (children are consecutive nodes)
+    uint2* front;                                // [n_games][cap] the child that is first in the CURRENT order: {id | cell << 24, its link word}
+    uint8_t* ord;                                // [n_games][cap] the node's position in its parent's current child order
     TradHeader* hdr;
     const uint8_t* moves;                        // [n_games][225] position to search from (read when hdr.fresh)
     const int32_t* lens;
@@ -158,7 +161,8 @@ struct Game {
     uint2* stat;
     uint2* info;
     uint32_t* link;
-    uint32_t* kids;
+    uint2* front;
+    uint8_t* ord;
     int cached, init;
     unsigned long long updates;
 };
@@ -214,7 +218,8 @@ void trad_playouts_kernel(TradParams prm) {
     g.stat = prm.stat + arena;
     g.info = prm.info + arena;
     g.link = prm.link + arena;
-    g.kids = prm.kids + arena;
+    g.front = prm.front + arena;
+    g.ord = prm.ord + arena;
     g.updates = 0;
     TradHeader* hdr = prm.hdr + game;
     int32_t* meta = reinterpret_cast<int32_t*>(g.c.st + oMeta);
@@ -252,21 +257,43 @@ void trad_playouts_kernel(TradParams prm) {
     }
     g.cached = g.init;
 
+    // path[0 .. valid] is known to be the chain of first children from the root (node id | cell << 24, child range)
+    int valid = 0;
+    if (lane == 0) { g.path_node[0] = 0u; g.path_link[0] = fresh ? 0u : g.link[0]; }
+    wave_phase_fence();
+
+    struct Level {                                              // what backup needs of one path node: its statistics and its children
+        uint2 ns, cs[4], ci[4];
+        uint32_t cl[4], co[4];
+    };
+    auto load_level = [&](int d) {
+        Level L;
+        const uint32_t nd = g.path_node[d] & 0xFFFFFFu, lk = g.path_link[d], first = lk & 0xFFFFFFu, n = lk >> 24;
+        L.ns = g.stat[nd];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = lane + 64 * k, id = first + i;
+            if (i < n) { L.cs[k] = g.stat[id]; L.ci[k] = g.info[id]; L.cl[k] = g.link[id]; L.co[k] = g.ord[id]; }
+            else { L.cs[k] = make_uint2(0u, 0u); L.ci[k] = make_uint2(0u, 0u); L.cl[k] = 0u; L.co[k] = 0xFFFFFFFFu; }
+        }
+        return L;
+    };
+
     for (int it = 0; it < prm.playouts && !(status & 1u); ++it) {
-        // ---- select: always the first child in the current order; the evaluator follows ----
-        int depth = 0;
-        uint32_t node = 0, link = g.link[0];
-        g.path_node[0] = 0;
-        g.path_link[0] = link;
+        // ---- select: always the first child in the current order (RAVE::Select); the evaluator follows ----
+        int depth = valid;
+        for (int d = 1; d <= depth; ++d) cached_apply_move(g, static_cast<int>(g.path_node[d] >> 24));
+        uint32_t node = g.path_node[depth] & 0xFFFFFFu, link = g.path_link[depth];
         while (link >> 24) {
-            node = g.kids[(link & 0xFFFFFFu) - 1u];
-            const uint32_t cell = g.info[node].x >> 24;
-            link = g.link[node];
+            const uint2 rec = g.front[node];
+            node = rec.x & 0xFFFFFFu;
+            link = rec.y;
             ++depth;
-            if (lane == 0) { g.path_node[depth] = node; g.path_link[depth] = link; }
-            cached_apply_move(g, static_cast<int>(cell));
+            if (lane == 0) { g.path_node[depth] = rec.x; g.path_link[depth] = link; }
+            cached_apply_move(g, static_cast<int>(rec.x >> 24));
         }
         wave_phase_fence();
+        int path_len = depth;                                   // deepest level with a known node
 
         // ---- TraditionalPolicy::checkGameEnd -> Evaluator::checkGameEnd (Pattern.cpp:344-354) ----
         bool ended = meta[1] == 0;
@@ -304,13 +331,14 @@ void trad_playouts_kernel(TradParams prm) {
             value = -state_value;
 
             // ---- Default::Expand, extraCheck = false: children in ascending cell order ----
-            int total = 0, rank[4];
+            int total = 0, rank[4], first_cell = -1;
             bool nz[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 nz[j] = lane + 64 * j < kCells && probs.v[j] != 0.0f;
                 const unsigned long long b = __ballot(nz[j]);
                 rank[j] = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
+                if (first_cell < 0 && b) first_cell = 64 * j + __ffsll(static_cast<unsigned long long>(b)) - 1;
                 total += __popcll(b);
             }
             if (total > 0) {
@@ -324,10 +352,19 @@ void trad_playouts_kernel(TradParams prm) {
                             g.stat[child] = make_uint2(0u, 0u);
                             g.info[child] = make_uint2(node | (static_cast<uint32_t>(lane + 64 * j) << 24), __float_as_uint(probs.v[j]));
                             g.link[child] = 0u;
-                            g.kids[child - 1u] = child;
+                            g.ord[child] = static_cast<uint8_t>(rank[j]);
                         }
                     link = n_nodes | (static_cast<uint32_t>(total) << 24);
-                    if (lane == 0) { g.link[node] = link; g.path_link[depth] = link; }
+                    if (lane == 0) {
+                        const uint32_t front_rec = n_nodes | (static_cast<uint32_t>(first_cell) << 24);
+                        g.link[node] = link;
+                        g.front[node] = make_uint2(front_rec, 0u);
+                        if (depth > 0) g.front[g.path_node[depth - 1] & 0xFFFFFFu] = make_uint2(g.path_node[depth], link);      // the parent's record of this node
+                        g.path_link[depth] = link;
+                        g.path_node[depth + 1] = front_rec;
+                        g.path_link[depth + 1] = 0u;
+                    }
+                    path_len = depth + 1;
                     n_nodes += total;
                 }
             }
@@ -338,40 +375,70 @@ void trad_playouts_kernel(TradParams prm) {
         wave_phase_fence();
         if (status & 1u) break;
 
-        // ---- RAVE::BackPropogate<false> (MonteCarlo.hpp:160-184) ----
+        // ---- RAVE::BackPropogate<false> (MonteCarlo.hpp:160-184), leaf to root ----
+        int swap_level = -1;
+        uint2 swap_rec = make_uint2(0u, 0u);
+        uint32_t updated_id = 0xFFFFFFFFu;                      // the path node one level below: its statistics were just rewritten
+        uint2 updated_stat = make_uint2(0u, 0u);
+        Level cur = load_level(depth);
         for (int d = depth; d >= 0; --d, value = -value) {
-            const uint32_t nd = g.path_node[d], lk = g.path_link[d];
+            Level nxt;
+            if (d > 0) nxt = load_level(d - 1);                 // in flight while this level is reduced
+            const uint32_t nd = g.path_node[d] & 0xFFFFFFu, lk = g.path_link[d];
             const uint32_t first = lk & 0xFFFFFFu, n = lk >> 24;
-            const uint2 st = g.stat[nd];
-            const double sqrt_n = sqrt(static_cast<double>(st.x));
+            const double sqrt_n = sqrt(static_cast<double>(cur.ns.x));
             double best_score = -INFINITY;
-            uint32_t best_i = 0xFFFFFFFFu;
-            for (uint32_t i = lane; i < n; i += 64) {
-                const uint32_t kid = g.kids[first - 1u + i];
-                const uint2 cs = g.stat[kid];
-                const double p_i = __uint_as_float(g.info[kid].y), n_i = static_cast<double>(cs.x + 1u);
+            uint32_t best_ord = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = lane + 64 * k;
+                if (i >= n) continue;
+                uint2 cs = cur.cs[k];
+                if (first + i == updated_id) cs = updated_stat;
+                const double p_i = __uint_as_float(cur.ci[k].y), n_i = static_cast<double>(cs.x + 1u);
                 double score = prm.c_puct * p_i * sqrt_n / n_i;                        // Default::PUCB (:23-28)
                 score += __uint_as_float(cs.y);
-                if (score > best_score) { best_score = score; best_i = i; }
+                // the reference scans the children in their current order and keeps the first maximum
+                if (score > best_score || (score == best_score && cur.co[k] < best_ord)) { best_score = score; best_ord = cur.co[k]; }
             }
 #pragma unroll
-            for (int s = 32; s > 0; s >>= 1) {                                         // first maximum in the current order
+            for (int s = 32; s > 0; s >>= 1) {
                 const double os = __shfl_down(best_score, s);
-                const uint32_t oi = __shfl_down(best_i, s);
-                if (os > best_score || (os == best_score && oi < best_i)) { best_score = os; best_i = oi; }
+                const uint32_t oo = __shfl_down(best_ord, s);
+                if (os > best_score || (os == best_score && oo < best_ord)) { best_score = os; best_ord = oo; }
             }
-            best_i = __shfl(best_i, 0);
-            if (lane == 0) {
-                if (n && best_i != 0xFFFFFFFFu && best_i != 0u) {                      // the best child moves to the front
-                    const uint32_t a = g.kids[first - 1u], b = g.kids[first - 1u + best_i];
-                    g.kids[first - 1u] = b;
-                    g.kids[first - 1u + best_i] = a;
+            best_ord = __shfl(best_ord, 0);
+            if (n && best_ord != 0xFFFFFFFFu && best_ord != 0u) {                      // the best child moves to the front: it swaps places with the first one
+                uint2 mine = make_uint2(0u, 0u);
+                bool owner = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (lane + 64 * k < n && cur.co[k] == best_ord) { owner = true; mine = make_uint2((first + lane + 64 * k) | (cur.ci[k].x & 0xFF000000u), cur.cl[k]); }
+                const int src = __ffsll(static_cast<unsigned long long>(__ballot(owner))) - 1;
+                const uint2 rec = make_uint2(__shfl(mine.x, src), __shfl(mine.y, src));
+                if (lane == 0) {
+                    g.ord[rec.x & 0xFFFFFFu] = 0;
+                    g.ord[g.path_node[d + 1] & 0xFFFFFFu] = static_cast<uint8_t>(best_ord);
+                    g.front[nd] = rec;
                 }
-                const uint32_t visits = st.x + 1u;
-                const float q = __uint_as_float(st.y);
-                g.stat[nd] = make_uint2(visits, __float_as_uint(q + (value - q) / static_cast<float>(visits)));
+                swap_level = d;
+                swap_rec = rec;
             }
+            const uint32_t visits = cur.ns.x + 1u;
+            const float q = __uint_as_float(cur.ns.y);
+            updated_id = nd;
+            updated_stat = make_uint2(visits, __float_as_uint(q + (value - q) / static_cast<float>(visits)));
+            if (lane == 0) g.stat[nd] = updated_stat;
+            cur = nxt;
         }
+        wave_phase_fence();
+        if (swap_level >= 0) {                                  // below the shallowest swap the chain of first children is a different one
+            if (lane == 0) { g.path_node[swap_level + 1] = swap_rec.x; g.path_link[swap_level + 1] = swap_rec.y; }
+            valid = swap_level + 1;
+        } else {
+            valid = path_len;
+        }
+        wave_phase_fence();
 
         // ---- Heuristic::CachedRevertMove (Heuristic.hpp:192-200) ----
         if (meta[0] != g.cached) status |= 4u;                  // the reference would take stones off the inner board only: not reproduced
@@ -396,27 +463,26 @@ void trad_playouts_kernel(TradParams prm) {
 
 // root statistics by cell and the child MCTS::stepForward would pick (most visited, first in the CURRENT order)
 __global__ __launch_bounds__(64)
-void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t* link, const uint32_t* kids, int cap,
+void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t* link, const uint8_t* ord, int cap,
                             uint32_t* visits, float* values, float* priors, int32_t* best, uint32_t* root_visits, float* root_value) {
     const int game = blockIdx.x, lane = threadIdx.x;
     const size_t arena = static_cast<size_t>(game) * cap;
     const uint32_t lk = link[arena], first = lk & 0xFFFFFFu, n = lk >> 24;
-    uint32_t best_visits = 0, best_i = 0xFFFFFFFFu;
+    uint32_t best_visits = 0, best_ord = 0xFFFFFFFFu, best_cell = 0;
     for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t kid = kids[arena + first - 1u + i];
-        const uint2 cs = stat[arena + kid], ci = info[arena + kid];
-        const uint32_t cell = ci.x >> 24;
+        const uint2 cs = stat[arena + first + i], ci = info[arena + first + i];
+        const uint32_t cell = ci.x >> 24, o = ord[arena + first + i];
         if (visits) visits[static_cast<size_t>(game) * 225 + cell] = cs.x;
         if (values) values[static_cast<size_t>(game) * 225 + cell] = __uint_as_float(cs.y);
         if (priors) priors[static_cast<size_t>(game) * 225 + cell] = __uint_as_float(ci.y);
-        if (best_i == 0xFFFFFFFFu || cs.x > best_visits) { best_visits = cs.x; best_i = i; }
+        if (best_ord == 0xFFFFFFFFu || cs.x > best_visits || (cs.x == best_visits && o < best_ord)) { best_visits = cs.x; best_ord = o; best_cell = cell; }
     }
     for (int s = 32; s > 0; s >>= 1) {
-        const uint32_t ov = __shfl_down(best_visits, s), oi = __shfl_down(best_i, s);
-        if (oi != 0xFFFFFFFFu && (best_i == 0xFFFFFFFFu || ov > best_visits || (ov == best_visits && oi < best_i))) { best_visits = ov; best_i = oi; }
+        const uint32_t ov = __shfl_down(best_visits, s), oo = __shfl_down(best_ord, s), oc = __shfl_down(best_cell, s);
+        if (oo != 0xFFFFFFFFu && (best_ord == 0xFFFFFFFFu || ov > best_visits || (ov == best_visits && oo < best_ord))) { best_visits = ov; best_ord = oo; best_cell = oc; }
     }
     if (lane == 0) {
-        if (best) best[game] = best_i == 0xFFFFFFFFu ? -1 : static_cast<int32_t>(info[arena + kids[arena + first - 1u + best_i]].x >> 24);
+        if (best) best[game] = best_ord == 0xFFFFFFFFu ? -1 : static_cast<int32_t>(best_cell);
         if (root_visits) root_visits[game] = stat[arena].x;
         if (root_value) root_value[game] = __uint_as_float(stat[arena].y);
     }
@@ -428,7 +494,9 @@ struct gmk_trad {
     int n_games = 0, cap = 0;
     uint32_t* d_states = nullptr;
     uint2 *d_stat = nullptr, *d_info = nullptr;
-    uint32_t *d_link = nullptr, *d_kids = nullptr;
+    uint32_t* d_link = nullptr;
+    uint2* d_front = nullptr;
+    uint8_t* d_ord = nullptr;
     TradHeader* d_hdr = nullptr;
     uint8_t* d_moves = nullptr;
     int32_t* d_lens = nullptr;
@@ -438,7 +506,7 @@ struct gmk_trad {
 extern "C" int gmk_trad_destroy(gmk_trad* t) {
     if (!t) return GMK_OK;
     (void)hipFree(t->d_states); (void)hipFree(t->d_stat); (void)hipFree(t->d_info); (void)hipFree(t->d_link);
-    (void)hipFree(t->d_kids); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
+    (void)hipFree(t->d_front); (void)hipFree(t->d_ord); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
     delete t;
     return GMK_OK;
 }
@@ -461,7 +529,7 @@ extern "C" int gmk_trad_create(int n_games, int node_capacity, gmk_trad** out) {
     const size_t nodes = static_cast<size_t>(n_games) * node_capacity;
     bool ok = hipMalloc(&t->d_states, static_cast<size_t>(n_games) * kStateWords * 4) == hipSuccess &&
               hipMalloc(&t->d_stat, nodes * 8) == hipSuccess && hipMalloc(&t->d_info, nodes * 8) == hipSuccess &&
-              hipMalloc(&t->d_link, nodes * 4) == hipSuccess && hipMalloc(&t->d_kids, nodes * 4) == hipSuccess &&
+              hipMalloc(&t->d_link, nodes * 4) == hipSuccess && hipMalloc(&t->d_front, nodes * 8) == hipSuccess && hipMalloc(&t->d_ord, nodes) == hipSuccess &&
               hipMalloc(&t->d_hdr, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess &&
               hipMalloc(&t->d_moves, static_cast<size_t>(n_games) * 225) == hipSuccess &&
               hipMalloc(&t->d_lens, static_cast<size_t>(n_games) * 4) == hipSuccess;
@@ -497,7 +565,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
         t->attr_set = true;
     }
     TradParams prm;
-    prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.kids = t->d_kids; prm.hdr = t->d_hdr;
+    prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.front = t->d_front; prm.ord = t->d_ord; prm.hdr = t->d_hdr;
     prm.moves = t->d_moves; prm.lens = t->d_lens;
     prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
@@ -520,7 +588,7 @@ extern "C" int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_val
     GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4)); GMK_TRY(hipMalloc(&d_priors, n * 225 * 4));
     GMK_TRY(hipMalloc(&d_best, n * 4)); GMK_TRY(hipMalloc(&d_root_visits, n * 4)); GMK_TRY(hipMalloc(&d_root_value, n * 4));
     GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_priors, 0, n * 225 * 4));
-    hipLaunchKernelGGL(trad_root_stats_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->d_stat, t->d_info, t->d_link, t->d_kids, t->cap,
+    hipLaunchKernelGGL(trad_root_stats_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->d_stat, t->d_info, t->d_link, t->d_ord, t->cap,
                        d_visits, d_values, d_priors, d_best, d_root_visits, d_root_value);
     GMK_TRY(hipGetLastError());
     GMK_TRY(hipDeviceSynchronize());
