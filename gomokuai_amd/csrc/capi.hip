@@ -71,7 +71,10 @@ extern "C" int gmk_device_info(int* cu_count, size_t* hbm_bytes, char* name, int
     GMK_HIP_CHECK(hipGetDeviceProperties(&prop, st.device));
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
-    if (name && name_cap > 0) { std::strncpy(name, prop.name, static_cast<size_t>(name_cap) - 1); name[name_cap - 1] = 0; }
+    if (name && name_cap > 0) {                                  // the marketing name can be empty on this image (no amdgpu.ids): fall back to the ISA name
+        std::strncpy(name, prop.name[0] ? prop.name : prop.gcnArchName, static_cast<size_t>(name_cap) - 1);
+        name[name_cap - 1] = 0;
+    }
     return GMK_OK;
 }
 
