@@ -144,6 +144,46 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
             "note": "a serial chain per game (one wavefront each): bound by LDS / HBM latency, not by bandwidth; no roofline fraction is claimed"}
 
 
+def bench_az(args, G, torch, dev, rank, world, distributed):
+    """BASELINE configs[4]: network-guided MCTS (K7) in lock step, PolicyValueNetwork (PyTorch-ROCm, float32, random weights)
+    at the leaves.  One step = one playout of every game = select kernel + network forward + expand kernel."""
+    import numpy as np
+    from gomokuai_amd.network import PolicyValueNetwork
+    n, P = args.az_games, args.az_playouts
+    moves, lens, planes, _ = mcts_openings(G, np, n, rank * n)
+    last = np.stack([moves[np.arange(n), lens - 1], moves[np.arange(n), lens - 2]], 1).astype(np.int16)
+    net = PolicyValueNetwork(seed=1).to(dev).eval()
+    tree = G.AlphaZeroMCTS(n, node_capacity=(P + 4) * 225 + 1)
+    tree.set_roots(planes, last)
+    with torch.no_grad():
+        tree.search(net, 3)                                # warm-up (MIOpen picks its kernels here)
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tree.search(net, P)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        s = tree.states.clone()
+        e0.record()
+        for _ in range(10):
+            net(s)
+        e1.record()
+        torch.cuda.synchronize()
+        net_ms = e0.elapsed_time(e1) / 10
+    if distributed:
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = float(t[0])
+    tree.close()
+    return {"metric": "network-guided-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_step": ms / P,
+            "network_ms_per_step": net_ms,
+            "config": {"workload": "network-guided MCTS (K7), %d games x %d lock-step playouts per GPU, PolicyValueNetwork float32 with random weights, 4-ply openings" % (n, P)},
+            "note": "the step is the network's forward pass (MIOpen convolutions through PyTorch-ROCm); the select and expand kernels take the remainder"}
+
+
 def cpu_baseline_trad(G, playouts):
     """The oracle's restatement of the same search (oracle/go_trad.c), single thread, ~5 s."""
     from oracle import oracle as O
@@ -194,6 +234,8 @@ def main():
     ap.add_argument("--mcts-games", type=int, default=4096, help="games per GPU for the secondary MCTS measurement (BASELINE configs[2]); 0 = skip")
     ap.add_argument("--mcts-playouts", type=int, default=800)
     ap.add_argument("--mcts-reps", type=int, default=3)
+    ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
+    ap.add_argument("--az-playouts", type=int, default=60)
     ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
@@ -262,6 +304,10 @@ def main():
     if args.trad_games > 0:
         trad = bench_trad(args, G, torch, dev, rank, world, distributed)
 
+    az = None
+    if args.az_games > 0:
+        az = bench_az(args, G, torch, dev, rank, world, distributed)
+
     if rank == 0:
         achieved = ALG_BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -290,6 +336,8 @@ def main():
             out["secondary"] = mcts
         if trad is not None:
             out["supervisor"] = trad
+        if az is not None:
+            out["network_guided"] = az
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.kind)
             if mcts is not None:

@@ -1,0 +1,324 @@
+// az_kernel.hip -- K7: network-guided tree search, many games per step (BASELINE.json configs[4]).
+//
+// The reference's AlphaZero-style agent is MCTS with Policy(eval_state = network.eval_state, c_puct)
+// (agents/alphazero.py:5-9): Default::Select, a network call at every new leaf instead of rollouts, Default::Expand with
+// the returned probabilities and the legality check, Default::BackPropogate (core/lib/include/algorithms/MonteCarlo.hpp:
+// 57-95, core/lib/src/MCTS.cpp:158-177).  One game evaluates ONE position per playout, so a GPU batch comes from running
+// many games in lock step; a playout of every game is
+//     az_select_kernel      descend to a leaf; finished games at the leaf are backed up at once, the others write the
+//                           leaf's feature planes (Board.encoded_states, core/py_ext/src/game_ext.hpp:87-104) as one
+//                           row of the batch [n_games][6][15][15]
+//     the network           any callable on that batch (PyTorch-ROCm PolicyValueNetwork, network/model_tf.py:28-66)
+//     az_expand_kernel      children with the returned priors, value backed up to the root
+// all on one HIP stream (the three steps can be captured in a hipGraph and replayed per playout).
+// Mapping: one wavefront per game, lanes over the (<= 225) children; the tree is an SoA arena per game in HBM.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "board_device.h"
+#include "capi_common.h"
+
+namespace {
+
+using gmk::five_through;
+
+constexpr int kCells = 225;
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+struct AzHeader {                                // 256 B per game, in HBM
+    uint32_t rows[16];                           // root position: black | white << 16 per row
+    uint32_t leaf_rows[16];                      // position of the pending leaf
+    uint32_t n_nodes, stones, last_move, last_move2;           // cells 0..224, 255 = none
+    uint32_t status;                             // bit 1: node arena full
+    uint32_t leaf, leaf_pending;                 // node waiting for the network's answer (leaf_pending = 1)
+    uint32_t leaf_stones;
+    uint32_t pad[24];
+};
+static_assert(sizeof(AzHeader) == 256, "AzHeader layout");
+
+struct AzTree {
+    AzHeader* hdr;
+    uint2* stat;                                 // [n_games][cap] {visits, value bits}
+    uint2* kids;                                 // [n_games][cap] {first child, children | cell << 8}
+    float* prior;                                // [n_games][cap]
+    uint32_t* parent;                            // [n_games][cap]
+    int cap, n_games;
+    double c_puct;
+};
+
+// Default::BackPropogate (MonteCarlo.hpp:90-95): one lane walks the parent chain
+__device__ __forceinline__ void backup(uint2* stat, const uint32_t* parent, uint32_t node, float value) {
+    for (; node != kNoNode; node = parent[node], value = -value) {
+        const uint2 s = stat[node];
+        const uint32_t visits = s.x + 1u;
+        const float q = __uint_as_float(s.y);
+        stat[node] = make_uint2(visits, __float_as_uint(q + (value - q) / static_cast<float>(visits)));
+    }
+}
+
+__global__ __launch_bounds__(64)
+void az_select_kernel(AzTree t, float* __restrict__ out_states) {
+    __shared__ uint32_t s_rows[16];
+    const int game = blockIdx.x, lane = threadIdx.x;
+    if (game >= t.n_games) return;
+    AzHeader* hdr = t.hdr + game;
+    const size_t arena = static_cast<size_t>(game) * t.cap;
+    uint2* stat = t.stat + arena;
+    const uint2* kids = t.kids + arena;
+    const float* prior = t.prior + arena;
+    if (lane < 16) s_rows[lane] = hdr->rows[lane];
+    __syncthreads();
+    uint32_t node = 0;
+    int stones = static_cast<int>(hdr->stones);
+    uint32_t last = hdr->last_move, last2 = hdr->last_move2;
+
+    // ---- Default::Select (MonteCarlo.hpp:57-68) down to a leaf ----
+    for (;;) {
+        const uint2 k = kids[node];
+        const uint32_t first = k.x, n = k.y & 0xFFu;
+        if (n == 0) break;
+        const double sqrt_n = sqrt(static_cast<double>(stat[node].x));
+        double best_score = -1.0;
+        uint32_t best_i = 0xFFFFFFFFu;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint2 cs = stat[first + i];
+            const double p_i = prior[first + i], n_i = static_cast<double>(cs.x + 1u);
+            const double score = static_cast<double>(__uint_as_float(cs.y)) + t.c_puct * p_i * sqrt_n / n_i;       // Q + PUCB (:23-28)
+            if (score > best_score) { best_score = score; best_i = i; }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {                                             // first maximum, strict '>'
+            const double os = __shfl_down(best_score, s);
+            const uint32_t oi = __shfl_down(best_i, s);
+            if (os > best_score || (os == best_score && oi < best_i)) { best_score = os; best_i = oi; }
+        }
+        best_i = __shfl(best_i, 0);
+        if (best_i == 0xFFFFFFFFu) best_i = 0;                                          // nothing beat the initial -1.0: the first child
+        node = first + best_i;
+        const uint32_t cell = (kids[node].y >> 8) & 0xFFu;
+        if (lane == 0) s_rows[cell / 15] |= 1u << (cell % 15 + ((stones & 1) ? 16 : 0));                            // Policy::applyMove: black moves on even counts
+        __syncthreads();
+        ++stones;
+        last2 = last;
+        last = cell;
+    }
+
+    // ---- Board::checkGameEnd (Game.cpp:88-136): five through the last stone, or a full board ----
+    bool ended = false;
+    int winner = 0;
+    if (stones > 0 && last < 225u) {
+        const int mover_white = (stones - 1) & 1;
+        if (five_through<1>(s_rows, last % 15, last / 15, mover_white ? 16 : 0)) { ended = true; winner = mover_white ? -1 : 1; }
+    }
+    if (!ended && stones == kCells) ended = true;
+    if (ended) {
+        // CalcScore(node.player, winner) (Game.h:34-36): the node's player is the one who made the last move
+        const int node_player = (stones & 1) ? 1 : -1;
+        if (lane == 0) {
+            backup(stat, t.parent + arena, node, static_cast<float>(node_player * winner));
+            hdr->leaf_pending = 0;
+        }
+        if (out_states)
+            for (int i = lane; i < 6 * kCells; i += 64) out_states[static_cast<size_t>(game) * 6 * kCells + i] = 0.0f;
+        return;
+    }
+    if (lane == 0) { hdr->leaf = node; hdr->leaf_pending = 1; hdr->leaf_stones = static_cast<uint32_t>(stones); }
+    if (lane < 16) hdr->leaf_rows[lane] = s_rows[lane];
+    // ---- Board.encoded_states (game_ext.hpp:87-104): own stones, opponent's, empties, last move, the one before, colour to move ----
+    const int cur_white = stones & 1;
+    float* out = out_states + static_cast<size_t>(game) * 6 * kCells;
+    for (int i = lane; i < kCells; i += 64) {
+        const uint32_t row = s_rows[i / 15] >> (i % 15);
+        const bool black = row & 1u, white = (row >> 16) & 1u;
+        out[0 * kCells + i] = (cur_white ? white : black) ? 1.0f : 0.0f;
+        out[1 * kCells + i] = (cur_white ? black : white) ? 1.0f : 0.0f;
+        out[2 * kCells + i] = (!black && !white) ? 1.0f : 0.0f;
+        out[3 * kCells + i] = static_cast<uint32_t>(i) == last ? 1.0f : 0.0f;
+        out[4 * kCells + i] = static_cast<uint32_t>(i) == last2 ? 1.0f : 0.0f;
+        out[5 * kCells + i] = cur_white ? 0.0f : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(64)
+void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* __restrict__ probs) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    if (game >= t.n_games) return;
+    AzHeader* hdr = t.hdr + game;
+    if (!hdr->leaf_pending) return;
+    const size_t arena = static_cast<size_t>(game) * t.cap;
+    const uint32_t leaf = hdr->leaf;
+    uint32_t n_nodes = hdr->n_nodes;
+    // ---- Default::Expand with extraCheck (MonteCarlo.hpp:71-80): probability not 0 and the cell is free; ascending cell id ----
+    const float* p = probs + static_cast<size_t>(game) * kCells;
+    float pv[4];
+    bool take[4];
+    int rank[4], total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        pv[j] = i < kCells ? p[i] : 0.0f;
+        const uint32_t row = i < kCells ? hdr->leaf_rows[i / 15] >> (i % 15) : 0x10001u;
+        take[j] = i < kCells && pv[j] != 0.0f && !(row & 0x10001u);
+        const unsigned long long b = __ballot(take[j]);
+        rank[j] = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
+        total += __popcll(b);
+    }
+    if (total > 0) {
+        if (n_nodes + total > static_cast<uint32_t>(t.cap)) {
+            if (lane == 0) { hdr->status |= 2u; hdr->leaf_pending = 0; }               // arena full: this playout is dropped
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (take[j]) {
+                const uint32_t child = n_nodes + rank[j];
+                t.stat[arena + child] = make_uint2(0u, 0u);
+                t.kids[arena + child] = make_uint2(0u, static_cast<uint32_t>(lane + 64 * j) << 8);
+                t.prior[arena + child] = pv[j];
+                t.parent[arena + child] = leaf;
+            }
+        if (lane == 0) {
+            const uint32_t cell_bits = t.kids[arena + leaf].y & 0xFF00u;
+            t.kids[arena + leaf] = make_uint2(n_nodes, static_cast<uint32_t>(total) | cell_bits);
+            hdr->n_nodes = n_nodes + total;
+        }
+    }
+    __threadfence_block();
+    if (lane == 0) {
+        backup(t.stat + arena, t.parent + arena, leaf, -values[game]);                  // node_value = -state_value (MCTS.cpp:166-168)
+        hdr->leaf_pending = 0;
+    }
+}
+
+__global__ void az_init_roots_kernel(AzTree t) {
+    const int game = blockIdx.x * blockDim.x + threadIdx.x;
+    if (game >= t.n_games) return;
+    const size_t arena = static_cast<size_t>(game) * t.cap;
+    t.stat[arena] = make_uint2(0u, 0u);
+    t.kids[arena] = make_uint2(0u, (t.hdr[game].last_move & 0xFFu) << 8);
+    t.prior[arena] = 1.0f;
+    t.parent[arena] = kNoNode;
+}
+
+__global__ __launch_bounds__(64)
+void az_root_stats_kernel(AzTree t, uint32_t* visits, float* values, float* priors, uint32_t* root_visits, float* root_value) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    const size_t arena = static_cast<size_t>(game) * t.cap;
+    const uint2 k = t.kids[arena];
+    for (uint32_t i = lane; i < (k.y & 0xFFu); i += 64) {
+        const uint32_t child = k.x + i, cell = (t.kids[arena + child].y >> 8) & 0xFFu;
+        const uint2 cs = t.stat[arena + child];
+        if (visits) visits[static_cast<size_t>(game) * kCells + cell] = cs.x;
+        if (values) values[static_cast<size_t>(game) * kCells + cell] = __uint_as_float(cs.y);
+        if (priors) priors[static_cast<size_t>(game) * kCells + cell] = t.prior[arena + child];
+    }
+    if (lane == 0) {
+        if (root_visits) root_visits[game] = t.stat[arena].x;
+        if (root_value) root_value[game] = __uint_as_float(t.stat[arena].y);
+    }
+}
+
+}  // namespace
+
+struct gmk_az {
+    AzTree t{};
+    bool rooted = false;
+};
+
+extern "C" int gmk_az_destroy(gmk_az* a) {
+    if (!a) return GMK_OK;
+    (void)hipFree(a->t.hdr); (void)hipFree(a->t.stat); (void)hipFree(a->t.kids); (void)hipFree(a->t.prior); (void)hipFree(a->t.parent);
+    delete a;
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_create(int n_games, int node_capacity, double c_puct, gmk_az** out) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!out || n_games <= 0 || node_capacity < 256) { gmk::set_error("gmk_az_create: bad arguments"); return GMK_ERR_ARG; }
+    gmk_az* a = new gmk_az;
+    a->t.n_games = n_games; a->t.cap = node_capacity; a->t.c_puct = c_puct;
+    const size_t nodes = static_cast<size_t>(n_games) * node_capacity;
+    const bool ok = hipMalloc(&a->t.hdr, static_cast<size_t>(n_games) * sizeof(AzHeader)) == hipSuccess &&
+                    hipMalloc(&a->t.stat, nodes * 8) == hipSuccess && hipMalloc(&a->t.kids, nodes * 8) == hipSuccess &&
+                    hipMalloc(&a->t.prior, nodes * 4) == hipSuccess && hipMalloc(&a->t.parent, nodes * 4) == hipSuccess;
+    if (!ok) { gmk_az_destroy(a); gmk::set_error("gmk_az_create: device allocation failed"); return GMK_ERR_HIP; }
+    *out = a;
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_set_roots(gmk_az* a, const uint16_t* h_planes, const int16_t* h_last_moves) {
+    if (!a || !h_planes || !h_last_moves) { gmk::set_error("gmk_az_set_roots: bad arguments"); return GMK_ERR_ARG; }
+    std::vector<AzHeader> hdr(a->t.n_games);
+    for (int g = 0; g < a->t.n_games; ++g) {
+        AzHeader& h = hdr[g];
+        std::memset(&h, 0, sizeof h);
+        const uint16_t* p = h_planes + static_cast<size_t>(g) * 32;
+        int stones = 0;
+        for (int y = 0; y < 15; ++y) {
+            if ((p[y] & p[16 + y]) || ((p[y] | p[16 + y]) & 0x8000u)) { gmk::set_error("gmk_az_set_roots: game %d has an invalid position", g); return GMK_ERR_ARG; }
+            h.rows[y] = static_cast<uint32_t>(p[y]) | (static_cast<uint32_t>(p[16 + y]) << 16);
+            stones += __builtin_popcount(h.rows[y]);
+        }
+        h.n_nodes = 1;
+        h.stones = static_cast<uint32_t>(stones);
+        const int16_t l1 = h_last_moves[2 * g], l2 = h_last_moves[2 * g + 1];
+        h.last_move = l1 >= 0 && l1 < 225 ? static_cast<uint32_t>(l1) : 255u;
+        h.last_move2 = l2 >= 0 && l2 < 225 ? static_cast<uint32_t>(l2) : 255u;
+    }
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    GMK_HIP_CHECK(hipMemcpy(a->t.hdr, hdr.data(), hdr.size() * sizeof(AzHeader), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(az_init_roots_kernel, dim3((a->t.n_games + 255) / 256), dim3(256), 0, nullptr, a->t);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    a->rooted = true;
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_select(gmk_az* a, float* d_states, void* stream) {
+    if (!a || !d_states) { gmk::set_error("gmk_az_select: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_select: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    hipLaunchKernelGGL(az_select_kernel, dim3(a->t.n_games), dim3(64), 0, static_cast<hipStream_t>(stream), a->t, d_states);
+    GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_probs, void* stream) {
+    if (!a || !d_values || !d_probs) { gmk::set_error("gmk_az_expand: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_expand: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    hipLaunchKernelGGL(az_expand_kernel, dim3(a->t.n_games), dim3(64), 0, static_cast<hipStream_t>(stream), a->t, d_values, d_probs);
+    GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
+                                 float* h_root_value, int32_t* h_n_nodes, int32_t* h_status) {
+    if (!a) { gmk::set_error("gmk_az_root_stats: bad arguments"); return GMK_ERR_ARG; }
+    const size_t n = static_cast<size_t>(a->t.n_games);
+    uint32_t *d_visits = nullptr, *d_root_visits = nullptr;
+    float *d_values = nullptr, *d_priors = nullptr, *d_root_value = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_values); (void)hipFree(d_priors); (void)hipFree(d_root_visits); (void)hipFree(d_root_value); };
+#define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
+    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4)); GMK_TRY(hipMalloc(&d_priors, n * 225 * 4));
+    GMK_TRY(hipMalloc(&d_root_visits, n * 4)); GMK_TRY(hipMalloc(&d_root_value, n * 4));
+    GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_priors, 0, n * 225 * 4));
+    GMK_TRY(hipDeviceSynchronize());
+    hipLaunchKernelGGL(az_root_stats_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, d_visits, d_values, d_priors, d_root_visits, d_root_value);
+    GMK_TRY(hipGetLastError());
+    GMK_TRY(hipDeviceSynchronize());
+    if (h_visits) GMK_TRY(hipMemcpy(h_visits, d_visits, n * 225 * 4, hipMemcpyDeviceToHost));
+    if (h_values) GMK_TRY(hipMemcpy(h_values, d_values, n * 225 * 4, hipMemcpyDeviceToHost));
+    if (h_priors) GMK_TRY(hipMemcpy(h_priors, d_priors, n * 225 * 4, hipMemcpyDeviceToHost));
+    if (h_root_visits) GMK_TRY(hipMemcpy(h_root_visits, d_root_visits, n * 4, hipMemcpyDeviceToHost));
+    if (h_root_value) GMK_TRY(hipMemcpy(h_root_value, d_root_value, n * 4, hipMemcpyDeviceToHost));
+    std::vector<AzHeader> hdr(n);
+    GMK_TRY(hipMemcpy(hdr.data(), a->t.hdr, n * sizeof(AzHeader), hipMemcpyDeviceToHost));
+#undef GMK_TRY
+    for (size_t g = 0; g < n; ++g) {
+        if (h_n_nodes) h_n_nodes[g] = static_cast<int32_t>(hdr[g].n_nodes);
+        if (h_status) h_status[g] = static_cast<int32_t>(hdr[g].status);
+    }
+    cleanup();
+    return GMK_OK;
+}

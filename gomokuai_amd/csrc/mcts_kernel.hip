@@ -25,9 +25,13 @@
 #include <vector>
 
 #include "capi_common.h"
+#include "board_device.h"
 #include "philox.h"
 
 namespace {
+
+using gmk::five_through;
+using gmk::run_of_five;
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kMaxGamesPerBlock = 16;
@@ -63,33 +67,6 @@ struct SearchParams {
 
 __constant__ float c_prior[226];          // 1.0f / float(n) evaluated on the host (MonteCarlo.hpp:50-55)
 __constant__ float c_value[129];          // float(double(sum) / double(c_rollouts)), index sum + c_rollouts (Random.h:30-33)
-
-__device__ __forceinline__ bool run_of_five(uint32_t m) { return (m & (m >> 1) & (m >> 2) & (m >> 3) & (m >> 4)) != 0; }
-
-// Five or more in a row through (x, y) for the colour in bits [shift, shift+15) of the row words
-// (Board::checkGameEnd, core/lib/src/Game.cpp:88-136).  rows[y * Stride].
-template <int Stride>
-__device__ __forceinline__ bool five_through(const uint32_t* rows, int x, int y, int shift) {
-    const uint32_t own = (rows[y * Stride] >> shift) & 0x7FFFu;
-    if (run_of_five(own)) return true;
-    uint32_t v = 16u, d1 = 16u, d2 = 16u;                       // bit 4 = the stone itself
-#pragma unroll
-    for (int i = 1; i <= 4; ++i) {
-        if (y + i < 15) {
-            const uint32_t o = ((rows[(y + i) * Stride] >> shift) & 0x7FFFu) << 4;
-            v |= ((o >> (x + 4)) & 1u) << (4 + i);
-            d1 |= ((o >> (x + i + 4)) & 1u) << (4 + i);
-            d2 |= ((o >> (x - i + 4)) & 1u) << (4 + i);
-        }
-        if (y - i >= 0) {
-            const uint32_t o = ((rows[(y - i) * Stride] >> shift) & 0x7FFFu) << 4;
-            v |= ((o >> (x + 4)) & 1u) << (4 - i);
-            d1 |= ((o >> (x - i + 4)) & 1u) << (4 - i);
-            d2 |= ((o >> (x + i + 4)) & 1u) << (4 - i);
-        }
-    }
-    return run_of_five(v) || run_of_five(d1) || run_of_five(d2);
-}
 
 // Line words of a position (the layout of K1): word = black | white << 16, bit = position along the line.
 // rows [0,15), columns [16,31), diagonals x-y+14 at [32,61), anti-diagonals x+y at [61,90).

@@ -31,6 +31,7 @@ EXPORTS = [
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
+    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_root_stats",
     "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_root_stats", "gmk_trad_read_evaluators",
 ]
 
@@ -88,6 +89,12 @@ def load():
     L.gmk_evalstate_update.argtypes = [vp, vp, C.c_int, vp]
     L.gmk_evalstate_update_host.argtypes = [vp, vp, C.c_int]
     L.gmk_evalstate_read.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.gmk_az_create.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(vp)]
+    L.gmk_az_destroy.argtypes = [vp]
+    L.gmk_az_set_roots.argtypes = [vp, vp, vp]
+    L.gmk_az_select.argtypes = [vp, vp, vp]
+    L.gmk_az_expand.argtypes = [vp, vp, vp, vp]
+    L.gmk_az_root_stats.argtypes = [vp] * 8
     L.gmk_trad_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
     L.gmk_trad_destroy.argtypes = [vp]
     L.gmk_trad_reset_evaluators.argtypes = [vp]
@@ -363,4 +370,60 @@ class TraditionalMCTS:
                "meta": np.zeros((self.n, 4), np.int32), "record": np.zeros((self.n, 228), np.uint8)}
         _check(load().gmk_trad_read_evaluators(self.h, out["scores"].ctypes.data, out["density"].ctypes.data, out["pattern_dist"].ctypes.data,
                                                out["compound_dist"].ctypes.data, out["meta"].ctypes.data, out["record"].ctypes.data))
+        return out
+
+
+# ---------------- K7: network-guided search, many games in lock step ----------------
+class AlphaZeroMCTS:
+    """n_games searches of MCTS(policy=Policy(eval_state=network.eval_state, c_puct)) (agents/alphazero.py:5-9) advancing one
+    playout per step: select() writes the leaves' feature planes into `states` (torch float32 [n, 6, 15, 15] on the GPU), the
+    caller's network maps them to (value [n], probs [n, 225]), expand() grows the trees and backs the values up."""
+
+    def __init__(self, n_games, node_capacity=1 << 16, c_puct=5.0):
+        import torch
+        init()
+        self.n = n_games
+        h = C.c_void_p()
+        _check(load().gmk_az_create(n_games, int(node_capacity), float(c_puct), C.byref(h)))
+        self.h = h
+        self.states = torch.zeros((n_games, 6, 15, 15), dtype=torch.float32, device="cuda")
+
+    def close(self):
+        if getattr(self, "h", None) and load is not None:
+            load().gmk_az_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_roots(self, planes, last_moves):
+        """planes uint16[n,2,16]; last_moves int16[n,2] = (last move, the one before), -1 where there is none."""
+        planes = np.ascontiguousarray(planes, dtype=np.uint16)
+        last_moves = np.ascontiguousarray(last_moves, dtype=np.int16)
+        assert planes.shape == (self.n, 2, 16) and last_moves.shape == (self.n, 2)
+        _check(load().gmk_az_set_roots(self.h, planes.ctypes.data, last_moves.ctypes.data))
+
+    def select(self, stream=None):
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _check(load().gmk_az_select(self.h, self.states.data_ptr(), stream))
+        return self.states
+
+    def expand(self, values, probs, stream=None):
+        import torch
+        assert values.dtype == torch.float32 and probs.dtype == torch.float32 and values.is_contiguous() and probs.is_contiguous()
+        assert values.numel() == self.n and probs.numel() == self.n * N
+        stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _check(load().gmk_az_expand(self.h, values.data_ptr(), probs.data_ptr(), stream))
+
+    def search(self, network, playouts):
+        """`playouts` lock-step playouts; network(states) -> (value [n], probs [n, 225]) on the GPU."""
+        for _ in range(playouts):
+            values, probs = network(self.select())
+            self.expand(values.contiguous(), probs.contiguous())
+
+    def root_stats(self):
+        out = {"visits": np.zeros((self.n, N), np.uint32), "values": np.zeros((self.n, N), np.float32), "priors": np.zeros((self.n, N), np.float32),
+               "root_visits": np.zeros(self.n, np.uint32), "root_value": np.zeros(self.n, np.float32),
+               "n_nodes": np.zeros(self.n, np.int32), "status": np.zeros(self.n, np.int32)}
+        _check(load().gmk_az_root_stats(self.h, *[out[k].ctypes.data for k in ("visits", "values", "priors", "root_visits", "root_value", "n_nodes", "status")]))
         return out

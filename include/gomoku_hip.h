@@ -201,6 +201,24 @@ int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float*
 int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density, uint32_t* h_pattern_dist,
                              uint32_t* h_compound_dist, int32_t* h_meta, uint8_t* h_record);
 
+/* ---- K7: network-guided tree search, many games in lock step (BASELINE.json configs[4]) ----
+ * Replaces MCTS(policy = Policy(eval_state = network.eval_state, c_puct)) (agents/alphazero.py:5-9): Default::Select
+ * (core/lib/include/algorithms/MonteCarlo.hpp:57-68), the evaluator call at a new leaf (core/lib/src/MCTS.cpp:164-168),
+ * Default::Expand with extraCheck = true (:71-80), Default::BackPropogate (:90-95).  One playout of every game =
+ * gmk_az_select (writes the leaves' Board.encoded_states planes, core/py_ext/src/game_ext.hpp:87-104, as float32
+ * [n][6][15][15]; games that are over at the leaf are backed up at once and get a zero row), the caller's network on that
+ * batch, gmk_az_expand with its value [n] and probabilities [n][225] (device pointers, same stream). */
+typedef struct gmk_az gmk_az;
+int gmk_az_create(int n_games, int node_capacity, double c_puct, gmk_az** out);
+int gmk_az_destroy(gmk_az* a);
+/* fresh roots; h_planes uint16[n][2][16] as gmk_eval_batch, h_last_moves int16[n][2] = {last move, the one before} or -1 */
+int gmk_az_set_roots(gmk_az* a, const uint16_t* h_planes, const int16_t* h_last_moves);
+int gmk_az_select(gmk_az* a, float* d_states, void* stream);
+int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_probs, void* stream);
+/* host outputs, any may be NULL; status bit 1 = node arena full (playouts of that game were dropped) */
+int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
+                      float* h_root_value, int32_t* h_n_nodes, int32_t* h_status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,8 @@ struct go_mcts {
     int      use_mt;
     go_mt19937 mt;
     float    noise_alpha, noise_epsilon;      /* alpha == 0: AddNoise disabled */
+    go_eval_state_fn eval_state;              /* Policy(eval_state = ...) (agents/alphazero.py:5-9): replaces the rollouts */
+    void    *eval_user;
 };
 
 void go__gamma_draws(unsigned seed, float alpha, int n, float *out);     /* go_stdsort.cpp */
@@ -172,6 +174,23 @@ static size_t default_expand(go_mcts *m, int32_t ni, const go_board *b) {
     return (size_t)count;
 }
 
+/* Default::Expand with the probabilities an evaluator returned and extraCheck = true (MonteCarlo.hpp:71-80): one child
+   per cell whose probability is not 0 AND which is a legal move */
+static size_t probs_expand(go_mcts *m, int32_t ni, const go_board *b, const float *probs) {
+    int first = -1, count = 0;
+    int player = -m->nodes[ni].player;
+    for (int i = 0; i < GO_N; ++i)
+        if (probs[i] != 0.0f && go_board_check_move(b, i)) {
+            int32_t c = new_node(m, ni, i, player, 0.0f, probs[i]);
+            if (first < 0) first = c;
+            ++count;
+        }
+    m->nodes[ni].first_child = first;
+    m->nodes[ni].n_children = count;
+    m->alg_bytes += (uint64_t)count * 16;
+    return (size_t)count;
+}
+
 /* Random.h:22-35 + MonteCarlo.hpp:37-47.  RNG: Philox counter = (game, playout, search<<8 | rollout, ply>>3), key = seed;
    ply p takes the 16-bit half (p&1) of word (p>>1)&3; cell draw = (half * 225) >> 16, then the probe rule (Game.cpp:68-72).
    (The KAT hook keeps the survey's recipe: id = mt19937() % 225.) */
@@ -223,8 +242,19 @@ static size_t playout(go_mcts *m, go_board *b, uint32_t idx) {
     double node_value;
     size_t expand_size;
     if (!go_board_check_end(b)) {
-        float state_value = averaged_simulate(m, b, idx);
-        expand_size = default_expand(m, ni, b);
+        float state_value;
+        if (m->eval_state) {                                     /* policy->simulate = the callback (MCTS.cpp:18-33, policy_ext / mcts_ext bindings) */
+            uint8_t states[6 * GO_N];
+            float probs[GO_N];
+            go_board_encoded_states(b, states);
+            state_value = 0.0f;
+            memset(probs, 0, sizeof probs);
+            m->eval_state(states, &state_value, probs, m->eval_user);
+            expand_size = probs_expand(m, ni, b, probs);
+        } else {
+            state_value = averaged_simulate(m, b, idx);
+            expand_size = default_expand(m, ni, b);
+        }
         node_value = -state_value;
     } else {
         expand_size = 0;
@@ -256,6 +286,7 @@ static void add_noise(go_mcts *m, const go_board *b) {
 }
 
 void go_mcts_set_noise(go_mcts *m, float alpha, float epsilon) { m->noise_alpha = alpha; m->noise_epsilon = epsilon; }
+void go_mcts_set_evaluator(go_mcts *m, go_eval_state_fn fn, void *user) { m->eval_state = fn; m->eval_user = user; }
 
 void go_mcts_run_playouts(go_mcts *m, go_board *b) {
     go_mcts_sync_with_board(m, b);

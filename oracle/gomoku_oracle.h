@@ -127,6 +127,8 @@ void go_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]
 
 /* ---------------- MCTS (MCTS.h/.cpp, MonteCarlo.hpp:13-110, Random.h:22-35) ---------------- */
 typedef struct go_mcts go_mcts;
+/* Policy(eval_state = f) (agents/alphazero.py:5-9): f(encoded states u8[6][15][15]) -> value, probs f32[225] */
+typedef void (*go_eval_state_fn)(const uint8_t *states, float *value, float *probs, void *user);
 go_mcts *go_mcts_new(uint64_t c_iterations, double c_puct, int c_rollouts,
                      uint64_t seed, uint32_t game_id);
 void go_mcts_free(go_mcts *m);
@@ -148,6 +150,8 @@ void go_mcts_root_children(const go_mcts *m, uint32_t *visits /*[225]*/, float *
 uint64_t go_mcts_alg_bytes(const go_mcts *m);
 /* Default::AddNoise at the start of every search (MCTS.cpp:182); alpha = 0 (default) disables it. */
 void go_mcts_set_noise(go_mcts *m, float alpha, float epsilon);
+/* the search then calls fn at every new leaf instead of rolling out, and expands with Default::Expand(extraCheck = true) */
+void go_mcts_set_evaluator(go_mcts *m, go_eval_state_fn fn, void *user);
 /* KAT hook: draw rollout moves sequentially from std::mt19937(seed) (id = eng() % 225) instead of Philox,
    to replay the search recorded in SURVEY.md Appendix B.2. */
 void go_mcts_use_mt19937(go_mcts *m, uint32_t seed);

@@ -44,6 +44,9 @@ class AC(C.Structure):
 _lib = None
 
 
+EVAL_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -101,6 +104,8 @@ def lib():
     L.go_trad_evaluator.restype = C.c_void_p
     L.go_trad_heuristic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.go_trad_heuristic.restype = C.c_float
+    L.go_mcts_set_evaluator.argtypes = [C.c_void_p, EVAL_FN, C.c_void_p]
+    L.go_mcts_set_evaluator.restype = None
     L.go_mcts_new.argtypes = [C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_uint32]
     L.go_mcts_new.restype = C.c_void_p
     L.go_mcts_free.argtypes = [C.c_void_p]
@@ -264,6 +269,15 @@ class MCTS:
 
     def set_noise(self, alpha, epsilon):
         self.L.go_mcts_set_noise(self.h, alpha, epsilon)
+
+    def set_evaluator(self, fn):
+        """fn(states uint8[6,15,15]) -> (value, probs float32[225]): Policy(eval_state=fn) of the reference (agents/alphazero.py:5-9)."""
+        def thunk(states, value, probs, _user):
+            v, p = fn(np.ctypeslib.as_array(states, shape=(6, 15, 15)))
+            value[0] = float(np.float32(v))
+            np.ctypeslib.as_array(probs, shape=(N,))[:] = np.asarray(p, dtype=np.float32)
+        self._eval_cb = EVAL_FN(thunk)                 # keep the callback alive
+        self.L.go_mcts_set_evaluator(self.h, self._eval_cb, None)
 
     def eval_state(self, board):
         probs = np.zeros(N, dtype=np.float32)

@@ -1,0 +1,131 @@
+"""K7 parity: the lock-step network-guided search (gmk_az_*) against the oracle's MCTS with an external evaluator
+(Policy(eval_state=f), agents/alphazero.py:5-9; Default::Select / Expand(extraCheck) / BackPropogate).  The evaluator of the
+parity test is a pure function of the feature planes that both sides compute on the host with the same numpy code, so
+the search itself is compared exactly (visit counts, value and prior bits, tree size); the real network is run end to end
+in a second test and checked against a float64 numpy forward pass with a tolerance."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gomokuai_amd import lib as G
+
+pytestmark = pytest.mark.gpu
+
+
+def surrogate(states):
+    """states uint8/float [6, 15, 15] -> (value, probs): deterministic, exactly reproducible, with zero probabilities on some
+    empty cells and non-zero ones on some occupied cells (so that both halves of Default::Expand's test matter)."""
+    s = np.asarray(states).reshape(6, 225).astype(np.int64)
+    code = s[0] * 3 + s[1] * 5 + s[3] * 7 + s[4] * 11 + s[5]
+    idx = np.arange(225, dtype=np.int64)
+    h = (int((code * (idx + 1)).sum()) * 2654435761 + idx * 40503 * (int(code.sum()) + 1)) % 65536
+    probs = ((h % 1021) + 1).astype(np.float32) / np.float32(1024.0)
+    probs[h % 7 == 0] = 0.0
+    value = np.float32((int(h.sum()) % 2001) - 1000) / np.float32(1000.0)
+    return value, probs
+
+
+def _roots(n, max_len):
+    moves, lens, _ = G.synth_boards(n, 1, first_board=500)
+    lens = np.array([min(int(lens[g]), (3 * g) % (max_len + 1)) for g in range(n)], dtype=np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.full((n, 2), -1, np.int16)
+    for g in range(n):
+        if lens[g] >= 1: last[g, 0] = moves[g, lens[g] - 1]
+        if lens[g] >= 2: last[g, 1] = moves[g, lens[g] - 2]
+    return moves, lens, planes, last
+
+
+def test_search_matches_oracle(oracle):
+    import torch
+    O = oracle
+    G.init()
+    n, playouts = 12, 160
+    moves, lens, planes, last = _roots(n, 30)
+    tree = G.AlphaZeroMCTS(n, node_capacity=1 << 16, c_puct=5.0)
+    tree.set_roots(planes, last)
+
+    def host_network(states):                                   # the batch goes to the host, through the surrogate, and back
+        s = states.cpu().numpy()
+        vp = [surrogate(s[g]) for g in range(n)]
+        return (torch.tensor([v for v, _ in vp], dtype=torch.float32, device="cuda"),
+                torch.from_numpy(np.stack([p for _, p in vp])).cuda())
+    tree.search(host_network, playouts)
+    st = tree.root_stats()
+    assert (st["status"] == 0).all()
+    for g in range(n):
+        b = O.new_board()
+        for i in range(int(lens[g])):
+            O.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        om = O.MCTS(playouts, 5.0, 5, 0, 0)
+        om.set_evaluator(surrogate)
+        om.run_playouts(b)
+        v, q, p = om.root_children()
+        np.testing.assert_array_equal(st["visits"][g], v)
+        np.testing.assert_array_equal(st["values"][g].view(np.uint32), q.view(np.uint32))
+        np.testing.assert_array_equal(st["priors"][g].view(np.uint32), p.view(np.uint32))
+        assert st["root_visits"][g] == om.root_visits and st["n_nodes"][g] == om.size
+        assert np.float32(st["root_value"][g]).view(np.uint32) == np.float32(om.root_value).view(np.uint32)
+    tree.close()
+
+
+def test_finished_games_and_full_arena():
+    import torch
+    G.init()
+    c = lambda y, x: y * 15 + x
+    won = [c(7, 7), c(0, 0), c(7, 8), c(0, 2), c(7, 9), c(0, 4), c(7, 10), c(0, 6), c(7, 11)]          # black has five: the root is terminal
+    moves = np.zeros((2, 64), np.uint8); moves[0, :9] = won; moves[1, :3] = [112, 113, 127]
+    lens = np.array([9, 3], np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    tree = G.AlphaZeroMCTS(2, node_capacity=256, c_puct=5.0)
+    tree.set_roots(planes, np.array([[won[-1], won[-2]], [127, 113]], np.int16))
+    uniform = lambda s: (torch.zeros(2, device="cuda"), torch.full((2, 225), 1.0 / 225, device="cuda"))
+    tree.search(uniform, 40)
+    st = tree.root_stats()
+    assert st["root_visits"][0] == 40 and st["root_value"][0] == 1.0 and st["n_nodes"][0] == 1        # every playout ends at the root: its player won
+    assert st["status"][1] & 2 and st["n_nodes"][1] <= 256                                             # 222 children per node: the second expansion does not fit
+    tree.close()
+
+
+def test_policy_value_network_end_to_end():
+    import torch
+    from gomokuai_amd.network import PolicyValueNetwork
+    G.init()
+    torch.manual_seed(0)
+    net = PolicyValueNetwork(seed=3).cuda().eval()
+    n, playouts = 64, 48
+    _, lens, planes, last = _roots(n, 20)
+    tree = G.AlphaZeroMCTS(n, node_capacity=1 << 15, c_puct=5.0)
+    tree.set_roots(planes, last)
+    with torch.no_grad():
+        tree.search(net, playouts)
+        st = tree.root_stats()
+        states = tree.select().clone()                          # one more batch of leaves, for the numerics check below
+        value, probs = net(states)
+    assert (st["status"] == 0).all() and (st["root_visits"] == playouts).all()
+    assert (st["visits"].sum(1) == playouts - 1).all()
+    assert ((st["priors"] > 0).sum(1) == 225 - lens).all()     # softmax never returns 0: one child per empty cell
+    assert float(probs.sum(1).sub(1).abs().max()) < 1e-5 and float(value.abs().max()) <= 1.0
+    # float64 numpy forward pass of the same weights (model_tf.py:28-66) on a few rows
+    w = {k: v.detach().cpu().double().numpy() for k, v in net.state_dict().items()}
+    x = states[:4].cpu().double().numpy()
+
+    def conv(x, wt, b):                                         # 'same' convolution, NCHW
+        k = wt.shape[2]
+        xp = np.pad(x, ((0, 0), (0, 0), (k // 2, k // 2), (k // 2, k // 2)))
+        out = np.zeros((x.shape[0], wt.shape[0], 15, 15))
+        for dy in range(k):
+            for dx in range(k):
+                out += np.einsum("bchw,oc->bohw", xp[:, :, dy:dy + 15, dx:dx + 15], wt[:, :, dy, dx])
+        return out + b[None, :, None, None]
+    for i in range(3):
+        x = np.maximum(conv(x, w["conv.%d.weight" % i], w["conv.%d.bias" % i]), 0)
+    p = np.maximum(conv(x, w["policy_conv.weight"], w["policy_conv.bias"]), 0).transpose(0, 2, 3, 1).reshape(4, -1)
+    logits = p @ w["policy_dense.weight"].T + w["policy_dense.bias"]
+    ref_probs = np.exp(logits - logits.max(1, keepdims=True)); ref_probs /= ref_probs.sum(1, keepdims=True)
+    v = np.maximum(conv(x, w["value_conv.weight"], w["value_conv.bias"]), 0).transpose(0, 2, 3, 1).reshape(4, -1)
+    ref_value = np.tanh(np.maximum(v @ w["value_hidden.weight"].T + w["value_hidden.bias"], 0) @ w["value_out.weight"].T + w["value_out.bias"]).reshape(-1)
+    assert np.abs(probs[:4].cpu().numpy() - ref_probs).max() < 1e-4      # float32 convolutions vs float64: tolerance
+    assert np.abs(value[:4].cpu().numpy() - ref_value).max() < 1e-4
+    tree.close()
