@@ -116,6 +116,57 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, bool((status & 2).any()))
 
 
+def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
+                          device=None, node_capacity=None):
+    """n_games complete games of the reference's self-play SUPERVISOR against itself (config.py:9-12: "traditional_mcts",
+    MCTS(TraditionalPolicy) on both sides), all games side by side on the current GPU: every move = one K6 search of
+    `playouts` playouts per unfinished game (fresh root, the games' evaluators are kept and synchronised like the
+    policy objects of the reference), then MCTS::stepForward's choice is played.  The search is deterministic; variety
+    comes from the openings (synthetic generator, `opening_plies` plies of game first_game_id + g).  Returns the same
+    GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
+    from . import core
+    G.init(torch.cuda.current_device() if device is None else device.index)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    moves = np.zeros((n_games, N), dtype=np.uint8)
+    lens = np.zeros(n_games, dtype=np.int32)
+    boards = [core.Board() for _ in range(n_games)]           # host boards: legality and Board::checkGameEnd (Game.cpp:88-136)
+    if opening_plies > 0:
+        m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+        for g in range(n_games):
+            for i in range(min(int(l[g]), opening_plies)):
+                boards[g].apply_move(core.Position(int(m[g, i])))
+                moves[g, i] = m[g, i]
+            lens[g] = min(int(l[g]), opening_plies)
+    visits = np.zeros((n_games, N, N), dtype=np.uint16)
+    over = np.array([b.status["is_end"] for b in boards], dtype=bool)
+    tree = G.TraditionalMCTS(n_games, node_capacity=node_capacity if node_capacity is not None else min(playouts * 226 + 1, (1 << 24) - 1), c_puct=c_puct)
+    overflow = False
+    for _ in range(max_moves):
+        if over.all():
+            break
+        tree.set_positions([moves[g, :lens[g]] for g in range(n_games)])
+        tree.run(playouts, stream)
+        st = tree.root_stats()
+        overflow |= bool((st["status"] & 1).any())
+        for g in range(n_games):
+            if over[g]:
+                continue
+            best = int(st["best"][g])
+            if best < 0:                                    # no child: nothing the policy wants to play (cannot happen on a live board)
+                over[g] = True
+                continue
+            visits[g, lens[g]] = np.minimum(st["visits"][g], 65535)
+            boards[g].apply_move(core.Position(best))
+            moves[g, lens[g]] = best
+            lens[g] += 1
+            over[g] = boards[g].status["is_end"]
+    tree.close()
+    winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
+    return GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),
+                       torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
+
+
 def gather_records(rec, dst=0, group=None):
     """The exchange step: every rank contributes its fixed-stride records, rank `dst` receives the concatenation in
     rank order (= global game id order).  Works on any torch.distributed backend; with world size 1 it is the identity."""

@@ -125,3 +125,24 @@ def test_device_samples_match_host_and_augmentation():
     ref = agents.augment_game_data([(states[i], values[i], pi[i]) for i in range(k)])
     for i, (st, val, p) in enumerate(ref):
         assert (a_states[i] == st).all() and a_values[i] == val and (a_pi[i] == p).all()
+
+
+def test_supervisor_self_play(oracle):
+    """Complete games of the pattern-guided supervisor against itself (K6 per move): the records replay to the recorded
+    winner on the oracle's board, are reproducible, and turn into training tuples on the device."""
+    import ctypes as C
+    from gomokuai_amd import selfplay
+    rec = selfplay.play_supervisor_games(6, 80, opening_plies=3, first_game_id=11)
+    again = selfplay.play_supervisor_games(6, 80, opening_plies=3, first_game_id=11)
+    assert not rec.overflow and (rec.moves.cpu() == again.moves.cpu()).all() and (rec.winner.cpu() == again.winner.cpu()).all()
+    r = rec.cpu()
+    for g in range(len(rec)):
+        b = oracle.new_board()
+        L = int(r.lens[g])
+        for i in range(L):
+            assert oracle.lib().go_board_check_move(C.byref(b), int(r.moves[g, i]))
+            oracle.lib().go_board_apply(C.byref(b), int(r.moves[g, i]), 1)
+        assert b.cur_player == 0 and b.winner == int(r.winner[g])          # the game ended exactly with the last recorded move
+        assert L >= 9
+    states, values, pi = rec.to_samples(first_move=3)
+    assert states.shape[0] == int((r.lens - 3).sum()) and float(pi.sum(1).sub(1).abs().max()) < 1e-3
