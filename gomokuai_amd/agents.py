@@ -2,9 +2,13 @@
 agents/mcts.py:5-34 and agents/utils.py:5-63 (same names, arguments and return shapes), on top of the
 MI355X CorePyExt.  Written for this repo; the reference's own files run unchanged on the same module
 (see tests/test_pyext.py and INTEGRATION.md)."""
+import json
+import os
+from subprocess import PIPE, Popen
+
 import numpy as np
 
-from .core import Board, GameConfig as Game, MCTS, Player, RandomPolicy, TraditionalPolicy
+from .core import Board, GameConfig as Game, MCTS, Player, Position, RandomPolicy, TraditionalPolicy
 
 
 class Agent:
@@ -79,6 +83,63 @@ def dual_play(agents, board=None, verbose=False):
             if verbose:
                 return [(s[0], np.array(Player.calc_score(s[1], winner)), s[2]) for s in result]
             return winner
+
+
+def eval_agents(agents, num_games=9, verbose=False):
+    """agents/utils.py:66-103: win rates of two agents over num_games games, colours swapped every game, a tie counts half."""
+    board = Board()
+    players = [Player.black, Player.white]
+    win_cnts = np.zeros(2)
+    for i in range(num_games):
+        winner = dual_play(dict(zip(players, agents)), board)
+        if winner in players:
+            win_cnts[players.index(winner)] += 1
+        else:
+            win_cnts += 0.5
+        if verbose:
+            print("Round {} ends, winner is {};".format(i + 1, winner))
+        players.reverse()
+        board.reset()
+        for agent in agents:
+            agent.reset()
+    return tuple(win_cnts / num_games)
+
+
+class BotzoneAgent(Agent):
+    """agents/botzone.py:11-45: an external Botzone-protocol program as an agent.  The position goes to the program's
+    stdin as {"requests": [...], "responses": [...]} (the opponent's moves and its own, {"x": -1, "y": -1} first when it
+    plays black), its stdout answers {"response": {"x": .., "y": ..}}."""
+
+    def __init__(self, program, keep_alive=False, working_dir="."):
+        self.program = program
+        self.working_dir = os.path.realpath(working_dir)
+        self.keep_alive = keep_alive
+
+    def get_action(self, state):
+        return self._communicate(state)
+
+    def eval_state(self, state):
+        action = self._communicate(state)
+        action_probs = np.zeros(Game["board_size"])
+        action_probs[int(action)] = 1.0
+        return 0.0, action_probs, action
+
+    @staticmethod
+    def _parse_state(state):
+        record = [{"x": p.x, "y": p.y} for p in state.move_record]
+        offset = len(record) % 2
+        padding = [{"x": -1, "y": -1}] * (1 - offset)
+        return json.dumps({"requests": padding + record[1 - offset::2], "responses": record[offset::2]})
+
+    def _communicate(self, state):
+        bot = Popen(self.program, shell=True, stdin=PIPE, cwd=self.working_dir, stdout=PIPE, universal_newlines=True)
+        output, _ = bot.communicate(self._parse_state(state))
+        bot.terminate()
+        response = json.loads(output)["response"]
+        return Position(response["x"], response["y"])
+
+    def __repr__(self):
+        return "Botzone Agent at <{}/{}>".format(self.working_dir, self.program)
 
 
 def augment_game_data(data):

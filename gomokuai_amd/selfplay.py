@@ -6,6 +6,8 @@ Replaces the reference's data generation loop -- `network/data_helper.py:58-83` 
 GPU (K3 + `gmk_mcts_advance`) sharded over ranks by global game id, and ONE gather of the compact records
 (moves, per-move root visit counts, winner) to rank 0 over `torch.distributed` (RCCL on MI355X, gloo on CPU).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -165,6 +167,40 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
     winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
     return GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),
                        torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
+
+
+def dump_batches(samples, path, batch_size=512):
+    """The reference appends mini-batches to `latest.train.hdf5` as three growing datasets `state_batch`, `value_batch`,
+    `probs_batch` of shape (batches, batch_size, ...) (network/data_helper.py:176-194).  h5py is written when it can be
+    imported; otherwise the same three arrays go to `<path>.npz` (numpy's archive), with the same names and shapes.
+    `samples` = (states, values, pi) as GameRecords.to_samples() returns them; a trailing partial batch is dropped like
+    the reference's generator does.  Returns the number of batches written."""
+    states, values, pi = (t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t) for t in samples)
+    n_batches = states.shape[0] // batch_size
+    if n_batches == 0:
+        return 0
+    cut = n_batches * batch_size
+    arrays = {"state_batch": states[:cut].reshape(n_batches, batch_size, *states.shape[1:]).astype(np.float32),
+              "value_batch": values[:cut].reshape(n_batches, batch_size).astype(np.float32),
+              "probs_batch": pi[:cut].reshape(n_batches, batch_size, pi.shape[1]).astype(np.float32)}
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None and not path.endswith(".npz"):
+        with h5py.File(path, "a") as hf:
+            for name, arr in arrays.items():
+                if name not in hf:
+                    hf.create_dataset(name, (0, *arr.shape[1:]), maxshape=(None, *arr.shape[1:]))
+                hf[name].resize(hf[name].shape[0] + arr.shape[0], axis=0)
+                hf[name][-arr.shape[0]:] = arr
+    else:
+        path = path if path.endswith(".npz") else path + ".npz"
+        if os.path.exists(path):
+            with np.load(path) as old:
+                arrays = {name: np.concatenate([old[name], arr]) for name, arr in arrays.items()}
+        np.savez(path, **arrays)
+    return n_batches
 
 
 def gather_records(rec, dst=0, group=None):

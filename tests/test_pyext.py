@@ -4,6 +4,7 @@ against the oracle.  In this container only: the REFERENCE's own agents/utils.py
 imported from /root/reference and played on top of the module (they never travel to the GPU box)."""
 import ctypes as C
 import datetime
+import json
 import os
 import sys
 
@@ -157,3 +158,38 @@ def test_reference_agents_run_unchanged_on_this_module():
                 sys.modules.pop(k)
         sys.modules.update(saved)
         sys.path.remove("/root/reference")
+
+
+def test_botzone_agent_and_eval_agents(tmp_path):
+    """agents/botzone.py:11-45 and agents/utils.py:66-103 on the host module: an external program speaking the Botzone
+    JSON protocol plays against the random agent."""
+    from gomokuai_amd import agents
+    bot = tmp_path / "bot.py"
+    bot.write_text(
+        "import json, sys\n"
+        "d = json.loads(sys.stdin.read())\n"
+        "taken = {(m['x'], m['y']) for m in d['requests'] + d['responses']}\n"
+        "x, y = next((x, y) for y in range(15) for x in range(15) if (x, y) not in taken)\n"
+        "print(json.dumps({'response': {'x': x, 'y': y}}))\n")
+    agent = agents.BotzoneAgent("python3 bot.py", working_dir=str(tmp_path))
+    b = core.Board()
+    assert json.loads(agents.BotzoneAgent._parse_state(b)) == {"requests": [{"x": -1, "y": -1}], "responses": []}
+    mv = agent.get_action(b)
+    assert (mv.x, mv.y) == (0, 0)
+    b.apply_move(mv); b.apply_move(core.Position(7, 7))
+    q, probs, mv2 = agent.eval_state(b)
+    assert (mv2.x, mv2.y) == (1, 0) and probs[int(mv2)] == 1.0 and probs.sum() == 1.0
+    rates = agents.eval_agents([agent, agents.RandomAgent()], num_games=2)
+    assert abs(sum(rates) - 1.0) < 1e-9
+
+
+def test_dump_batches(tmp_path):
+    from gomokuai_amd import selfplay
+    rng = np.random.RandomState(1)
+    samples = (rng.randint(0, 2, size=(70, 6, 15, 15)).astype(np.uint8), rng.rand(70).astype(np.float32), rng.rand(70, 225).astype(np.float32))
+    path = str(tmp_path / "latest.train.npz")
+    assert selfplay.dump_batches(samples, path, batch_size=32) == 2
+    assert selfplay.dump_batches(samples, path, batch_size=32) == 2
+    with np.load(path) as f:
+        assert f["state_batch"].shape == (4, 32, 6, 15, 15) and f["value_batch"].shape == (4, 32) and f["probs_batch"].shape == (4, 32, 225)
+        assert (f["state_batch"][2] == samples[0][:32]).all()
