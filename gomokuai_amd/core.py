@@ -14,7 +14,7 @@ try:
     from CorePyExt import GameConfig, Player, Position, Board  # noqa: E402,F401
     from CorePyExt import Node, Policy, MCTS  # noqa: E402,F401
     from CorePyExt import RandomPolicy, PoolRAVEPolicy, TraditionalPolicy  # noqa: E402,F401
-    from CorePyExt import set_seed  # noqa: E402,F401  (extension: reproducible searches)
+    from CorePyExt import set_seed, set_root_noise  # noqa: E402,F401  (extensions: reproducible searches, AddNoise parameters)
 except ImportError as exc:              # fail loudly: there is no pure-Python stand-in
     raise ImportError("CorePyExt (MI355X build) is not built: run `python -m gomokuai_amd.build`") from exc
 

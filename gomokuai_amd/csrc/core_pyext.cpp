@@ -58,6 +58,8 @@ std::mt19937& rng() {                                   // reference: random_dev
 }
 uint64_t g_search_seed = (static_cast<uint64_t>(std::random_device()()) << 32) | std::random_device()();
 uint32_t g_next_game_id = 0;
+// Default::AddNoise(m_root) runs at the start of every search with these defaults (MCTS.cpp:182, MonteCarlo.hpp:97); alpha 0 switches it off
+float g_root_noise_alpha = 0.05f, g_root_noise_epsilon = 0.25f;
 
 // ---- Board: same observable behaviour as Gomoku::Board (core/lib/src/Game.cpp:37-146) ----
 class Board {
@@ -238,7 +240,7 @@ public:
         i = (i == board.record_.size()) ? 0 : i + 1;
         for (; i < board.record_.size(); ++i) step_forward(board.record_[i]);
     }
-    void reset() { init(Position(-1), Player::White); }
+    void reset() { init(Position(-1), Player::White); device_valid_ = false; }
 
     std::shared_ptr<Policy> policy_;
     std::shared_ptr<Node> root_;
@@ -253,8 +255,32 @@ private:
         game_id_ = g_next_game_id++;
     }
 
-    // MCTS::runPlayouts (MCTS.cpp:179-198).  Each call searches the current position from a fresh device
-    // tree (subtree reuse across moves is not carried to the device yet: DESIGN.md, "what comes next").
+    // Device-side bookkeeping of the RandomPolicy tree.  The tree lives on the GPU across calls, like the reference's
+    // m_root: MCTS::syncWithBoard / stepForward(move) (MCTS.cpp:119-147) become gmk_mcts_step with the subtree kept, and
+    // every search starts with Default::AddNoise on the root's children (MCTS.cpp:182; a no-op on a childless root).
+    void device_fresh_root(Board& board) {
+        uint16_t planes[32];
+        board.planes(planes);
+        const int16_t last = board.record_.empty() ? -1 : board.record_.back().id;
+        throw_gmk(gmk_mcts_set_roots(handle_, planes, &last, game_id_));
+        device_record_.assign(board.record_.begin(), board.record_.end());
+    }
+
+    // brings the device tree's root to the board's position: steps through the moves played since the last search when
+    // the board continues that game, otherwise starts a fresh tree
+    void device_sync(Board& board) {
+        const size_t have = device_record_.size(), want = board.record_.size();
+        bool continues = device_valid_ && have <= want;
+        for (size_t i = 0; continues && i < have; ++i) continues = device_record_[i] == board.record_[i];
+        if (!continues) { device_fresh_root(board); device_valid_ = true; return; }
+        for (size_t i = have; i < want; ++i) {
+            const int16_t mv = board.record_[i].id;
+            throw_gmk(gmk_mcts_step_host(handle_, &mv, 1));
+            device_record_.push_back(board.record_[i]);
+        }
+    }
+
+    // MCTS::runPlayouts (MCTS.cpp:179-198)
     void run_playouts(Board& board) {
         const auto start = std::chrono::system_clock::now();
         auto* random = dynamic_cast<RandomPolicy*>(policy_.get());
@@ -267,21 +293,22 @@ private:
         sync_with_board(board);
         policy_->prepare(board);
         const int chunk = by_iterations_ ? static_cast<int>(iterations_) : 256;
-        const int capacity = by_iterations_ ? chunk * kN + 1 : (1 << 22);
+        // room for the kept subtree (at most everything the previous searches grew) plus this search
+        const int capacity = by_iterations_ ? 3 * chunk * kN + 1 : (1 << 22);
         if (!handle_ || capacity_ != capacity || c_rollouts_ != random->c_rollouts || c_puct_ != random->c_puct) {
             if (handle_) gmk_mcts_destroy(handle_);
             handle_ = nullptr;
             throw_gmk(gmk_mcts_create(1, capacity, random->c_puct, static_cast<int>(random->c_rollouts), g_search_seed, &handle_));
             capacity_ = capacity; c_rollouts_ = random->c_rollouts; c_puct_ = random->c_puct;
+            device_valid_ = false;
         }
-        uint16_t planes[32];
-        board.planes(planes);
-        const int16_t last = board.record_.empty() ? -1 : board.record_.back().id;
-        throw_gmk(gmk_mcts_set_roots(handle_, planes, &last, game_id_));
-        uint32_t root_visits = 0, nodes = 1;
+        device_sync(board);
+        if (g_root_noise_alpha > 0.0f) throw_gmk(gmk_mcts_add_root_noise(handle_, g_root_noise_alpha, g_root_noise_epsilon, nullptr));
+        uint32_t root_visits = 0, nodes = 1, nodes_before = 1;
         float q = 0.0f;
         int32_t status = 0;
         visits_.assign(kN, 0);
+        throw_gmk(gmk_mcts_root_stats(handle_, visits_.data(), &q, &root_visits, &nodes_before, &status));     // the kept subtree
         if (by_iterations_) {
             throw_gmk(gmk_mcts_run(handle_, chunk, nullptr));
             throw_gmk(gmk_mcts_root_stats(handle_, visits_.data(), &q, &root_visits, &nodes, &status));
@@ -309,7 +336,7 @@ private:
                     c->node_visits = visits_[i];
                     root_->children.push_back(c);
                 }
-        size_ = nodes;
+        size_ += nodes - nodes_before;                              // m_size only ever grows (MCTS.cpp:189, 194)
         policy_->cleanup(board);
     }
 
@@ -369,6 +396,8 @@ private:
     }
 
     gmk_mcts* handle_ = nullptr;
+    std::vector<Position> device_record_;                           // the moves that lead to the device tree's root
+    bool device_valid_ = false;
     gmk_trad* trad_handle_ = nullptr;
     int trad_capacity_ = 0, best_in_order_ = -1;
     int capacity_ = 0;
@@ -386,6 +415,8 @@ PYBIND11_MODULE(CorePyExt, mod) {
 
     mod.add_object("GameConfig", py::dict("width"_a = kW, "height"_a = kH, "board_size"_a = kN, "max_renju"_a = kRenju));
     // extension: make searches reproducible (the reference seeds from random_device and has no such hook)
+    mod.def("set_root_noise", [](float alpha, float epsilon) { g_root_noise_alpha = alpha; g_root_noise_epsilon = epsilon; }, "alpha"_a = 0.05f, "epsilon"_a = 0.25f,
+            "MI355X build only: the Dirichlet noise Default::AddNoise mixes into the root priors before every search (alpha 0 = none)");
     mod.def("set_seed", [](uint64_t seed) { g_search_seed = seed; g_next_game_id = 0; rng().seed(static_cast<uint32_t>(seed)); }, "seed"_a);
 
     py::enum_<Player>(mod, "Player", "Gomoku player types")

@@ -391,14 +391,19 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
                          uint32_t* __restrict__ parent, uint2* __restrict__ stats2, uint32_t* __restrict__ link2,
                          uint32_t* __restrict__ parent2, size_t cap, int n_games,
                          uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
-                         int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse) {
+                         int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse,
+                         const int16_t* __restrict__ forced /* null, or per game: the move to step to (MCTS::stepForward(move)), -1 = the most visited child */) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= n_games) return;
     GameHeader& hdr = headers[g];
     const size_t base = static_cast<size_t>(g) * cap;
     const uint32_t root = hdr.root, stones = hdr.stones;
     const uint32_t first = link[base + root] >> 8;
-    if ((hdr.status & 1u) || !first) {                              // already over, or never searched: nothing to play
+    const int want = forced ? forced[g] : -1;
+    const uint32_t row_want = (want >= 0 && want < 225) ? hdr.rows[want / 15] >> (want % 15) : 0x10001u;
+    const bool can_force = want >= 0 && want < 225 && !(row_want & 0x10001u);
+    if (want >= 0 && !can_force && lane == 0) hdr.status |= 4u;     // the move is not legal on the root position: nothing is played
+    if ((hdr.status & 1u) || (!first && !can_force) || (want >= 0 && !can_force)) {     // already over, never searched, or an illegal request: nothing to play
         if (reuse && lane == 0) {                                   // the live arena flips for every game: carry the root over
             stats2[base] = stats[base + root];
             link2[base] = link[base + root] & 0xFFu;
@@ -411,25 +416,30 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
     const int n_child = 225 - static_cast<int>(stones);
     long long best = -1;
     int best_i = 0;
-    for (int i = lane; i < n_child; i += 64) {
-        const long long v = stats[base + first + i].x;
-        if (v > best) { best = v; best_i = i; }                      // std::max_element: first maximum
-    }
+    if (first) {
+        for (int i = lane; i < n_child; i += 64) {
+            // stepForward(): std::max_element, the first maximum; stepForward(move): the child of that move
+            const long long v = can_force ? ((link[base + first + i] & 0xFFu) == static_cast<uint32_t>(want) ? 1 : 0) : static_cast<long long>(stats[base + first + i].x);
+            if (v > best) { best = v; best_i = i; }
+        }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const long long o = __shfl_xor(best, m, 64);
-        const int oi = __shfl_xor(best_i, m, 64);
-        if (o > best || (o == best && oi < best_i)) { best = o; best_i = oi; }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const long long o = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(best_i, m, 64);
+            if (o > best || (o == best && oi < best_i)) { best = o; best_i = oi; }
+        }
     }
     const uint32_t child = first + static_cast<uint32_t>(best_i);
-    const uint32_t cell = link[base + child] & 0xFFu;
+    const uint32_t cell = first ? (link[base + child] & 0xFFu) : static_cast<uint32_t>(want);
+    const bool keep = reuse && first;                               // an unexpanded root has no subtree to keep (MCTS.cpp:140-145 creates a node)
     const int len = rec_lens[g];
     if (rec_visits) {
         uint16_t* rv = rec_visits + (static_cast<size_t>(g) * 225 + static_cast<size_t>(len)) * 225;
         for (int i = lane; i < 225; i += 64) rv[i] = 0;
         __syncthreads();
-        for (int i = lane; i < n_child; i += 64)
-            rv[link[base + first + i] & 0xFFu] = static_cast<uint16_t>(min(stats[base + first + i].x, 65535u));
+        if (first)
+            for (int i = lane; i < n_child; i += 64)
+                rv[link[base + first + i] & 0xFFu] = static_cast<uint16_t>(min(stats[base + first + i].x, 65535u));
     }
     __syncthreads();
     if (lane == 0) {
@@ -449,15 +459,15 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
         }
         hdr.playouts_done = 0;
         hdr.noise = 0;
-        if (!reuse) {                                               // MCTS::reset + syncWithBoard: a fresh one-node tree
+        if (!keep) {                                                // MCTS::reset + syncWithBoard: a fresh one-node tree
             hdr.root = 0;
             hdr.n_nodes = 1;
-            stats[base] = make_uint2(0u, 0u);
-            link[base] = cell;
-            parent[base] = kNone;
+            (reuse ? stats2 : stats)[base] = make_uint2(0u, 0u);    // with reuse the live arena flips for every game
+            (reuse ? link2 : link)[base] = cell;
+            (reuse ? parent2 : parent)[base] = kNone;
         }
     }
-    if (!reuse) return;
+    if (!keep) return;
 
     // The subtree of the move becomes the tree (updateRoot, MCTS.cpp:63-67); the reference frees the siblings, here
     // the kept subtree is copied level by level into the other arena so that node indices stay dense.  In the new
@@ -540,6 +550,7 @@ struct gmk_mcts {
     uint32_t* d_link2 = nullptr;
     uint32_t* d_parent2 = nullptr;
     float* d_root_prior = nullptr;     // [n_games][225] by child index, used while GameHeader::noise is set
+    void* d_step_scratch = nullptr;    // record outputs of gmk_mcts_step_host
     hipStream_t last_stream = nullptr;
 };
 
@@ -579,7 +590,7 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
 extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     if (!m) return GMK_OK;
     (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent);
-    (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2); (void)hipFree(m->d_root_prior);
+    (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2); (void)hipFree(m->d_root_prior); (void)hipFree(m->d_step_scratch);
     delete m;
     return GMK_OK;
 }
@@ -628,29 +639,58 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     return GMK_OK;
 }
 
+extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner,
+                             int32_t* d_unfinished, int reuse_subtree, void* stream);
+
 extern "C" int gmk_mcts_advance(gmk_mcts* m, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner,
                                 int32_t* d_unfinished, int reuse_subtree, void* stream) {
-    if (!m || !d_moves || !d_lens || !d_winner || !d_unfinished) { gmk::set_error("gmk_mcts_advance: bad arguments"); return GMK_ERR_ARG; }
+    return gmk_mcts_step(m, nullptr, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, stream);
+}
+
+extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner,
+                             int32_t* d_unfinished, int reuse_subtree, void* stream) {
+    if (!m || !d_moves || !d_lens || !d_winner || !d_unfinished) { gmk::set_error("gmk_mcts_step: bad arguments"); return GMK_ERR_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     m->last_stream = s;
     if (reuse_subtree && !m->d_stats2) {
         const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
         if (hipMalloc(&m->d_stats2, nodes * sizeof(uint2)) != hipSuccess || hipMalloc(&m->d_link2, nodes * 4) != hipSuccess ||
             hipMalloc(&m->d_parent2, nodes * 4) != hipSuccess) {
-            gmk::set_error("gmk_mcts_advance: hipMalloc of the second arena (%zu nodes) failed", nodes);
+            gmk::set_error("gmk_mcts_step: hipMalloc of the second arena (%zu nodes) failed", nodes);
             return GMK_ERR_HIP;
         }
     }
     GMK_HIP_CHECK(hipMemsetAsync(d_unfinished, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(mcts_advance_kernel, dim3(m->n_games), dim3(64), 0, s, m->d_headers, m->d_stats, m->d_link, m->d_parent,
                        m->d_stats2, m->d_link2, m->d_parent2, static_cast<size_t>(m->node_capacity), m->n_games,
-                       d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree);
+                       d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, d_forced_moves);
     GMK_HIP_CHECK(hipGetLastError());
     if (reuse_subtree) {                                            // the copy is the live tree from here on
         std::swap(m->d_stats, m->d_stats2);
         std::swap(m->d_link, m->d_link2);
         std::swap(m->d_parent, m->d_parent2);
     }
+    return GMK_OK;
+}
+
+// gmk_mcts_step for callers without device buffers of their own (the one-game searcher behind CorePyExt): the moves
+// come from the host, the record outputs go to scratch buffers owned by the handle.
+extern "C" int gmk_mcts_step_host(gmk_mcts* m, const int16_t* h_moves, int reuse_subtree) {
+    if (!m || !h_moves) { gmk::set_error("gmk_mcts_step_host: bad arguments"); return GMK_ERR_ARG; }
+    const size_t n = static_cast<size_t>(m->n_games);
+    if (!m->d_step_scratch) GMK_HIP_CHECK(hipMalloc(&m->d_step_scratch, n * (225 + 4 + 2 + 1) + 64));
+    uint8_t* base = static_cast<uint8_t*>(m->d_step_scratch);
+    int32_t* d_lens = reinterpret_cast<int32_t*>(base);
+    int32_t* d_unfinished = reinterpret_cast<int32_t*>(base + n * 4);
+    int16_t* d_forced = reinterpret_cast<int16_t*>(base + n * 4 + 16);
+    int8_t* d_winner = reinterpret_cast<int8_t*>(base + n * 4 + 16 + n * 2);
+    uint8_t* d_moves = base + n * 4 + 16 + n * 2 + ((n + 15) & ~size_t(15));
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    GMK_HIP_CHECK(hipMemset(d_lens, 0, n * 4));
+    GMK_HIP_CHECK(hipMemcpy(d_forced, h_moves, n * sizeof(int16_t), hipMemcpyHostToDevice));
+    const int rc = gmk_mcts_step(m, d_forced, d_moves, nullptr, d_lens, d_winner, d_unfinished, reuse_subtree, nullptr);
+    if (rc != GMK_OK) return rc;
+    GMK_HIP_CHECK(hipDeviceSynchronize());
     return GMK_OK;
 }
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
-    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
+    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
     "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_root_stats",
     "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_root_stats", "gmk_trad_read_evaluators",
@@ -82,6 +82,8 @@ def load():
     L.gmk_mcts_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gmk_visits_to_pi.argtypes = [vp, C.c_int, vp]
     L.gmk_mcts_advance.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.gmk_mcts_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.gmk_mcts_step_host.argtypes = [vp, vp, C.c_int]
     L.gmk_mcts_add_root_noise.argtypes = [vp, C.c_float, C.c_float, vp]
     L.gmk_evalstate_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.gmk_evalstate_destroy.argtypes = [vp]
@@ -254,6 +256,10 @@ class BatchedMCTS:
     def advance(self, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree=False, stream=None):
         """One self-play move for every unfinished game (device pointers as ints)."""
         _check(load().gmk_mcts_advance(self.h, d_moves, d_visits, d_lens, d_winner, d_unfinished, int(reuse_subtree), stream))
+
+    def step(self, d_forced_moves, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree=False, stream=None):
+        """MCTS::stepForward(move) per game: d_forced_moves int16[n] on the device, -1 = the most visited child."""
+        _check(load().gmk_mcts_step(self.h, d_forced_moves, d_moves, d_visits, d_lens, d_winner, d_unfinished, int(reuse_subtree), stream))
 
     def add_root_noise(self, alpha=0.05, epsilon=0.25, stream=None):
         _check(load().gmk_mcts_add_root_noise(self.h, alpha, epsilon, stream))

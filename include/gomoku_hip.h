@@ -149,6 +149,14 @@ int gmk_mcts_run(gmk_mcts *m, int playouts, void *stream);
  * Finished games are skipped by later gmk_mcts_run calls. */
 int gmk_mcts_advance(gmk_mcts *m, uint8_t *d_moves, uint16_t *d_visits, int32_t *d_lens, int8_t *d_winner,
                      int32_t *d_unfinished, int reuse_subtree, void *stream);
+/* The same step with the move given: MCTS::stepForward(next_move) (core/lib/src/MCTS.cpp:136-147), e.g. the opponent's
+ * reply.  d_forced_moves int16[n] (device): the cell to step to, or -1 for the most visited child (= gmk_mcts_advance).
+ * A root that was never expanded simply moves on; with reuse_subtree the child's subtree is kept.  An illegal cell
+ * sets status bit 2 of that game and plays nothing. */
+int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens,
+                  int8_t* d_winner, int32_t* d_unfinished, int reuse_subtree, void* stream);
+/* the same from host memory, synchronous, without game records: h_moves int16[n] */
+int gmk_mcts_step_host(gmk_mcts* m, const int16_t* h_moves, int reuse_subtree);
 /* Default::AddNoise (MonteCarlo.hpp:97-108, Statistical.hpp:29-34) on every unfinished game whose root has children:
  * P <- (1-epsilon) P + epsilon * normalized(gamma(alpha,1)); the reference calls it at the start of every runPlayouts
  * (MCTS.cpp:182) with alpha 0.05, epsilon 0.25.  No-op for childless (fresh) roots.  The priors stay in force until the

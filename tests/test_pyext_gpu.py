@@ -87,3 +87,37 @@ def test_traditional_agent_plays_a_game():
     assert len(data) >= 9 and data[0][0][2].sum() == 225
     with pytest.raises(RuntimeError):
         agents.TraditionalAgent(5.0, use_rave=True, c_iterations=10).get_action(core.Board())
+
+
+def test_agent_loop_keeps_the_tree_and_adds_root_noise(oracle):
+    """The reference's MCTSAgent keeps its tree from move to move (syncWithBoard / stepForward, MCTS.cpp:119-147) and mixes
+    Dirichlet noise into the root priors before every search (MCTS.cpp:182).  CorePyExt.MCTS does both on the device; the
+    oracle's MCTS object, driven the same way with the same seeds, sees the same visit counts move after move."""
+    O = oracle
+    core.set_seed(2024)
+    core.set_root_noise(0.05, 0.25)
+    m = core.MCTS(c_iterations=150, policy=core.RandomPolicy(5.0, 5))
+    om = O.MCTS(150, 5.0, 5, 2024, 0)
+    om.set_noise(0.05, 0.25)
+    b, ob = core.Board(), O.new_board()
+    for mv in (112, 113):
+        b.apply_move(core.Position(mv)); O.lib().go_board_apply(C.byref(ob), mv, 1)
+    sizes = []
+    for ply in range(6):
+        q, pi = m.eval_state(b)
+        oq, opi, ovisits = om.eval_state(ob)
+        assert np.float32(q).tobytes() == np.float32(oq).tobytes(), "move %d" % ply
+        assert [c.node_visits for c in m.root.children] == [int(v) for i, v in enumerate(ovisits) if ob.states[1][i]], "move %d" % ply
+        assert m.size == om.size
+        sizes.append(int(m.root.node_visits))
+        m.step_forward()
+        assert m.root.position.id == om.step_forward()
+        b.apply_move(m.root.position)
+        O.lib().go_board_apply(C.byref(ob), m.root.position.id, 1)
+        if b.status["is_end"]:
+            break
+    assert max(sizes[1:]) > 150                         # the kept subtree brings visits along: more than one search's worth at the root
+    # an unrelated position starts a fresh tree
+    b2 = core.Board(); b2.apply_move(core.Position(0))
+    m.eval_state(b2)
+    assert m.root.node_visits == 150
