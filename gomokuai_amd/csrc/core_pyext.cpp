@@ -240,7 +240,7 @@ public:
         i = (i == board.record_.size()) ? 0 : i + 1;
         for (; i < board.record_.size(); ++i) step_forward(board.record_[i]);
     }
-    void reset() { init(Position(-1), Player::White); device_valid_ = false; }
+    void reset() { init(Position(-1), Player::White); device_valid_ = false; trad_valid_ = false; }
 
     std::shared_ptr<Policy> policy_;
     std::shared_ptr<Node> root_;
@@ -347,18 +347,34 @@ private:
         sync_with_board(board);
         policy_->prepare(board);
         const int chunk = by_iterations_ ? static_cast<int>(iterations_) : 256;
-        const long long want = by_iterations_ ? static_cast<long long>(chunk) * 226 + 1 : (1ll << 22);
+        // room for the kept subtree plus this search
+        const long long want = by_iterations_ ? 3ll * chunk * 226 + 1 : (1ll << 22);
         const int capacity = static_cast<int>(std::min<long long>(std::max<long long>(want, 256), (1ll << 24) - 1));
         if (!trad_handle_ || trad_capacity_ != capacity) {
             if (trad_handle_) gmk_trad_destroy(trad_handle_);
             trad_handle_ = nullptr;
             throw_gmk(gmk_trad_create(1, capacity, &trad_handle_));
             trad_capacity_ = capacity;
+            trad_valid_ = false;
         }
-        uint8_t moves[kN] = {};
-        const int32_t len = static_cast<int32_t>(board.record_.size());
-        for (int i = 0; i < len; ++i) moves[i] = static_cast<uint8_t>(board.record_[i].id);
-        throw_gmk(gmk_trad_set_positions(trad_handle_, moves, &len));
+        // MCTS::syncWithBoard (MCTS.cpp:119-125): step through the moves played since the last search, subtree kept
+        const size_t have = trad_record_.size(), now = board.record_.size();
+        bool continues = trad_valid_ && have <= now;
+        for (size_t i = 0; continues && i < have; ++i) continues = trad_record_[i] == board.record_[i];
+        if (continues) {
+            for (size_t i = have; i < now; ++i) {
+                const int16_t mv = board.record_[i].id;
+                throw_gmk(gmk_trad_step(trad_handle_, &mv));
+            }
+        } else {
+            uint8_t moves[kN] = {};
+            const int32_t len = static_cast<int32_t>(now);
+            for (int i = 0; i < len; ++i) moves[i] = static_cast<uint8_t>(board.record_[i].id);
+            throw_gmk(gmk_trad_set_positions(trad_handle_, moves, &len));
+        }
+        trad_record_.assign(board.record_.begin(), board.record_.end());
+        trad_valid_ = true;
+        if (g_root_noise_alpha > 0.0f) throw_gmk(gmk_trad_add_root_noise(trad_handle_, g_root_noise_alpha, g_root_noise_epsilon, g_search_seed, game_id_));
         std::vector<float> values(kN), priors(kN);
         uint32_t root_visits = 0;
         float q = 0.0f;
@@ -400,6 +416,8 @@ private:
     bool device_valid_ = false;
     gmk_trad* trad_handle_ = nullptr;
     int trad_capacity_ = 0, best_in_order_ = -1;
+    std::vector<Position> trad_record_;                             // the moves that lead to the device tree's root (TraditionalPolicy)
+    bool trad_valid_ = false;
     int capacity_ = 0;
     size_t c_rollouts_ = 0;
     double c_puct_ = 0;

@@ -18,9 +18,11 @@
 // order (sum225, the same as oracle/go_trad.c); PUCB and tanh are evaluated in double like the reference.
 #include <cmath>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "evalstate_device.h"
+#include "philox.h"
 
 namespace {
 
@@ -35,7 +37,8 @@ constexpr int kPerGame = (kStateWords + kScratchWords + 2 * kPathCap + kRecordWo
 constexpr uint32_t kNoParent = 0xFFFFFFu;
 
 struct TradHeader {                              // 64 B per game in HBM
-    uint32_t n_nodes, init_acts, status, fresh;  // status: bit 0 node capacity reached, bit 1 evaluator error, bit 2 board-only revert met
+    uint32_t n_nodes, init_acts, status, fresh;  // status: bit 0 node capacity reached, bit 1 evaluator error, bit 2 board-only revert met, bit 3 illegal step
+                                                 // fresh: 1 = new root + evaluator sync, 2 = the tree was re-rooted (kept): evaluator sync only
     uint32_t playouts_done, root_black, pad0, pad1;
     unsigned long long evaluator_updates, pad2;
     uint32_t pad3[4];
@@ -226,9 +229,10 @@ void trad_playouts_kernel(TradParams prm) {
     const uint8_t* record = reinterpret_cast<const uint8_t*>(g.c.st + oRecord);
     uint32_t n_nodes = hdr->n_nodes, status = hdr->status;
     int root_black = hdr->root_black;
-    const bool fresh = hdr->fresh != 0u;
+    const uint32_t fresh_mode = hdr->fresh;
+    const bool fresh = fresh_mode == 1u;
 
-    if (fresh) {
+    if (fresh_mode != 0u) {
         // Policy::prepare + TraditionalPolicy::prepare: Evaluator::syncWithBoard (Pattern.cpp:356-368), then a fresh root
         const uint8_t* mv = prm.moves + static_cast<size_t>(game) * 225;
         const int n = prm.lens[game];
@@ -245,13 +249,15 @@ void trad_playouts_kernel(TradParams prm) {
         for (int k = meta[0] - i; k > 0; --k) { revert_move(g.c); wave_phase_fence(); ++g.updates; }
         g.init = n;
         root_black = n & 1;                                     // the player of the last move
-        if (lane == 0) {
-            g.stat[0] = make_uint2(0u, 0u);
-            g.info[0] = make_uint2(kNoParent | ((n ? mv[n - 1] : 255u) << 24), __float_as_uint(1.0f));
-            g.link[0] = 0u;
+        if (fresh) {
+            if (lane == 0) {
+                g.stat[0] = make_uint2(0u, 0u);
+                g.info[0] = make_uint2(kNoParent | ((n ? mv[n - 1] : 255u) << 24), __float_as_uint(1.0f));
+                g.link[0] = 0u;
+            }
+            n_nodes = 1;
+            status = 0;
         }
-        n_nodes = 1;
-        status = 0;
     } else {
         g.init = static_cast<int>(hdr->init_acts);
     }
@@ -461,13 +467,133 @@ void trad_playouts_kernel(TradParams prm) {
     for (int i = lane; i < kStateWords / 4; i += 64) dst[i] = src[i];
 }
 
+// MCTS::stepForward() / stepForward(move) (MCTS.cpp:129-147): the chosen child's subtree becomes the tree.  The reference
+// frees the siblings; here the kept subtree is copied level by level into the other arena so that node indices stay dense
+// (children consecutive, the root at 0).  A copied node carries its OLD child range and OLD first-child record until the
+// scan reaches it, copies its children and rewrites both.  One wavefront per game.
+struct TradArena {
+    uint2* stat; uint2* info; uint32_t* link; uint2* front; uint8_t* ord;
+};
+
+__global__ __launch_bounds__(64)
+void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n_games, const int16_t* forced, uint8_t* moves, int32_t* lens) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    if (game >= n_games) return;
+    TradHeader& hdr = hdrs[game];
+    const size_t base = static_cast<size_t>(game) * cap;
+    uint8_t* mv = moves + static_cast<size_t>(game) * 225;
+    const int len = lens[game];
+    if (hdr.fresh == 1u) {                                      // the position was set but never searched: its root node does not exist yet
+        if (lane == 0) {
+            a.stat[base] = make_uint2(0u, 0u);
+            a.info[base] = make_uint2(kNoParent | ((len ? mv[len - 1] : 255u) << 24), __float_as_uint(1.0f));
+            a.link[base] = 0u;
+            hdr.n_nodes = 1; hdr.status = 0; hdr.root_black = static_cast<uint32_t>(len & 1);
+        }
+        __syncthreads();
+    }
+    const uint32_t lk = a.link[base], first = lk & 0xFFFFFFu, n = lk >> 24;
+    int want = forced ? forced[game] : -1;
+    // the child to keep: the one of the wanted move, or the most visited one, first in the current order
+    uint32_t best_visits = 0, best_ord = 0xFFFFFFFFu, best_id = 0;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t id = first + i, cell = a.info[base + id].x >> 24, o = a.ord[base + id];
+        const uint32_t v = want >= 0 ? (cell == static_cast<uint32_t>(want) ? 1u : 0u) : a.stat[base + id].x + 1u;
+        if (v > best_visits || (v == best_visits && v != 0u && o < best_ord)) { best_visits = v; best_ord = o; best_id = id; }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        const uint32_t ov = __shfl_down(best_visits, s), oo = __shfl_down(best_ord, s), oi = __shfl_down(best_id, s);
+        if (ov > best_visits || (ov == best_visits && ov != 0u && oo < best_ord)) { best_visits = ov; best_ord = oo; best_id = oi; }
+    }
+    best_visits = __shfl(best_visits, 0);
+    best_id = __shfl(best_id, 0);
+    const bool found = best_visits != 0u;
+    if (want < 0 && !found) {                                   // stepForward() on a childless root: nothing moves (MCTS.cpp:133)
+        if (lane == 0) { b.stat[base] = a.stat[base]; b.info[base] = a.info[base]; b.link[base] = 0u; b.ord[base] = 0; hdr.n_nodes = 1; hdr.fresh = 2; }
+        return;
+    }
+    const uint32_t cell = found ? a.info[base + best_id].x >> 24 : static_cast<uint32_t>(want);
+    bool legal = cell < 225u && len < 225;
+    for (int i = lane; i < len; i += 64) legal &= mv[i] != cell;
+    legal = __all(legal);
+    if (!legal) {                                               // not a move of this game: the tree stays as it is (copied over, the arenas flip for everybody)
+        if (lane == 0) hdr.status |= 8u;
+        want = -2;
+    }
+    if (lane == 0 && want != -2) { mv[len] = static_cast<uint8_t>(cell); lens[game] = len + 1; hdr.fresh = 2; hdr.root_black ^= 1u; }
+    const uint32_t src_root = want == -2 ? 0u : best_id;
+    if (want != -2 && !found) {                                 // stepForward(move) without such a child: a new node (MCTS.cpp:140-145)
+        if (lane == 0) {
+            b.stat[base] = make_uint2(0u, 0u); b.info[base] = make_uint2(kNoParent | (cell << 24), __float_as_uint(1.0f));
+            b.link[base] = 0u; b.ord[base] = 0; hdr.n_nodes = 1;
+        }
+        return;
+    }
+    if (lane == 0) {
+        b.stat[base] = a.stat[base + src_root];
+        b.info[base] = make_uint2(kNoParent | (a.info[base + src_root].x & 0xFF000000u), a.info[base + src_root].y);
+        b.link[base] = a.link[base + src_root];
+        b.front[base] = a.front[base + src_root];
+        b.ord[base] = 0;
+    }
+    __syncthreads();
+    uint32_t next = 1;
+    for (uint32_t i0 = 0, chunk = 0; i0 < next; i0 += chunk) {
+        chunk = min(64u, next - i0);                            // nodes appended while this chunk is handled come after it
+        const uint32_t old_link = static_cast<uint32_t>(lane) < chunk ? b.link[base + i0 + lane] : 0u;
+        unsigned long long todo = __ballot((old_link >> 24) != 0u);
+        while (todo) {
+            const int j = __ffsll(static_cast<long long>(todo)) - 1;
+            todo &= todo - 1ull;
+            const uint32_t ol = __shfl(old_link, j), of = ol & 0xFFFFFFu, nk = ol >> 24, node = i0 + static_cast<uint32_t>(j);
+            for (uint32_t k = lane; k < nk; k += 64) {
+                const uint2 inf = a.info[base + of + k];
+                b.stat[base + next + k] = a.stat[base + of + k];
+                b.info[base + next + k] = make_uint2(node | (inf.x & 0xFF000000u), inf.y);
+                b.link[base + next + k] = a.link[base + of + k];
+                b.front[base + next + k] = a.front[base + of + k];
+                b.ord[base + next + k] = a.ord[base + of + k];
+            }
+            if (lane == 0) {
+                const uint32_t new_link = next | (nk << 24);
+                b.link[base + node] = new_link;
+                const uint2 fr = b.front[base + node];              // still the OLD id of the first child in the current order
+                b.front[base + node] = make_uint2((next + ((fr.x & 0xFFFFFFu) - of)) | (fr.x & 0xFF000000u), fr.y);
+                if (node != 0u) {                                   // am I my parent's first child?  then its record of me carries my child range
+                    const uint32_t p = b.info[base + node].x & 0xFFFFFFu;
+                    const uint2 pf = b.front[base + p];
+                    if ((pf.x & 0xFFFFFFu) == node) b.front[base + p] = make_uint2(pf.x, new_link);
+                }
+            }
+            next += nk;
+            __syncthreads();
+        }
+        __syncthreads();                                        // children written above are scanned below
+    }
+    if (lane == 0) hdr.n_nodes = next;
+}
+
+// Default::AddNoise (MonteCarlo.hpp:97-108): the root children's priors, by cell, as the host computed them
+__global__ __launch_bounds__(64)
+void trad_set_root_priors_kernel(TradArena a, const TradHeader* hdrs, int cap, const float* priors) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    const size_t base = static_cast<size_t>(game) * cap;
+    if (hdrs[game].fresh == 1u) return;                         // no root node yet: nothing to mix noise into
+    const uint32_t lk = a.link[base], first = lk & 0xFFFFFFu, n = lk >> 24;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint2 inf = a.info[base + first + i];
+        a.info[base + first + i] = make_uint2(inf.x, __float_as_uint(priors[static_cast<size_t>(game) * 225 + (inf.x >> 24)]));
+    }
+}
+
 // root statistics by cell and the child MCTS::stepForward would pick (most visited, first in the CURRENT order)
 __global__ __launch_bounds__(64)
-void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t* link, const uint8_t* ord, int cap,
+void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t* link, const uint8_t* ord, const TradHeader* hdrs, int cap,
                             uint32_t* visits, float* values, float* priors, int32_t* best, uint32_t* root_visits, float* root_value) {
     const int game = blockIdx.x, lane = threadIdx.x;
     const size_t arena = static_cast<size_t>(game) * cap;
-    const uint32_t lk = link[arena], first = lk & 0xFFFFFFu, n = lk >> 24;
+    const bool no_root = hdrs[game].fresh == 1u;                // the position was set but never searched
+    const uint32_t lk = no_root ? 0u : link[arena], first = lk & 0xFFFFFFu, n = lk >> 24;
     uint32_t best_visits = 0, best_ord = 0xFFFFFFFFu, best_cell = 0;
     for (uint32_t i = lane; i < n; i += 64) {
         const uint2 cs = stat[arena + first + i], ci = info[arena + first + i];
@@ -483,8 +609,8 @@ void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t
     }
     if (lane == 0) {
         if (best) best[game] = best_ord == 0xFFFFFFFFu ? -1 : static_cast<int32_t>(best_cell);
-        if (root_visits) root_visits[game] = stat[arena].x;
-        if (root_value) root_value[game] = __uint_as_float(stat[arena].y);
+        if (root_visits) root_visits[game] = no_root ? 0u : stat[arena].x;
+        if (root_value) root_value[game] = no_root ? 0.0f : __uint_as_float(stat[arena].y);
     }
 }
 
@@ -497,6 +623,11 @@ struct gmk_trad {
     uint32_t* d_link = nullptr;
     uint2* d_front = nullptr;
     uint8_t* d_ord = nullptr;
+    uint2 *d_stat2 = nullptr, *d_info2 = nullptr, *d_front2 = nullptr;      // second arena, allocated by the first gmk_trad_step
+    uint32_t* d_link2 = nullptr;
+    uint8_t* d_ord2 = nullptr;
+    int16_t* d_forced = nullptr;
+    float* d_priors = nullptr;
     TradHeader* d_hdr = nullptr;
     uint8_t* d_moves = nullptr;
     int32_t* d_lens = nullptr;
@@ -506,7 +637,8 @@ struct gmk_trad {
 extern "C" int gmk_trad_destroy(gmk_trad* t) {
     if (!t) return GMK_OK;
     (void)hipFree(t->d_states); (void)hipFree(t->d_stat); (void)hipFree(t->d_info); (void)hipFree(t->d_link);
-    (void)hipFree(t->d_front); (void)hipFree(t->d_ord); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
+    (void)hipFree(t->d_front); (void)hipFree(t->d_ord); (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_front2);
+    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
     delete t;
     return GMK_OK;
 }
@@ -577,6 +709,71 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
 
 extern "C" int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float* h_priors, int32_t* h_best,
                                    uint32_t* h_root_visits, float* h_root_value, int32_t* h_n_nodes, int32_t* h_status,
+                                   uint64_t* h_evaluator_updates);
+
+extern "C" int gmk_trad_step(gmk_trad* t, const int16_t* h_moves) {
+    if (!t) { gmk::set_error("gmk_trad_step: bad arguments"); return GMK_ERR_ARG; }
+    if (!t->positioned) { gmk::set_error("gmk_trad_step: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
+    const size_t n = static_cast<size_t>(t->n_games), nodes = n * static_cast<size_t>(t->cap);
+    if (!t->d_stat2) {
+        const bool ok = hipMalloc(&t->d_stat2, nodes * 8) == hipSuccess && hipMalloc(&t->d_info2, nodes * 8) == hipSuccess &&
+                        hipMalloc(&t->d_link2, nodes * 4) == hipSuccess && hipMalloc(&t->d_front2, nodes * 8) == hipSuccess &&
+                        hipMalloc(&t->d_ord2, nodes) == hipSuccess && hipMalloc(&t->d_forced, n * 2) == hipSuccess;
+        if (!ok) { gmk::set_error("gmk_trad_step: hipMalloc of the second arena (%zu nodes) failed", nodes); return GMK_ERR_HIP; }
+    }
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    if (h_moves) GMK_HIP_CHECK(hipMemcpy(t->d_forced, h_moves, n * 2, hipMemcpyHostToDevice));
+    const TradArena a{t->d_stat, t->d_info, t->d_link, t->d_front, t->d_ord}, b{t->d_stat2, t->d_info2, t->d_link2, t->d_front2, t->d_ord2};
+    hipLaunchKernelGGL(trad_step_kernel, dim3(t->n_games), dim3(64), 0, nullptr, a, b, t->d_hdr, t->cap, t->n_games,
+                       h_moves ? t->d_forced : nullptr, t->d_moves, t->d_lens);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    std::swap(t->d_stat, t->d_stat2); std::swap(t->d_info, t->d_info2); std::swap(t->d_link, t->d_link2);
+    std::swap(t->d_front, t->d_front2); std::swap(t->d_ord, t->d_ord2);
+    return GMK_OK;
+}
+
+// Default::AddNoise (MonteCarlo.hpp:97-108) on every root that has children:
+//   P <- (1 - epsilon) * P + epsilon * normalized(gamma(alpha, 1) per child, ascending cell)   (Statistical.hpp:29-34)
+// drawn with the toolchain's std::gamma_distribution<float> over std::mt19937 like the reference; the engine is seeded with
+// Philox(seed; game id, stones on the root board, 'nois') instead of random_device (as gmk_mcts_add_root_noise does).
+extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id) {
+    if (!t || !(alpha > 0.0f)) { gmk::set_error("gmk_trad_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
+    if (!t->positioned) { gmk::set_error("gmk_trad_add_root_noise: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
+    const size_t n = static_cast<size_t>(t->n_games);
+    std::vector<float> priors(n * 225);
+    std::vector<int32_t> lens(n);
+    int rc = gmk_trad_root_stats(t, nullptr, nullptr, priors.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc != GMK_OK) return rc;
+    GMK_HIP_CHECK(hipMemcpy(lens.data(), t->d_lens, n * 4, hipMemcpyDeviceToHost));
+    const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+    for (size_t g = 0; g < n; ++g) {
+        float* p = &priors[g * 225];
+        int n_child = 0;
+        for (int i = 0; i < 225; ++i) n_child += p[i] != 0.0f;
+        if (!n_child) continue;
+        std::mt19937 engine(gmk::philox4x32_10(first_game_id + static_cast<uint32_t>(g), static_cast<uint32_t>(lens[g]), 0x6E6F6973u, 0u, k0, k1).v[0]);
+        std::gamma_distribution<float> gamma(alpha, 1.0f);
+        float noise[225], sq = 0.0f;
+        for (int i = 0; i < 225; ++i) {
+            p[i] *= 1 - epsilon;
+            noise[i] = p[i] ? gamma(engine) : 0.0f;
+            sq += noise[i] * noise[i];
+        }
+        const float norm = sq > 0.0f ? std::sqrt(sq) : 1.0f;
+        for (int i = 0; i < 225; ++i) p[i] += epsilon * (sq > 0.0f ? noise[i] / norm : noise[i]);
+    }
+    if (!t->d_priors) GMK_HIP_CHECK(hipMalloc(&t->d_priors, n * 225 * 4));
+    GMK_HIP_CHECK(hipMemcpy(t->d_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
+    const TradArena a{t->d_stat, t->d_info, t->d_link, t->d_front, t->d_ord};
+    hipLaunchKernelGGL(trad_set_root_priors_kernel, dim3(t->n_games), dim3(64), 0, nullptr, a, t->d_hdr, t->cap, t->d_priors);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float* h_priors, int32_t* h_best,
+                                   uint32_t* h_root_visits, float* h_root_value, int32_t* h_n_nodes, int32_t* h_status,
                                    uint64_t* h_evaluator_updates) {
     if (!t) { gmk::set_error("gmk_trad_root_stats: bad arguments"); return GMK_ERR_ARG; }
     const size_t n = static_cast<size_t>(t->n_games);
@@ -588,7 +785,7 @@ extern "C" int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_val
     GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4)); GMK_TRY(hipMalloc(&d_priors, n * 225 * 4));
     GMK_TRY(hipMalloc(&d_best, n * 4)); GMK_TRY(hipMalloc(&d_root_visits, n * 4)); GMK_TRY(hipMalloc(&d_root_value, n * 4));
     GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_priors, 0, n * 225 * 4));
-    hipLaunchKernelGGL(trad_root_stats_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->d_stat, t->d_info, t->d_link, t->d_ord, t->cap,
+    hipLaunchKernelGGL(trad_root_stats_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->d_stat, t->d_info, t->d_link, t->d_ord, t->d_hdr, t->cap,
                        d_visits, d_values, d_priors, d_best, d_root_visits, d_root_value);
     GMK_TRY(hipGetLastError());
     GMK_TRY(hipDeviceSynchronize());

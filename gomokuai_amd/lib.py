@@ -32,7 +32,7 @@ EXPORTS = [
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
     "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_root_stats",
-    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_root_stats", "gmk_trad_read_evaluators",
+    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators",
 ]
 
 
@@ -102,6 +102,8 @@ def load():
     L.gmk_trad_reset_evaluators.argtypes = [vp]
     L.gmk_trad_set_positions.argtypes = [vp, vp, vp]
     L.gmk_trad_run.argtypes = [vp, C.c_int, C.c_double, vp]
+    L.gmk_trad_step.argtypes = [vp, vp]
+    L.gmk_trad_add_root_noise.argtypes = [vp, C.c_float, C.c_float, C.c_uint64, C.c_uint32]
     L.gmk_trad_root_stats.argtypes = [vp] * 10
     L.gmk_trad_read_evaluators.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.gmk_samples_from_records.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
@@ -361,6 +363,18 @@ class TraditionalMCTS:
 
     def run(self, playouts, stream=0):
         _check(load().gmk_trad_run(self.h, int(playouts), self.c_puct, stream))
+
+    def step(self, moves=None):
+        """MCTS::stepForward: per game the cell to step to (int16[n]), -1 / None = the most visited child; the subtree is kept."""
+        if moves is None:
+            _check(load().gmk_trad_step(self.h, None))
+        else:
+            m = np.ascontiguousarray(moves, dtype=np.int16)
+            assert m.shape == (self.n,)
+            _check(load().gmk_trad_step(self.h, m.ctypes.data))
+
+    def add_root_noise(self, alpha=0.05, epsilon=0.25, seed=DEFAULT_SEED, first_game_id=0):
+        _check(load().gmk_trad_add_root_noise(self.h, alpha, epsilon, seed, first_game_id))
 
     def root_stats(self):
         out = {"visits": np.zeros((self.n, N), np.uint32), "values": np.zeros((self.n, N), np.float32), "priors": np.zeros((self.n, N), np.float32),

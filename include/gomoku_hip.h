@@ -205,6 +205,13 @@ int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stream);
 int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float* h_priors, int32_t* h_best,
                         uint32_t* h_root_visits, float* h_root_value, int32_t* h_n_nodes, int32_t* h_status,
                         uint64_t* h_evaluator_updates);
+/* MCTS::stepForward() / stepForward(move) (core/lib/src/MCTS.cpp:129-147) for every game: h_moves int16[n] = the cell to step
+ * to, or -1 for the most visited child (first in the current child order); h_moves == NULL = -1 for all.  The child's
+ * subtree is kept (compacted into a second arena), a move without a child starts a new node; the move is appended to the
+ * game's position and the next gmk_trad_run synchronises the evaluator (Policy::prepare).  Status bit 3 = not a legal move. */
+int gmk_trad_step(gmk_trad* t, const int16_t* h_moves);
+/* Default::AddNoise on every root with children (the reference does this at the start of every search, MCTS.cpp:182) */
+int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id);
 /* the games' evaluator states, laid out as gmk_evalstate_read */
 int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density, uint32_t* h_pattern_dist,
                              uint32_t* h_compound_dist, int32_t* h_meta, uint8_t* h_record);

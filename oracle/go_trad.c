@@ -33,7 +33,13 @@ struct go_trad {
     int32_t *kids;  int n_kids, cap_kids;
     int      root;
     uint64_t evaluator_updates;     /* instrumentation: applied + reverted moves */
+    /* the MCTS object around the policy (MCTS.h:135-180) when the tree is kept from search to search */
+    int      have_tree;
+    float    noise_alpha, noise_epsilon;
+    uint64_t seed; uint32_t game_id;
 };
+
+void go__gamma_draws(unsigned seed, float alpha, int n, float *out);     /* go_stdsort.cpp */
 
 static int group1(int player) { return player == GO_BLACK; }
 static int group2(int favour, int perspective) { return ((favour == GO_BLACK) << 1) | (perspective == GO_BLACK); }
@@ -303,6 +309,73 @@ int go_trad_root_children(const go_trad *t, uint32_t *visits, float *values, flo
         if (best < 0 || ch->visits > best_visits) { best = ch->pos; best_visits = ch->visits; }
     }
     return best;
+}
+
+/* ---- the same search inside a persistent MCTS object: MCTS::syncWithBoard / stepForward / runPlayouts (MCTS.cpp:119-198) ---- */
+void go_trad_set_noise(go_trad *t, float alpha, float epsilon, uint64_t seed, uint32_t game_id) {
+    t->noise_alpha = alpha; t->noise_epsilon = epsilon; t->seed = seed; t->game_id = game_id;
+}
+
+/* MCTS::stepForward(next_move) (MCTS.cpp:136-147): the child of that move becomes the root, or a new node does */
+static void step_forward_move(go_trad *t, int move) {
+    tnode *r = &t->nodes[t->root];
+    int next = -1;
+    for (int i = 0; i < r->n && next < 0; ++i)
+        if (t->nodes[t->kids[r->first + i]].pos == move) next = t->kids[r->first + i];
+    if (next < 0) next = new_node(t, -1, move, -t->nodes[t->root].player, 0.0f, 1.0f);
+    t->nodes[next].parent = -1;
+    t->root = next;
+}
+
+/* MCTS::stepForward() (MCTS.cpp:129-134): the most visited child, first maximum in the current order; returns its move */
+int go_trad_step_forward(go_trad *t) {
+    const tnode *r = &t->nodes[t->root];
+    int best = -1; uint64_t best_visits = 0;
+    for (int i = 0; i < r->n; ++i) {
+        const tnode *ch = &t->nodes[t->kids[r->first + i]];
+        if (best < 0 || ch->visits > best_visits) { best = t->kids[r->first + i]; best_visits = ch->visits; }
+    }
+    if (best >= 0) { t->nodes[best].parent = -1; t->root = best; }
+    return t->nodes[t->root].pos;
+}
+
+/* Default::AddNoise (MonteCarlo.hpp:97-108) + Stats::DirichletNoise (Statistical.hpp:29-34), seeded like go_mcts.c:
+   std::mt19937(Philox(game, stones, 'nois'; seed).word0), one gamma draw per child in ascending cell order */
+static void add_noise(go_trad *t, int stones) {
+    tnode *root = &t->nodes[t->root];
+    if (!(t->noise_alpha > 0.0f) || root->n == 0) return;
+    float prior[GO_N], noise[GO_N], draws[GO_N], sq[GO_N];
+    uint32_t ctr[4] = { t->game_id, (uint32_t)stones, 0x6E6F6973u, 0u }, key[2] = { (uint32_t)t->seed, (uint32_t)(t->seed >> 32) }, w[4];
+    int k = 0;
+    for (int i = 0; i < GO_N; ++i) prior[i] = 0.0f;
+    for (int i = 0; i < root->n; ++i) prior[t->nodes[t->kids[root->first + i]].pos] = t->nodes[t->kids[root->first + i]].prior;
+    for (int i = 0; i < GO_N; ++i) prior[i] *= 1 - t->noise_epsilon;
+    go_philox4x32(ctr, key, w);
+    go__gamma_draws(w[0], t->noise_alpha, root->n, draws);
+    for (int i = 0; i < GO_N; ++i) { noise[i] = prior[i] ? draws[k++] : 0.0f; sq[i] = noise[i] * noise[i]; }
+    float z = 0.0f;
+    for (int i = 0; i < GO_N; ++i) z += sq[i];                   /* sequential, like go_mcts.c and the product's host code */
+    if (z > 0.0f) { float nrm = sqrtf(z); for (int i = 0; i < GO_N; ++i) noise[i] = noise[i] / nrm; }
+    for (int i = 0; i < GO_N; ++i) prior[i] += t->noise_epsilon * noise[i];
+    for (int i = 0; i < root->n; ++i) t->nodes[t->kids[root->first + i]].prior = prior[t->nodes[t->kids[root->first + i]].pos];
+}
+
+/* MCTS::runPlayouts (MCTS.cpp:179-198) on the kept tree: syncWithBoard, AddNoise, Policy::prepare, the playouts */
+void go_trad_run(go_trad *t, const uint8_t *moves, int n_moves, uint64_t playouts) {
+    if (!t->have_tree) {                                          /* MCTS(c_iterations): root = (Position(-1), White) */
+        t->n_nodes = 0; t->n_kids = 0;
+        t->root = new_node(t, -1, -1, GO_WHITE, 0.0f, 1.0f);
+        t->have_tree = 1;
+    }
+    int i = 0;                                                    /* MCTS::syncWithBoard (MCTS.cpp:119-125) */
+    while (i < n_moves && moves[i] != t->nodes[t->root].pos) ++i;
+    i = (i == n_moves) ? 0 : i + 1;
+    for (; i < n_moves; ++i) step_forward_move(t, moves[i]);
+    add_noise(t, n_moves);
+    t->init = (size_t)n_moves;
+    eval_sync(t, moves, n_moves);
+    t->cached = t->init;
+    for (uint64_t k = 0; k < playouts; ++k) playout(t);
 }
 
 uint64_t go_trad_root_visits(const go_trad *t) { return t->nodes[t->root].visits; }

@@ -169,6 +169,11 @@ go_trad *go_trad_new(double c_puct);
 void go_trad_free(go_trad *t);
 /* fresh root at the position after `moves`, `playouts` iterations; the policy's evaluator persists across calls */
 void go_trad_search(go_trad *t, const uint8_t *moves, int n_moves, uint64_t playouts);
+/* the same inside a persistent MCTS object: the tree is kept from call to call (syncWithBoard / stepForward(move)), noise is
+   mixed into the root priors before every search when alpha > 0 (Default::AddNoise), go_trad_step_forward plays the best child */
+void go_trad_set_noise(go_trad *t, float alpha, float epsilon, uint64_t seed, uint32_t game_id);
+void go_trad_run(go_trad *t, const uint8_t *moves, int n_moves, uint64_t playouts);
+int  go_trad_step_forward(go_trad *t);
 /* per-cell root child statistics; returns the move MCTS::stepForward() would play (-1 without children) */
 int  go_trad_root_children(const go_trad *t, uint32_t *visits, float *values, float *priors);
 uint64_t go_trad_root_visits(const go_trad *t);

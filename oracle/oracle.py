@@ -92,6 +92,11 @@ def lib():
     L.go_trad_free.argtypes = [C.c_void_p]
     L.go_trad_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
     L.go_trad_search.restype = None
+    L.go_trad_set_noise.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint32]
+    L.go_trad_set_noise.restype = None
+    L.go_trad_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+    L.go_trad_run.restype = None
+    L.go_trad_step_forward.argtypes = [C.c_void_p]
     L.go_trad_root_children.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.go_trad_root_visits.argtypes = [C.c_void_p]
     L.go_trad_root_visits.restype = C.c_uint64
@@ -357,6 +362,17 @@ class TraditionalMCTS:
     def search(self, moves, playouts):
         m = np.ascontiguousarray(moves, dtype=np.uint8)
         self.L.go_trad_search(self.h, m.ctypes.data, len(m), int(playouts))
+
+    def set_noise(self, alpha, epsilon, seed, game_id=0):
+        self.L.go_trad_set_noise(self.h, alpha, epsilon, seed, game_id)
+
+    def run(self, moves, playouts):
+        """runPlayouts on the kept tree (syncWithBoard, AddNoise, playouts)."""
+        m = np.ascontiguousarray(moves, dtype=np.uint8)
+        self.L.go_trad_run(self.h, m.ctypes.data, len(m), int(playouts))
+
+    def step_forward(self):
+        return self.L.go_trad_step_forward(self.h)
 
     def root_children(self):
         v = np.zeros(N, dtype=np.uint32)

@@ -58,27 +58,34 @@ def test_duration_constraint():
 
 
 def test_traditional_policy_matches_oracle(oracle):
-    """MCTS(policy=TraditionalPolicy) searches on the device (K6) and agrees with the oracle restatement, search after
-    search (the policy's evaluator persists), including which of several equally visited children is played."""
+    """MCTS(policy=TraditionalPolicy) searches on the device (K6) and agrees with the oracle restatement move after move of
+    an agent loop: the tree is kept (stepForward), Dirichlet noise goes into the root priors before every search, the
+    policy's evaluator persists; including which of several equally visited children is played."""
     O = oracle
+    core.set_seed(99)
+    core.set_root_noise(0.05, 0.25)
     m = core.MCTS(c_iterations=400, policy=core.TraditionalPolicy(5.0))
     om = O.TraditionalMCTS(5.0)
+    om.set_noise(0.05, 0.25, 99, 0)
     b = core.Board()
     played = []
     for mv in (112, 98, 127, 113):
         b.apply_move(core.Position(mv)); played.append(mv)
-    for _ in range(3):
+    kept = []
+    for _ in range(5):
         q, pi = m.eval_state(b)
-        om.search(played, 400)
+        om.run(played, 400)
         v, oq, p, best = om.root_children()
         assert np.float32(q).tobytes() == np.float32(om.root_value).tobytes()
         kids = {c.position.id: c for c in m.root.children}
         assert sorted(kids) == [int(i) for i in np.nonzero(p)[0]]
         assert all(kids[i].node_visits == int(v[i]) and np.float32(kids[i].action_prob).tobytes() == p[i].tobytes() for i in kids)
         assert abs(float(pi.sum()) - 1.0) < 1e-3
+        kept.append(int(m.root.node_visits))
         m.step_forward()
-        assert m.root.position.id == best
+        assert m.root.position.id == best == om.step_forward()
         b.apply_move(m.root.position); played.append(best)
+    assert max(kept[1:]) > 400                           # visits carried over with the kept subtree
 
 
 def test_traditional_agent_plays_a_game():

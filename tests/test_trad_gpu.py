@@ -132,3 +132,64 @@ def test_node_capacity_is_reported(gmk):
     s = t.root_stats()
     assert s["status"][0] & 1 and s["n_nodes"][0] <= 256
     t.close()
+
+
+def test_step_keeps_the_subtree_and_noise(gmk, oracle):
+    """gmk_trad_step + gmk_trad_add_root_noise (MCTS::stepForward / syncWithBoard, Default::AddNoise) for a batch of games:
+    searching, stepping to the best child, stepping to an arbitrary reply, searching again equals the oracle's persistent
+    MCTS object driven the same way.  Games that are over stop moving (a step on their childless root changes nothing)."""
+    import ctypes as C
+    G, O = gmk, oracle
+    n = 6
+    pos = _positions(G, n, 16, first=900)
+    pos = [p if len(p) >= 2 else [112, 113] for p in pos]
+    t = G.TraditionalMCTS(n, node_capacity=1 << 18)
+    orcs = [O.TraditionalMCTS(5.0) for _ in range(n)]
+    boards = []
+    for g, o in enumerate(orcs):
+        o.set_noise(0.05, 0.25, 4242, 50 + g)
+        b = O.new_board()
+        for mv in pos[g]:
+            O.lib().go_board_apply(C.byref(b), mv, 1)
+        boards.append(b)
+    t.set_positions(pos)
+    lists = [list(p) for p in pos]
+    compared = kept_visits = 0
+    for rnd in range(3):
+        t.add_root_noise(0.05, 0.25, seed=4242, first_game_id=50)
+        t.run(250)
+        st = t.root_stats()
+        live = [g for g in range(n) if boards[g].cur_player != 0]
+        for g in live:
+            orcs[g].run(lists[g], 250)
+            v, q, p, best = orcs[g].root_children()
+            where = "round %d game %d" % (rnd, g)
+            np.testing.assert_array_equal(st["priors"][g].view(np.uint32), p.view(np.uint32), where)
+            np.testing.assert_array_equal(st["visits"][g], v, where)
+            np.testing.assert_array_equal(st["values"][g].view(np.uint32), q.view(np.uint32), where)
+            assert st["best"][g] == best and st["root_visits"][g] == orcs[g].root_visits, where
+            assert np.float32(st["root_value"][g]).view(np.uint32) == np.float32(orcs[g].root_value).view(np.uint32), where
+            kept_visits = max(kept_visits, int(st["root_visits"][g]) - 250)
+            compared += 1
+        # everybody still playing steps to the most visited child, then the opponent answers somewhere: the first free
+        # cell (rarely a child: a new node) in odd games, a free cell in the middle in even ones
+        first = np.full(n, -1, np.int16)
+        for g in live:
+            first[g] = st["best"][g]
+            assert orcs[g].step_forward() == st["best"][g]
+            lists[g].append(int(first[g]))
+            O.lib().go_board_apply(C.byref(boards[g]), int(first[g]), 1)
+        t.step(first)
+        replies = np.full(n, -1, np.int16)
+        for g in live:
+            if boards[g].cur_player == 0:
+                continue
+            free = [c for c in range(225) if c not in lists[g]]
+            kid_visits = orcs[g].root_children()[0]              # the new root's children, when the kept subtree has some
+            replies[g] = free[0] if g % 2 else (int(np.argmax(kid_visits)) if kid_visits.any() else free[len(free) // 2])
+            lists[g].append(int(replies[g]))
+            O.lib().go_board_apply(C.byref(boards[g]), int(replies[g]), 1)
+        t.step(replies)
+        assert (t.root_stats()["status"] == 0).all()
+    assert compared >= 10 and kept_visits > 0            # some searches started from a kept subtree
+    t.close()
