@@ -119,12 +119,14 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
 
 
 def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                          device=None, node_capacity=None):
+                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None):
     """n_games complete games of the reference's self-play SUPERVISOR against itself (config.py:9-12: "traditional_mcts",
     MCTS(TraditionalPolicy) on both sides), all games side by side on the current GPU: every move = one K6 search of
-    `playouts` playouts per unfinished game (fresh root, the games' evaluators are kept and synchronised like the
-    policy objects of the reference), then MCTS::stepForward's choice is played.  The search is deterministic; variety
-    comes from the openings (synthetic generator, `opening_plies` plies of game first_game_id + g).  Returns the same
+    `playouts` playouts per unfinished game (the games' evaluators are kept and synchronised like the policy objects of
+    the reference; with reuse_subtree the chosen child's subtree is kept too, MCTS::stepForward, and root_noise =
+    (alpha, epsilon) mixes Default::AddNoise into the root priors before every search), then MCTS::stepForward's choice
+    is played.  Without noise the search is deterministic; variety then comes from the openings (synthetic generator,
+    `opening_plies` plies of game first_game_id + g).  Returns the same
     GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
     from . import core
     G.init(torch.cuda.current_device() if device is None else device.index)
@@ -142,15 +144,20 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
             lens[g] = min(int(l[g]), opening_plies)
     visits = np.zeros((n_games, N, N), dtype=np.uint16)
     over = np.array([b.status["is_end"] for b in boards], dtype=bool)
-    tree = G.TraditionalMCTS(n_games, node_capacity=node_capacity if node_capacity is not None else min(playouts * 226 + 1, (1 << 24) - 1), c_puct=c_puct)
+    cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * 226 + 1, (1 << 24) - 1)
+    tree = G.TraditionalMCTS(n_games, node_capacity=cap, c_puct=c_puct)
     overflow = False
-    for _ in range(max_moves):
+    for ply in range(max_moves):
         if over.all():
             break
-        tree.set_positions([moves[g, :lens[g]] for g in range(n_games)])
+        if ply == 0 or not reuse_subtree:
+            tree.set_positions([moves[g, :lens[g]] for g in range(n_games)])
+        if root_noise is not None:
+            tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
         tree.run(playouts, stream)
         st = tree.root_stats()
         overflow |= bool((st["status"] & 1).any())
+        played = np.full(n_games, -1, dtype=np.int16)
         for g in range(n_games):
             if over[g]:
                 continue
@@ -158,11 +165,14 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
             if best < 0:                                    # no child: nothing the policy wants to play (cannot happen on a live board)
                 over[g] = True
                 continue
+            played[g] = best
             visits[g, lens[g]] = np.minimum(st["visits"][g], 65535)
             boards[g].apply_move(core.Position(best))
             moves[g, lens[g]] = best
             lens[g] += 1
             over[g] = boards[g].status["is_end"]
+        if reuse_subtree:
+            tree.step(played)                               # finished games ask for -1 on a childless root: nothing moves
     tree.close()
     winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
     return GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),

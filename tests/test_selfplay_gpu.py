@@ -146,3 +146,14 @@ def test_supervisor_self_play(oracle):
         assert L >= 9
     states, values, pi = rec.to_samples(first_move=3)
     assert states.shape[0] == int((r.lens - 3).sum()) and float(pi.sum(1).sub(1).abs().max()) < 1e-3
+    # with the subtree kept and root noise: still legal, finished games, reproducible from the seed
+    a = selfplay.play_supervisor_games(4, 80, opening_plies=2, first_game_id=3, reuse_subtree=True, root_noise=(0.05, 0.25), seed=5)
+    b2 = selfplay.play_supervisor_games(4, 80, opening_plies=2, first_game_id=3, reuse_subtree=True, root_noise=(0.05, 0.25), seed=5)
+    assert (a.moves.cpu() == b2.moves.cpu()).all() and not a.overflow
+    ra = a.cpu()
+    for g in range(len(a)):
+        b = oracle.new_board()
+        for i in range(int(ra.lens[g])):
+            assert oracle.lib().go_board_check_move(C.byref(b), int(ra.moves[g, i]))
+            oracle.lib().go_board_apply(C.byref(b), int(ra.moves[g, i]), 1)
+        assert b.cur_player == 0 and b.winner == int(ra.winner[g])
