@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--kind", type=int, default=0, help="0 random-opening, 1 clustered")
     ap.add_argument("--cpu-sample", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the timed K1 steps one by one instead of replaying a hipGraph")
     ap.add_argument("--mcts-games", type=int, default=4096, help="games per GPU for the secondary MCTS measurement (BASELINE configs[2]); 0 = skip")
     ap.add_argument("--mcts-playouts", type=int, default=800)
     ap.add_argument("--mcts-reps", type=int, default=3)
@@ -267,23 +268,39 @@ def main():
     d_density = torch.empty((n, 2, 2, 225), dtype=torch.int32, device=dev)
     d_totals = torch.empty((n, 11), dtype=torch.int32, device=dev)
     d_status = torch.empty((n,), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
+    def step(stream=None):
         G.eval_batch(d_planes.data_ptr(), n, d_scores.data_ptr(), d_density.data_ptr(), d_totals.data_ptr(),
-                     d_status.data_ptr(), stream)
+                     d_status.data_ptr(), torch.cuda.current_stream().cuda_stream if stream is None else stream)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # the K timed steps are captured once into a hipGraph (K kernel nodes) and replayed: no per-launch host work in the
+    # timed region ("graph-launched"); --no-graph, or a failed capture, launches them one by one instead
+    graph = None
+    if not args.no_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(args.steps):
+                    step()
+            graph.replay()                                   # one untimed replay: the graph is uploaded here
+            torch.cuda.synchronize()
+        except Exception as exc:                             # noqa: BLE001
+            print("bench: hipGraph capture failed (%s); launching step by step" % exc, file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
     ev1.record()
     torch.cuda.synchronize()
     if distributed:
@@ -325,7 +342,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "batched AC-automaton position eval (K1), %d %s boards per GPU, 15x15, inputs resident in HBM"
                                    % (n, "random-opening" if args.kind == 0 else "clustered"),
-                       "boards_per_gpu": n, "parallelism": "boards sharded by rank, no collective"},
+                       "boards_per_gpu": n, "parallelism": "boards sharded by rank, no collective",
+                       "launch": "hipGraph replay of the K steps" if graph is not None else "K stream launches"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("eval_positions_kernel", "boards_per_launch", n),
