@@ -460,7 +460,6 @@ int upload_lane_jobs() {
         if (extra < static_cast<int>(lines.size())) { jobs[lane * 2 + 1] = pack(lines[extra]); total += lines[extra].len + 3; }
         steps = std::max(steps, total);
     }
-    if (const char* env = std::getenv("GMK_EVAL_SCAN_STEPS")) steps = std::atoi(env);      // profiling aid only: wrong results
     uint32_t init[kLineWords] = {};                              // every cell of every line blank (symbol 3)
     for (int i = 0; i < 15; ++i) init[i] = init[kColBase + i] = 0x3FFFFFFFu;
     for (int d = 0; d <= 28; ++d) init[kDiagBase + d] = init[kAntiBase + d] = (1u << (2 * (15 - std::abs(d - 14)))) - 1u;

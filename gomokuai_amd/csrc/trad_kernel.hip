@@ -62,8 +62,6 @@ struct TradParams {
     double c_puct;
 };
 
-__device__ __forceinline__ float lane_bcast(float v, int src) { return __shfl(v, src); }
-
 // the one summation order (oracle/go_trad.c: sum225): lane l first adds its cells l, l+64, l+128, l+192 in that order
 // (done by the caller into `p`), then a binary tree over the lanes; every lane gets the result
 __device__ __forceinline__ float tree_sum(float p) {
