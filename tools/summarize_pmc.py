@@ -22,7 +22,7 @@ for path in sorted(glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursi
             if k == "trad_playouts_kernel":                    # bench.py launches a short warm-up search first: keep the two full searches
                 v = sorted(v)[-2:]
             vals[k][c] = sum(v) / len(v)
-print("# rocprofv3 --pmc, one pass per counter group (separate runs), command: python3 bench.py --steps 5 --warmup 2 --mcts-reps 1 --no-cpu-baseline")
+print("# rocprofv3 --pmc, one pass per counter group (separate runs), command: python3 bench.py --steps 5 --warmup 2 --mcts-reps 1 --no-cpu-baseline --az-games 0")
 print("# FETCH_SIZE / WRITE_SIZE are in KB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half the bytes of wide coalesced reads (x2 below);")
 print("# narrower accesses are uncalibrated (the 8-byte node reads of the MCTS kernel are given uncorrected and corrected).")
 for k, unit, per in (("eval_positions_kernel", "board", n_boards), ("mcts_playouts_kernel", "playout", n_playouts), ("trad_playouts_kernel", "playout", n_trad)):
