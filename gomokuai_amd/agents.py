@@ -8,7 +8,7 @@ from subprocess import PIPE, Popen
 
 import numpy as np
 
-from .core import Board, GameConfig as Game, MCTS, Player, Position, RandomPolicy, TraditionalPolicy
+from .core import Board, GameConfig as Game, MCTS, Player, Policy, Position, RandomPolicy, TraditionalPolicy
 
 
 class Agent:
@@ -60,6 +60,12 @@ def RandomMCTSAgent(c_puct, c_rollouts=5, **constraint):
 def TraditionalAgent(c_puct, c_bias=0.0, use_rave=False, **constraint):
     """agents/mcts.py:44-48 of the reference: the pattern-guided searcher ("traditional_mcts" in config.py:9-12)."""
     return MCTSAgent(policy=TraditionalPolicy(c_puct, c_bias, use_rave), **constraint)
+
+
+def PyConvNetAgent(network, c_puct, **constraint):
+    """agents/alphazero.py:5-9: MCTS guided by network.eval_state(board) -> (value, probs[225]).  The tree search runs on the
+    GPU (K7), the network is called once per playout like in the reference; lib.AlphaZeroMCTS is the batched form."""
+    return MCTSAgent(policy=Policy(eval_state=network.eval_state, c_puct=c_puct), **constraint)
 
 
 def dual_play(agents, board=None, verbose=False):

@@ -224,11 +224,16 @@ void az_root_stats_kernel(AzTree t, uint32_t* visits, float* values, float* prio
 struct gmk_az {
     AzTree t{};
     bool rooted = false;
+    // device scratch of the host-driven form (gmk_az_select_host / gmk_az_expand_host)
+    float *h_states = nullptr, *h_values = nullptr, *h_probs = nullptr;
+    int16_t* h_paths = nullptr;
+    int32_t* h_lens = nullptr;
 };
 
 extern "C" int gmk_az_destroy(gmk_az* a) {
     if (!a) return GMK_OK;
     (void)hipFree(a->t.hdr); (void)hipFree(a->t.stat); (void)hipFree(a->t.kids); (void)hipFree(a->t.prior); (void)hipFree(a->t.parent);
+    (void)hipFree(a->h_states); (void)hipFree(a->h_values); (void)hipFree(a->h_probs); (void)hipFree(a->h_paths); (void)hipFree(a->h_lens);
     delete a;
     return GMK_OK;
 }
@@ -289,6 +294,58 @@ extern "C" int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_pr
     if (!a->rooted) { gmk::set_error("gmk_az_expand: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
     hipLaunchKernelGGL(az_expand_kernel, dim3(a->t.n_games), dim3(64), 0, static_cast<hipStream_t>(stream), a->t, d_values, d_probs);
     GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+// ---- host-driven form for callers that evaluate leaves on the host (one game behind CorePyExt: the evaluator is a Python
+// callable that wants a Board): the moves from the root to each pending leaf, and value / probabilities from host memory ----
+namespace {
+__global__ void az_leaf_path_kernel(AzTree t, int16_t* paths, int32_t* lens) {
+    const int game = blockIdx.x * blockDim.x + threadIdx.x;
+    if (game >= t.n_games) return;
+    const AzHeader& hdr = t.hdr[game];
+    int16_t* out = paths + static_cast<size_t>(game) * 226;
+    if (!hdr.leaf_pending) { lens[game] = -1; return; }
+    const size_t arena = static_cast<size_t>(game) * t.cap;
+    int depth = 0;
+    for (uint32_t node = hdr.leaf; node != 0u && node != kNoNode; node = t.parent[arena + node]) ++depth;
+    lens[game] = depth;
+    int i = depth;
+    for (uint32_t node = hdr.leaf; node != 0u && node != kNoNode; node = t.parent[arena + node])
+        out[--i] = static_cast<int16_t>((t.kids[arena + node].y >> 8) & 0xFFu);
+}
+}  // namespace
+
+static bool az_host_scratch(gmk_az* a) {
+    if (a->h_states) return true;
+    const size_t n = static_cast<size_t>(a->t.n_games);
+    return hipMalloc(&a->h_states, n * 6 * 225 * 4) == hipSuccess && hipMalloc(&a->h_values, n * 4) == hipSuccess &&
+           hipMalloc(&a->h_probs, n * 225 * 4) == hipSuccess && hipMalloc(&a->h_paths, n * 226 * 2) == hipSuccess &&
+           hipMalloc(&a->h_lens, n * 4) == hipSuccess;
+}
+
+// gmk_az_select, then for every game the moves from the root to its pending leaf: h_paths int16[n][226], h_lens int32[n]
+// (-1 = the playout ended at a finished game and is already backed up: nothing to evaluate)
+extern "C" int gmk_az_select_host(gmk_az* a, int16_t* h_paths, int32_t* h_lens) {
+    if (!a || !h_paths || !h_lens) { gmk::set_error("gmk_az_select_host: bad arguments"); return GMK_ERR_ARG; }
+    if (!az_host_scratch(a)) { gmk::set_error("gmk_az_select_host: device allocation failed"); return GMK_ERR_HIP; }
+    const int rc = gmk_az_select(a, a->h_states, nullptr);
+    if (rc != GMK_OK) return rc;
+    hipLaunchKernelGGL(az_leaf_path_kernel, dim3((a->t.n_games + 63) / 64), dim3(64), 0, nullptr, a->t, a->h_paths, a->h_lens);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipMemcpy(h_paths, a->h_paths, static_cast<size_t>(a->t.n_games) * 226 * 2, hipMemcpyDeviceToHost));
+    GMK_HIP_CHECK(hipMemcpy(h_lens, a->h_lens, static_cast<size_t>(a->t.n_games) * 4, hipMemcpyDeviceToHost));
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_expand_host(gmk_az* a, const float* h_values, const float* h_probs) {
+    if (!a || !h_values || !h_probs) { gmk::set_error("gmk_az_expand_host: bad arguments"); return GMK_ERR_ARG; }
+    if (!az_host_scratch(a)) { gmk::set_error("gmk_az_expand_host: device allocation failed"); return GMK_ERR_HIP; }
+    GMK_HIP_CHECK(hipMemcpy(a->h_values, h_values, static_cast<size_t>(a->t.n_games) * 4, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(a->h_probs, h_probs, static_cast<size_t>(a->t.n_games) * 225 * 4, hipMemcpyHostToDevice));
+    const int rc = gmk_az_expand(a, a->h_values, a->h_probs, nullptr);
+    if (rc != GMK_OK) return rc;
+    GMK_HIP_CHECK(hipDeviceSynchronize());
     return GMK_OK;
 }
 

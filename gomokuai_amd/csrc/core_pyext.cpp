@@ -198,7 +198,7 @@ public:
         : policy_(policy ? policy : std::make_shared<RandomPolicy>(5.0, 5)), duration_(duration), by_iterations_(false) { init(last_move, last_player); }
     MCTS(size_t iterations, Position last_move, Player last_player, std::shared_ptr<Policy> policy)
         : policy_(policy ? policy : std::make_shared<RandomPolicy>(5.0, 5)), iterations_(iterations), duration_(0), by_iterations_(true) { init(last_move, last_player); }
-    ~MCTS() { if (handle_) gmk_mcts_destroy(handle_); if (trad_handle_) gmk_trad_destroy(trad_handle_); }
+    ~MCTS() { if (handle_) gmk_mcts_destroy(handle_); if (trad_handle_) gmk_trad_destroy(trad_handle_); if (az_handle_) gmk_az_destroy(az_handle_); }
 
     Position get_action(Board& board) {
         run_playouts(board);
@@ -286,9 +286,10 @@ private:
         auto* random = dynamic_cast<RandomPolicy*>(policy_.get());
         auto* trad = dynamic_cast<TraditionalPolicy*>(policy_.get());
         if (trad && !trad->use_rave && !policy_->has_python_stages()) { run_traditional(board, *trad, start); return; }
+        if (!random && !trad && policy_->simulate && !policy_->select && !policy_->expand && !policy_->back_prop) { run_with_evaluator(board, start); return; }
         if (!random || policy_->has_python_stages())
-            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy and TraditionalPolicy(use_rave=False) in this build; ") +
-                                     policy_->kind() + " with host-side stages is not available (no CPU search path)");
+            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy, TraditionalPolicy(use_rave=False) and Policy(eval_state=...) in this build; ") +
+                                     policy_->kind() + " with other host-side stages is not available (no CPU search path)");
         throw_gmk(gmk_init(0));
         sync_with_board(board);
         policy_->prepare(board);
@@ -337,6 +338,70 @@ private:
                     root_->children.push_back(c);
                 }
         size_ += nodes - nodes_before;                              // m_size only ever grows (MCTS.cpp:189, 194)
+        policy_->cleanup(board);
+    }
+
+    // MCTS(policy = Policy(eval_state = f, c_puct)) (agents/alphazero.py:5-9): the tree search runs on the device (K7, gmk_az_*, one
+    // game), the evaluator is the Python callable, called once per playout with the leaf position like the reference's
+    // policy->simulate(board) (MCTS.cpp:164-166).  Every search starts from a fresh root.
+    void run_with_evaluator(Board& board, std::chrono::system_clock::time_point start) {
+        throw_gmk(gmk_init(0));
+        sync_with_board(board);
+        policy_->prepare(board);
+        const int budget = by_iterations_ ? static_cast<int>(iterations_) : (1 << 14);
+        const int capacity = std::max(256, budget * kN + 1);
+        if (!az_handle_ || az_capacity_ != capacity || az_c_puct_ != policy_->c_puct) {
+            if (az_handle_) gmk_az_destroy(az_handle_);
+            az_handle_ = nullptr;
+            throw_gmk(gmk_az_create(1, capacity, policy_->c_puct, &az_handle_));
+            az_capacity_ = capacity; az_c_puct_ = policy_->c_puct;
+        }
+        uint16_t planes[32];
+        board.planes(planes);
+        const size_t len = board.record_.size();
+        const int16_t last[2] = {len >= 1 ? board.record_[len - 1].id : static_cast<short>(-1), len >= 2 ? board.record_[len - 2].id : static_cast<short>(-1)};
+        throw_gmk(gmk_az_set_roots(az_handle_, planes, last));
+        std::vector<int16_t> path(226);
+        std::vector<float> probs(kN);
+        size_t done = 0;
+        auto playout = [&]() {
+            int32_t depth = -1;
+            throw_gmk(gmk_az_select_host(az_handle_, path.data(), &depth));
+            if (depth >= 0) {                                       // a live leaf: ask the evaluator about that position
+                Board leaf = board;
+                for (int i = 0; i < depth; ++i) leaf.apply_move(Position(path[i]), false);        // Policy::applyMove: no victory check
+                auto [value, arr] = policy_->simulate(leaf);
+                auto flat = py::array_t<float, py::array::c_style | py::array::forcecast>(arr);
+                if (flat.size() != kN) throw std::runtime_error("eval_state must return (value, probabilities of size 225)");
+                std::memcpy(probs.data(), flat.data(), sizeof(float) * kN);
+                throw_gmk(gmk_az_expand_host(az_handle_, &value, probs.data()));
+            }
+            ++done;
+        };
+        if (by_iterations_) {
+            for (size_t i = 0; i < iterations_; ++i) playout();
+            duration_ = std::chrono::duration_cast<milliseconds>(std::chrono::system_clock::now() - start);
+        } else {
+            for (auto end = start; end - start < duration_ && done < static_cast<size_t>(budget); end = std::chrono::system_clock::now()) playout();
+            iterations_ = done;
+        }
+        std::vector<float> values(kN), priors(kN);
+        uint32_t root_visits = 0;
+        float q = 0.0f;
+        int32_t nodes = 1, status = 0;
+        visits_.assign(kN, 0);
+        throw_gmk(gmk_az_root_stats(az_handle_, visits_.data(), values.data(), priors.data(), &root_visits, &q, &nodes, &status));
+        root_->state_value = q;
+        root_->node_visits = root_visits;
+        root_->children.clear();
+        for (int i = 0; i < kN; ++i)
+            if (priors[i] != 0.0f && board.cell_[i] == Player::None) {
+                auto c = std::make_shared<Node>();
+                c->parent = root_; c->position = Position(i); c->player = -root_->player;
+                c->action_prob = priors[i]; c->state_value = values[i]; c->node_visits = visits_[i];
+                root_->children.push_back(c);
+            }
+        size_ += static_cast<size_t>(nodes) - 1;
         policy_->cleanup(board);
     }
 
@@ -415,6 +480,9 @@ private:
     std::vector<Position> device_record_;                           // the moves that lead to the device tree's root
     bool device_valid_ = false;
     gmk_trad* trad_handle_ = nullptr;
+    gmk_az* az_handle_ = nullptr;
+    int az_capacity_ = 0;
+    double az_c_puct_ = 0;
     int trad_capacity_ = 0, best_in_order_ = -1;
     std::vector<Position> trad_record_;                             // the moves that lead to the device tree's root (TraditionalPolicy)
     bool trad_valid_ = false;

@@ -230,6 +230,11 @@ int gmk_az_destroy(gmk_az* a);
 int gmk_az_set_roots(gmk_az* a, const uint16_t* h_planes, const int16_t* h_last_moves);
 int gmk_az_select(gmk_az* a, float* d_states, void* stream);
 int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_probs, void* stream);
+/* The same two steps for an evaluator that runs on the host and wants positions, not planes (the Python callable of
+ * Policy(eval_state=...)): select, then the moves from the root to every pending leaf (h_paths int16[n][226], h_lens int32[n],
+ * -1 = nothing to evaluate); expand from host memory.  Synchronous. */
+int gmk_az_select_host(gmk_az* a, int16_t* h_paths, int32_t* h_lens);
+int gmk_az_expand_host(gmk_az* a, const float* h_values, const float* h_probs);
 /* host outputs, any may be NULL; status bit 1 = node arena full (playouts of that game were dropped) */
 int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
                       float* h_root_value, int32_t* h_n_nodes, int32_t* h_status);

@@ -128,3 +128,39 @@ def test_agent_loop_keeps_the_tree_and_adds_root_noise(oracle):
     b2 = core.Board(); b2.apply_move(core.Position(0))
     m.eval_state(b2)
     assert m.root.node_visits == 150
+
+
+def test_policy_with_python_evaluator_matches_oracle(oracle):
+    """MCTS(policy=Policy(eval_state=f, c_puct)) (agents/alphazero.py:5-9): the search runs on the device (K7), f is called with
+    the leaf Board once per playout; with the same f the oracle's MCTS sees the same tree."""
+    from test_az_gpu import surrogate
+    O = oracle
+    calls = []
+
+    def eval_state(board):
+        calls.append(len(board.move_record))
+        return surrogate(board.encoded_states())
+    m = core.MCTS(c_iterations=120, policy=core.Policy(eval_state=eval_state, c_puct=4.0))
+    b, ob = core.Board(), O.new_board()
+    for mv in (112, 98, 127, 113, 96):
+        b.apply_move(core.Position(mv)); O.lib().go_board_apply(C.byref(ob), mv, 1)
+    q, pi = m.eval_state(b)
+    om = O.MCTS(120, 4.0, 5, 0, 0)
+    om.set_evaluator(surrogate)
+    oq, opi, ovisits = om.eval_state(ob)
+    assert np.float32(q).tobytes() == np.float32(oq).tobytes()
+    kids = {c.position.id: c.node_visits for c in m.root.children}
+    assert all(kids.get(i, 0) == int(v) for i, v in enumerate(ovisits)) and sum(kids.values()) == 119
+    assert len(calls) == 120 and min(calls) == 5 and max(calls) > 5 and len(b.move_record) == 5
+    m.step_forward()
+    assert m.root.position.id == int(np.argmax(ovisits))
+
+
+def test_py_conv_net_agent_plays():
+    import torch
+    from gomokuai_amd.network import PolicyValueNetwork
+    net = PolicyValueNetwork(seed=5).cuda().eval()
+    agent = agents.PyConvNetAgent(net, 5.0, c_iterations=24)
+    b = core.Board()
+    q, pi, mv = agent.eval_state(b)
+    assert abs(float(pi.sum()) - 1.0) < 1e-3 and 0 <= mv.id < 225 and -1.0 <= q <= 1.0
