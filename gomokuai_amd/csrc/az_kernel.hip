@@ -14,10 +14,12 @@
 // Mapping: one wavefront per game, lanes over the (<= 225) children; the tree is an SoA arena per game in HBM.
 #include <cmath>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "board_device.h"
 #include "capi_common.h"
+#include "philox.h"
 
 namespace {
 
@@ -191,6 +193,87 @@ void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* _
     }
 }
 
+// MCTS::stepForward() / stepForward(move) (MCTS.cpp:129-147): the chosen child's subtree becomes the tree, copied level by
+// level into the other arena (root at 0, children consecutive); a move without a child starts a new node.  The move is
+// played on the root position.  One wavefront per game.
+struct AzArena { uint2* stat; uint2* kids; float* prior; uint32_t* parent; };
+
+__global__ __launch_bounds__(64)
+void az_step_kernel(AzTree t, AzArena b, const int16_t* forced) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    if (game >= t.n_games) return;
+    AzHeader& hdr = t.hdr[game];
+    const size_t base = static_cast<size_t>(game) * t.cap;
+    const uint2 rk = t.kids[base];
+    const uint32_t first = rk.x, n = rk.y & 0xFFu;
+    const int want = forced ? forced[game] : -1;
+    uint32_t best_v = 0, best_i = 0xFFFFFFFFu;                   // visits + 1 (or "is the wanted cell"), first maximum in child order
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t cell = (t.kids[base + first + i].y >> 8) & 0xFFu;
+        const uint32_t v = want >= 0 ? (cell == static_cast<uint32_t>(want) ? 1u : 0u) : t.stat[base + first + i].x + 1u;
+        if (v > best_v) { best_v = v; best_i = i; }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        const uint32_t ov = __shfl_down(best_v, s), oi = __shfl_down(best_i, s);
+        if (ov > best_v || (ov == best_v && ov != 0u && oi < best_i)) { best_v = ov; best_i = oi; }
+    }
+    best_v = __shfl(best_v, 0);
+    best_i = __shfl(best_i, 0);
+    const bool found = best_v != 0u;
+    const uint32_t stones = hdr.stones;
+    const uint32_t cell = found ? (t.kids[base + first + best_i].y >> 8) & 0xFFu : static_cast<uint32_t>(want);
+    const uint32_t row = cell < 225u ? hdr.rows[cell / 15] >> (cell % 15) : 0x10001u;
+    const bool legal = (want >= 0 || found) && cell < 225u && !(row & 0x10001u);
+    if (!legal) {                                               // nothing to play (childless root) or not a move of this game: the tree is carried over as it is
+        if (want >= 0 && lane == 0) hdr.status |= 4u;
+    } else if (lane == 0) {
+        hdr.rows[cell / 15] |= 1u << (cell % 15 + ((stones & 1u) ? 16 : 0));
+        hdr.stones = stones + 1;
+        hdr.last_move2 = hdr.last_move;
+        hdr.last_move = cell;
+        hdr.leaf_pending = 0;
+    }
+    const uint32_t src = !legal ? 0u : (found ? first + best_i : kNoNode);
+    if (src == kNoNode) {                                       // stepForward(move) without such a child: a new node (MCTS.cpp:140-145)
+        if (lane == 0) { b.stat[base] = make_uint2(0u, 0u); b.kids[base] = make_uint2(0u, cell << 8); b.prior[base] = 1.0f; b.parent[base] = kNoNode; hdr.n_nodes = 1; }
+        return;
+    }
+    if (lane == 0) { b.stat[base] = t.stat[base + src]; b.kids[base] = t.kids[base + src]; b.prior[base] = t.prior[base + src]; b.parent[base] = kNoNode; }
+    __syncthreads();
+    uint32_t next = 1;
+    for (uint32_t i0 = 0, chunk = 0; i0 < next; i0 += chunk) {
+        chunk = min(64u, next - i0);                            // nodes appended while this chunk is handled come after it
+        const uint2 old = static_cast<uint32_t>(lane) < chunk ? b.kids[base + i0 + lane] : make_uint2(0u, 0u);
+        unsigned long long todo = __ballot((old.y & 0xFFu) != 0u);
+        while (todo) {
+            const int j = __ffsll(static_cast<long long>(todo)) - 1;
+            todo &= todo - 1ull;
+            const uint32_t of = __shfl(old.x, j), oy = __shfl(old.y, j), nk = oy & 0xFFu, node = i0 + static_cast<uint32_t>(j);
+            for (uint32_t k = lane; k < nk; k += 64) {
+                b.stat[base + next + k] = t.stat[base + of + k];
+                b.kids[base + next + k] = t.kids[base + of + k];       // still the OLD child range: rewritten when the scan gets there
+                b.prior[base + next + k] = t.prior[base + of + k];
+                b.parent[base + next + k] = node;
+            }
+            if (lane == 0) b.kids[base + node] = make_uint2(next, oy);
+            next += nk;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    if (lane == 0) hdr.n_nodes = next;
+}
+
+// Default::AddNoise (MonteCarlo.hpp:97-108): the root children's priors, by cell, as the host computed them
+__global__ __launch_bounds__(64)
+void az_set_root_priors_kernel(AzTree t, const float* priors) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    const size_t base = static_cast<size_t>(game) * t.cap;
+    const uint2 rk = t.kids[base];
+    for (uint32_t i = lane; i < (rk.y & 0xFFu); i += 64)
+        t.prior[base + rk.x + i] = priors[static_cast<size_t>(game) * kCells + ((t.kids[base + rk.x + i].y >> 8) & 0xFFu)];
+}
+
 __global__ void az_init_roots_kernel(AzTree t) {
     const int game = blockIdx.x * blockDim.x + threadIdx.x;
     if (game >= t.n_games) return;
@@ -224,6 +307,9 @@ void az_root_stats_kernel(AzTree t, uint32_t* visits, float* values, float* prio
 struct gmk_az {
     AzTree t{};
     bool rooted = false;
+    AzArena other{};                                             // second arena, allocated by the first gmk_az_step
+    int16_t* d_forced = nullptr;
+    float* d_noise_priors = nullptr;
     // device scratch of the host-driven form (gmk_az_select_host / gmk_az_expand_host)
     float *h_states = nullptr, *h_values = nullptr, *h_probs = nullptr;
     int16_t* h_paths = nullptr;
@@ -233,6 +319,8 @@ struct gmk_az {
 extern "C" int gmk_az_destroy(gmk_az* a) {
     if (!a) return GMK_OK;
     (void)hipFree(a->t.hdr); (void)hipFree(a->t.stat); (void)hipFree(a->t.kids); (void)hipFree(a->t.prior); (void)hipFree(a->t.parent);
+    (void)hipFree(a->other.stat); (void)hipFree(a->other.kids); (void)hipFree(a->other.prior); (void)hipFree(a->other.parent);
+    (void)hipFree(a->d_forced); (void)hipFree(a->d_noise_priors);
     (void)hipFree(a->h_states); (void)hipFree(a->h_values); (void)hipFree(a->h_probs); (void)hipFree(a->h_paths); (void)hipFree(a->h_lens);
     delete a;
     return GMK_OK;
@@ -294,6 +382,63 @@ extern "C" int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_pr
     if (!a->rooted) { gmk::set_error("gmk_az_expand: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
     hipLaunchKernelGGL(az_expand_kernel, dim3(a->t.n_games), dim3(64), 0, static_cast<hipStream_t>(stream), a->t, d_values, d_probs);
     GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
+                                 float* h_root_value, int32_t* h_n_nodes, int32_t* h_status);
+
+extern "C" int gmk_az_step(gmk_az* a, const int16_t* h_moves) {
+    if (!a) { gmk::set_error("gmk_az_step: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_step: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    const size_t n = static_cast<size_t>(a->t.n_games), nodes = n * static_cast<size_t>(a->t.cap);
+    if (!a->other.stat) {
+        const bool ok = hipMalloc(&a->other.stat, nodes * 8) == hipSuccess && hipMalloc(&a->other.kids, nodes * 8) == hipSuccess &&
+                        hipMalloc(&a->other.prior, nodes * 4) == hipSuccess && hipMalloc(&a->other.parent, nodes * 4) == hipSuccess &&
+                        hipMalloc(&a->d_forced, n * 2) == hipSuccess;
+        if (!ok) { gmk::set_error("gmk_az_step: hipMalloc of the second arena (%zu nodes) failed", nodes); return GMK_ERR_HIP; }
+    }
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    if (h_moves) GMK_HIP_CHECK(hipMemcpy(a->d_forced, h_moves, n * 2, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(az_step_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, a->other, h_moves ? a->d_forced : nullptr);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    std::swap(a->t.stat, a->other.stat); std::swap(a->t.kids, a->other.kids); std::swap(a->t.prior, a->other.prior); std::swap(a->t.parent, a->other.parent);
+    return GMK_OK;
+}
+
+// Default::AddNoise on every root with children, seeded like gmk_mcts_add_root_noise / gmk_trad_add_root_noise
+extern "C" int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id) {
+    if (!a || !(alpha > 0.0f)) { gmk::set_error("gmk_az_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_add_root_noise: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    const size_t n = static_cast<size_t>(a->t.n_games);
+    std::vector<float> priors(n * 225);
+    int rc = gmk_az_root_stats(a, nullptr, nullptr, priors.data(), nullptr, nullptr, nullptr, nullptr);
+    if (rc != GMK_OK) return rc;
+    std::vector<AzHeader> hdr(n);
+    GMK_HIP_CHECK(hipMemcpy(hdr.data(), a->t.hdr, n * sizeof(AzHeader), hipMemcpyDeviceToHost));
+    const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
+    for (size_t g = 0; g < n; ++g) {
+        float* p = &priors[g * 225];
+        int n_child = 0;
+        for (int i = 0; i < 225; ++i) n_child += p[i] != 0.0f;
+        if (!n_child) continue;
+        std::mt19937 engine(gmk::philox4x32_10(first_game_id + static_cast<uint32_t>(g), hdr[g].stones, 0x6E6F6973u, 0u, k0, k1).v[0]);
+        std::gamma_distribution<float> gamma(alpha, 1.0f);
+        float noise[225], sq = 0.0f;
+        for (int i = 0; i < 225; ++i) {
+            p[i] *= 1 - epsilon;
+            noise[i] = p[i] ? gamma(engine) : 0.0f;
+            sq += noise[i] * noise[i];
+        }
+        const float norm = sq > 0.0f ? std::sqrt(sq) : 1.0f;
+        for (int i = 0; i < 225; ++i) p[i] += epsilon * (sq > 0.0f ? noise[i] / norm : noise[i]);
+    }
+    if (!a->d_noise_priors) GMK_HIP_CHECK(hipMalloc(&a->d_noise_priors, n * 225 * 4));
+    GMK_HIP_CHECK(hipMemcpy(a->d_noise_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(az_set_root_priors_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, a->d_noise_priors);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
     return GMK_OK;
 }
 

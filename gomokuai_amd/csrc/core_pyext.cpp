@@ -240,7 +240,7 @@ public:
         i = (i == board.record_.size()) ? 0 : i + 1;
         for (; i < board.record_.size(); ++i) step_forward(board.record_[i]);
     }
-    void reset() { init(Position(-1), Player::White); device_valid_ = false; trad_valid_ = false; }
+    void reset() { init(Position(-1), Player::White); device_valid_ = false; trad_valid_ = false; az_valid_ = false; }
 
     std::shared_ptr<Policy> policy_;
     std::shared_ptr<Node> root_;
@@ -343,24 +343,40 @@ private:
 
     // MCTS(policy = Policy(eval_state = f, c_puct)) (agents/alphazero.py:5-9): the tree search runs on the device (K7, gmk_az_*, one
     // game), the evaluator is the Python callable, called once per playout with the leaf position like the reference's
-    // policy->simulate(board) (MCTS.cpp:164-166).  Every search starts from a fresh root.
+    // policy->simulate(board) (MCTS.cpp:164-166).  The tree is kept from move to move and root noise is added like in the other searchers.
     void run_with_evaluator(Board& board, std::chrono::system_clock::time_point start) {
         throw_gmk(gmk_init(0));
         sync_with_board(board);
         policy_->prepare(board);
         const int budget = by_iterations_ ? static_cast<int>(iterations_) : (1 << 14);
-        const int capacity = std::max(256, budget * kN + 1);
+        const int capacity = std::max(256, 3 * budget * kN + 1);       // the kept subtree plus this search
         if (!az_handle_ || az_capacity_ != capacity || az_c_puct_ != policy_->c_puct) {
             if (az_handle_) gmk_az_destroy(az_handle_);
             az_handle_ = nullptr;
             throw_gmk(gmk_az_create(1, capacity, policy_->c_puct, &az_handle_));
             az_capacity_ = capacity; az_c_puct_ = policy_->c_puct;
+            az_valid_ = false;
         }
-        uint16_t planes[32];
-        board.planes(planes);
-        const size_t len = board.record_.size();
-        const int16_t last[2] = {len >= 1 ? board.record_[len - 1].id : static_cast<short>(-1), len >= 2 ? board.record_[len - 2].id : static_cast<short>(-1)};
-        throw_gmk(gmk_az_set_roots(az_handle_, planes, last));
+        // MCTS::syncWithBoard (MCTS.cpp:119-125): step through the moves played since the last search (subtree kept), or start over
+        const size_t have = az_record_.size(), len = board.record_.size();
+        bool continues = az_valid_ && have <= len;
+        for (size_t i = 0; continues && i < have; ++i) continues = az_record_[i] == board.record_[i];
+        if (continues) {
+            for (size_t i = have; i < len; ++i) {
+                const int16_t mv = board.record_[i].id;
+                throw_gmk(gmk_az_step(az_handle_, &mv));
+            }
+        } else {
+            uint16_t planes[32];
+            board.planes(planes);
+            const int16_t last[2] = {len >= 1 ? board.record_[len - 1].id : static_cast<short>(-1), len >= 2 ? board.record_[len - 2].id : static_cast<short>(-1)};
+            throw_gmk(gmk_az_set_roots(az_handle_, planes, last));
+        }
+        az_record_.assign(board.record_.begin(), board.record_.end());
+        az_valid_ = true;
+        if (g_root_noise_alpha > 0.0f) throw_gmk(gmk_az_add_root_noise(az_handle_, g_root_noise_alpha, g_root_noise_epsilon, g_search_seed, game_id_));
+        int32_t nodes_before = 1;
+        throw_gmk(gmk_az_root_stats(az_handle_, nullptr, nullptr, nullptr, nullptr, nullptr, &nodes_before, nullptr));
         std::vector<int16_t> path(226);
         std::vector<float> probs(kN);
         size_t done = 0;
@@ -401,7 +417,7 @@ private:
                 c->action_prob = priors[i]; c->state_value = values[i]; c->node_visits = visits_[i];
                 root_->children.push_back(c);
             }
-        size_ += static_cast<size_t>(nodes) - 1;
+        size_ += static_cast<size_t>(nodes - nodes_before);
         policy_->cleanup(board);
     }
 
@@ -481,6 +497,8 @@ private:
     bool device_valid_ = false;
     gmk_trad* trad_handle_ = nullptr;
     gmk_az* az_handle_ = nullptr;
+    std::vector<Position> az_record_;                               // the moves that lead to the device tree's root (Policy(eval_state=...))
+    bool az_valid_ = false;
     int az_capacity_ = 0;
     double az_c_puct_ = 0;
     int trad_capacity_ = 0, best_in_order_ = -1;

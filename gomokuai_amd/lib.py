@@ -31,7 +31,7 @@ EXPORTS = [
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
-    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_root_stats",
+    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_add_root_noise", "gmk_az_root_stats",
     "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators",
 ]
 
@@ -97,6 +97,8 @@ def load():
     L.gmk_az_select.argtypes = [vp, vp, vp]
     L.gmk_az_expand.argtypes = [vp, vp, vp, vp]
     L.gmk_az_select_host.argtypes = [vp, vp, vp]
+    L.gmk_az_step.argtypes = [vp, vp]
+    L.gmk_az_add_root_noise.argtypes = [vp, C.c_float, C.c_float, C.c_uint64, C.c_uint32]
     L.gmk_az_expand_host.argtypes = [vp, vp, vp]
     L.gmk_az_root_stats.argtypes = [vp] * 8
     L.gmk_trad_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
@@ -436,6 +438,18 @@ class AlphaZeroMCTS:
         assert values.numel() == self.n and probs.numel() == self.n * N
         stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _check(load().gmk_az_expand(self.h, values.data_ptr(), probs.data_ptr(), stream))
+
+    def step(self, moves=None):
+        """MCTS::stepForward for every game: int16[n] cells, -1 / None = the most visited child; the subtree is kept."""
+        if moves is None:
+            _check(load().gmk_az_step(self.h, None))
+        else:
+            m = np.ascontiguousarray(moves, dtype=np.int16)
+            assert m.shape == (self.n,)
+            _check(load().gmk_az_step(self.h, m.ctypes.data))
+
+    def add_root_noise(self, alpha=0.05, epsilon=0.25, seed=DEFAULT_SEED, first_game_id=0):
+        _check(load().gmk_az_add_root_noise(self.h, alpha, epsilon, seed, first_game_id))
 
     def search(self, network, playouts):
         """`playouts` lock-step playouts; network(states) -> (value [n], probs [n, 225]) on the GPU."""

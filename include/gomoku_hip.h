@@ -230,6 +230,11 @@ int gmk_az_destroy(gmk_az* a);
 int gmk_az_set_roots(gmk_az* a, const uint16_t* h_planes, const int16_t* h_last_moves);
 int gmk_az_select(gmk_az* a, float* d_states, void* stream);
 int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_probs, void* stream);
+/* MCTS::stepForward() / stepForward(move) (core/lib/src/MCTS.cpp:129-147) for every game, subtree kept (as gmk_trad_step): h_moves
+ * int16[n] = the cell to step to, -1 = the most visited child, NULL = -1 for all; status bit 2 = not a legal move. */
+int gmk_az_step(gmk_az* a, const int16_t* h_moves);
+/* Default::AddNoise on every root with children (core/lib/include/algorithms/MonteCarlo.hpp:97-108) */
+int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id);
 /* The same two steps for an evaluator that runs on the host and wants positions, not planes (the Python callable of
  * Policy(eval_state=...)): select, then the moves from the root to every pending leaf (h_paths int16[n][226], h_lens int32[n],
  * -1 = nothing to evaluate); expand from host memory.  Synchronous. */

@@ -129,3 +129,60 @@ def test_policy_value_network_end_to_end():
     assert np.abs(probs[:4].cpu().numpy() - ref_probs).max() < 1e-4      # float32 convolutions vs float64: tolerance
     assert np.abs(value[:4].cpu().numpy() - ref_value).max() < 1e-4
     tree.close()
+
+
+def test_step_keeps_the_subtree_and_noise(oracle):
+    """gmk_az_step + gmk_az_add_root_noise: search, step to the most visited child, step to the opponent's reply (a child or
+    not), search again from the kept subtree with fresh root noise: equal to the oracle's persistent MCTS object."""
+    import torch
+    O = oracle
+    G.init()
+    n, playouts = 6, 90
+    moves, lens, planes, last = _roots(n, 12)
+    tree = G.AlphaZeroMCTS(n, node_capacity=1 << 17, c_puct=5.0)
+    tree.set_roots(planes, last)
+
+    def host_network(states):
+        s = states.cpu().numpy()
+        vp = [surrogate(s[g]) for g in range(n)]
+        return (torch.tensor([v for v, _ in vp], dtype=torch.float32, device="cuda"), torch.from_numpy(np.stack([p for _, p in vp])).cuda())
+    boards, orcs = [], []
+    for g in range(n):
+        b = O.new_board()
+        for i in range(int(lens[g])):
+            O.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        om = O.MCTS(playouts, 5.0, 5, 777, 20 + g)
+        om.set_evaluator(surrogate)
+        om.set_noise(0.05, 0.25)
+        boards.append(b); orcs.append(om)
+    kept = 0
+    for rnd in range(3):
+        tree.add_root_noise(0.05, 0.25, seed=777, first_game_id=20)
+        tree.search(host_network, playouts)
+        st = tree.root_stats()
+        assert (st["status"] == 0).all()
+        best = np.full(n, -1, np.int16); reply = np.full(n, -1, np.int16)
+        for g in range(n):
+            if boards[g].cur_player == 0:
+                continue
+            orcs[g].run_playouts(boards[g])
+            v, q, p = orcs[g].root_children()
+            where = "round %d game %d" % (rnd, g)
+            np.testing.assert_array_equal(st["priors"][g].view(np.uint32), p.view(np.uint32), where)
+            np.testing.assert_array_equal(st["visits"][g], v, where)
+            np.testing.assert_array_equal(st["values"][g].view(np.uint32), q.view(np.uint32), where)
+            assert st["root_visits"][g] == orcs[g].root_visits, where
+            kept = max(kept, int(st["root_visits"][g]) - playouts)
+            best[g] = orcs[g].step_forward()
+            O.lib().go_board_apply(C.byref(boards[g]), int(best[g]), 1)
+        tree.step(best)
+        for g in range(n):
+            if boards[g].cur_player == 0:
+                continue
+            free = [c for c in range(225) if boards[g].states[1][c]]
+            kv = orcs[g].root_children()[0]
+            reply[g] = int(np.argmax(kv)) if (g % 2 == 0 and kv.any()) else free[g]
+            O.lib().go_board_apply(C.byref(boards[g]), int(reply[g]), 1)
+        tree.step(reply)
+    assert kept > 0
+    tree.close()

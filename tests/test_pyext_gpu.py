@@ -140,12 +140,14 @@ def test_policy_with_python_evaluator_matches_oracle(oracle):
     def eval_state(board):
         calls.append(len(board.move_record))
         return surrogate(board.encoded_states())
+    core.set_seed(31)
+    core.set_root_noise(0.05, 0.25)
     m = core.MCTS(c_iterations=120, policy=core.Policy(eval_state=eval_state, c_puct=4.0))
     b, ob = core.Board(), O.new_board()
     for mv in (112, 98, 127, 113, 96):
         b.apply_move(core.Position(mv)); O.lib().go_board_apply(C.byref(ob), mv, 1)
     q, pi = m.eval_state(b)
-    om = O.MCTS(120, 4.0, 5, 0, 0)
+    om = O.MCTS(120, 4.0, 5, 31, 0)
     om.set_evaluator(surrogate)
     oq, opi, ovisits = om.eval_state(ob)
     assert np.float32(q).tobytes() == np.float32(oq).tobytes()
@@ -153,7 +155,15 @@ def test_policy_with_python_evaluator_matches_oracle(oracle):
     assert all(kids.get(i, 0) == int(v) for i, v in enumerate(ovisits)) and sum(kids.values()) == 119
     assert len(calls) == 120 and min(calls) == 5 and max(calls) > 5 and len(b.move_record) == 5
     m.step_forward()
-    assert m.root.position.id == int(np.argmax(ovisits))
+    assert m.root.position.id == int(np.argmax(ovisits)) == om.step_forward()
+    # the next search of the agent loop starts from the kept subtree, with root noise (defaults of the reference)
+    b.apply_move(m.root.position); O.lib().go_board_apply(C.byref(ob), m.root.position.id, 1)
+    om.set_noise(0.05, 0.25)
+    q, pi = m.eval_state(b)
+    oq, opi, ovisits = om.eval_state(ob)
+    assert np.float32(q).tobytes() == np.float32(oq).tobytes() and m.root.node_visits == om.root_visits > 120
+    kids = {c.position.id: c.node_visits for c in m.root.children}
+    assert all(kids.get(i, 0) == int(v) for i, v in enumerate(ovisits))
 
 
 def test_py_conv_net_agent_plays():
