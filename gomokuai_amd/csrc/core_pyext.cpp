@@ -295,7 +295,7 @@ private:
         policy_->prepare(board);
         const int chunk = by_iterations_ ? static_cast<int>(iterations_) : 256;
         // room for the kept subtree (at most everything the previous searches grew) plus this search
-        const int capacity = by_iterations_ ? 3 * chunk * kN + 1 : (1 << 22);
+        const int capacity = by_iterations_ ? static_cast<int>(std::min<long long>(3ll * chunk * kN + 1, (1ll << 24) - 1)) : (1 << 22);
         if (!handle_ || capacity_ != capacity || c_rollouts_ != random->c_rollouts || c_puct_ != random->c_puct) {
             if (handle_) gmk_mcts_destroy(handle_);
             handle_ = nullptr;
@@ -349,7 +349,7 @@ private:
         sync_with_board(board);
         policy_->prepare(board);
         const int budget = by_iterations_ ? static_cast<int>(iterations_) : (1 << 14);
-        const int capacity = std::max(256, 3 * budget * kN + 1);       // the kept subtree plus this search
+        const int capacity = static_cast<int>(std::min<long long>(std::max<long long>(256, 3ll * budget * kN + 1), (1ll << 30)));       // the kept subtree plus this search
         if (!az_handle_ || az_capacity_ != capacity || az_c_puct_ != policy_->c_puct) {
             if (az_handle_) gmk_az_destroy(az_handle_);
             az_handle_ = nullptr;

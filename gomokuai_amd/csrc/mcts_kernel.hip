@@ -557,7 +557,10 @@ struct gmk_mcts {
 extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, int c_rollouts, uint64_t seed, gmk_mcts** out) {
     gmk::DeviceState& st = gmk::device_state();
     if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
-    if (!out || n_games <= 0 || node_capacity < 2 || c_rollouts < 1 || c_rollouts > 64) { gmk::set_error("gmk_mcts_create: bad arguments"); return GMK_ERR_ARG; }
+    if (!out || n_games <= 0 || node_capacity < 2 || node_capacity >= (1 << 24) || c_rollouts < 1 || c_rollouts > 64) {
+        gmk::set_error("gmk_mcts_create: bad arguments (2 <= node_capacity < 2^24: a node's first-child index shares a word with its cell)");
+        return GMK_ERR_ARG;
+    }
     gmk_mcts* m = new gmk_mcts;
     m->n_games = n_games; m->node_capacity = node_capacity; m->c_puct = c_puct; m->c_rollouts = c_rollouts; m->seed = seed;
     // Games per wavefront.  A game is a sequential chain (select -> rollouts -> backup), so wall time is set by
