@@ -94,40 +94,49 @@ __device__ __forceinline__ uint64_t window_symbols(const uint32_t* lines, int ce
 
 // Updater::matchPatterns (Pattern.cpp:128-136).  The reference matches twice per update, before and after the stone
 // changes; the two 13-symbol windows differ in the centre symbol only and do not depend on anything else the update
-// touches, so both are walked at once: lane = window * 4 + direction, window 0 = the board as it is (result set 0),
-// window 1 = `new_sym` in the centre (result set 1).
+// touches, so both are matched at once (window 0 = the board as it is -> result set 0, window 1 = `new_sym` in the
+// centre -> result set 1).  Only transitions at window indices 6..12 can report a match that covers the centre, and the
+// automaton forgets where it started after 7 symbols (checked for all 556 states x 4^7 strings when the tables are
+// built, PatternAutomaton::flatten), so every such transition gets its own lane: lane = (window * 4 + direction) * 7 +
+// (k - 6) starts at the root at index max(0, k - 7) and is at the right state after at most 7 lookups.  A chain of 8
+// dependent LDS reads instead of 13; the order of the results does not matter (every update they feed commutes).
 __device__ inline void match_patterns_both(const Ctx& c, int move, uint32_t new_sym) {
-    if (c.lane < 8) {
-        const int dir = c.lane & 3, w = c.lane >> 2;
+    if (c.lane < 8) c.scratch[oResultCount + c.lane] = 0u;
+    wave_phase_fence();
+    if (c.lane < 56) {
+        const int wd = c.lane / 7, k = 6 + c.lane % 7, dir = wd & 3, w = wd >> 2;
         uint64_t syms = window_symbols(c.st + oLines, move, dir);
         if (w) syms = (syms & ~(3ull << 12)) | (static_cast<uint64_t>(new_sym) << 12);
-        uint32_t* out = c.scratch + (w * 4 + dir) * kResultCap * 2;
-        uint32_t cur = static_cast<uint32_t>(syms) << 2, tw = 0;                       // symbol * 4 in bits 2..3, as in eval_kernel.hip
-        int n = 0;
-        for (int k = 0; k < 13; ++k) {
-            tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
+        const int start = k > 7 ? k - 7 : 0;
+        uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;        // symbol * 4 in bits 2..3, as in eval_kernel.hip
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
             cur >>= 2;
-            const uint32_t rid = gmk::dev_trans_record(tw);
-            if (k < 6 || !rid) continue;                         // a match that covers the centre ends at window index >= 6
+        }
+        const uint32_t rid = gmk::dev_trans_record(tw);
+        if (rid) {
+            uint32_t* out = c.scratch + (w * 4 + dir) * kResultCap * 2;
             const uint4 r = c.rec[rid];
             const uint32_t w0s[2] = {r.x, r.z}, w1s[2] = {r.y, r.w};
+#pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const uint32_t w0 = w0s[e];
                 if (!w0) continue;
                 const int back = k - static_cast<int>((w0 >> 27) & 1u) - 6, len = (w0 >> 5) & 7;      // HasCovered (Pattern.cpp:22-25)
                 if (back < 0 || back >= len) continue;
-                if (n < kResultCap) { out[2 * n] = (w0 & 0x07FFFFFFu) | (static_cast<uint32_t>(back) << 28); out[2 * n + 1] = w1s[e]; ++n; }
+                const uint32_t n = atomicAdd(&c.scratch[oResultCount + w * 4 + dir], 1u);
+                if (n < static_cast<uint32_t>(kResultCap)) { out[2 * n] = (w0 & 0x07FFFFFFu) | (static_cast<uint32_t>(back) << 28); out[2 * n + 1] = w1s[e]; }
                 else c.st[oMeta + 3] |= 4u;
             }
         }
-        c.scratch[oResultCount + w * 4 + dir] = static_cast<uint32_t>(n);
     }
 }
 
 // Updater::updatePatterns (Pattern.cpp:138-165): lane = direction * 16 + result slot
 __device__ inline void update_patterns(const Ctx& c, int move, int slot, int delta) {
     const int dir = c.lane >> 4, r = c.lane & 15;
-    if (r >= static_cast<int>(c.scratch[oResultCount + slot * 4 + dir])) return;
+    if (r >= min(static_cast<int>(c.scratch[oResultCount + slot * 4 + dir]), kResultCap)) return;
     const uint32_t* res = c.scratch + ((slot * 4 + dir) * kResultCap + r) * 2;
     const uint32_t w0 = res[0], w1 = res[1];
     const int type = w0 & 15, fav = (w0 >> 4) & 1, back = static_cast<int>(w0 >> 28);
@@ -205,52 +214,72 @@ __device__ inline void queue_compound(const Ctx& c, int cell, int pb /* player i
     }
 }
 
-// One queued component: updateCritical, updateAntis, the compound total (Pattern.cpp:488-550)
+// The queued components: updateCritical and the compound total by one lane per component, then updateAntis
+// (Pattern.cpp:488-550).  updateAntis wants the FIRST match of the component's type that runs through the cell with a
+// blank there, scanning the 13-symbol window from the left.  Such a match ends at window index 6..12, so eight lanes
+// share a component: lane kk looks at the transition at index 6 + kk only (its state is right after <= 7 lookups from
+// the root, see match_patterns_both), and the lowest lane with a hit applies it.
 __device__ inline void apply_compound_items(const Ctx& c, int delta) {
     const int n = min(static_cast<int>(c.scratch[oItemCount]), kCompoundCap);
-    for (int m = c.lane; m < n; m += 64) {
-        const uint32_t item = c.scratch[oItems + m];
-        const int cell = item & 255, pb = (item >> 8) & 1, ctype = (item >> 9) & 3, cdir = (item >> 11) & 3, ct = (item >> 13) & 3;
+    uint32_t* cd = c.st + oCdist;
+    uint32_t* scores = c.st + oScores;
+    if (c.lane < n) {
+        const uint32_t item = c.scratch[oItems + c.lane];
+        const int cell = item & 255, pb = (item >> 8) & 1, ctype = (item >> 9) & 3, cdir = (item >> 11) & 3;
         const int g_own = group2(pb, pb), g_opp = group2(pb, pb ^ 1);
-        uint32_t* cd = c.st + oCdist;
-        uint32_t* scores = c.st + oScores;
         // updateCritical: the cell itself, both views (the two flag fields share a word)
         const uint32_t lowers = (1u << ((4 * g_own + cdir) * 2)) | (1u << ((4 * g_opp + cdir) * 2));
         const uint32_t old = set_flags_begin(&cd[cell * 3 + ctype], delta, lowers);
         atomicAdd(&scores[g_own * kCells + cell], static_cast<uint32_t>(delta * 600));
         atomicAdd(&scores[g_opp * kCells + cell], static_cast<uint32_t>(delta * 600));
         if (item & (1u << 16)) atomicAdd(&cd[225 * 3 + ctype], static_cast<uint32_t>(delta) << (16 * pb));
-        if (item & (1u << 15)) {                                                       // updateAntis: first match of the component's type through the cell
-            const int want = ct == 0 ? 5 : ct == 1 ? 4 : 3, stride = dir_stride(cdir);
-            uint32_t cur = static_cast<uint32_t>(window_symbols(c.st + oLines, cell, cdir)) << 2, tw = 0;
-            bool found = false;
-            for (int k = 0; k < 13 && !found; ++k) {
-                tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
+        set_flags_end(&cd[cell * 3 + ctype], delta, lowers, old);
+    }
+    for (int m0 = 0; m0 < n; m0 += 8) {                          // eight components per pass
+        const int m = m0 + (c.lane >> 3), kk = c.lane & 7, k = 6 + kk;
+        const uint32_t item = m < n ? c.scratch[oItems + m] : 0u;
+        const int cell = item & 255, pb = (item >> 8) & 1, ctype = (item >> 9) & 3, cdir = (item >> 11) & 3, ct = (item >> 13) & 3;
+        uint32_t hit_w0 = 0;                                      // the first qualifying match of this lane's transition
+        int hit_back = 0;
+        if ((item & (1u << 15)) && kk < 7) {
+            const int want = ct == 0 ? 5 : ct == 1 ? 4 : 3;
+            const uint64_t syms = window_symbols(c.st + oLines, cell, cdir);
+            const int start = k > 7 ? k - 7 : 0;
+            uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
                 cur >>= 2;
-                if (k < 6 || !((gmk::dev_trans_kinds(tw) >> ct) & 1u)) continue;
+            }
+            if ((gmk::dev_trans_kinds(tw) >> ct) & 1u) {
                 const uint4 r = c.rec[gmk::dev_trans_record(tw)];
                 const uint32_t w0s[2] = {r.x, r.z};
-                for (int e = 0; e < 2 && !found; ++e) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
                     const uint32_t w0 = w0s[e];
-                    if (!w0 || static_cast<int>(w0 & 15u) != want) continue;
+                    if (hit_w0 || !w0 || static_cast<int>(w0 & 15u) != want) continue;
                     const int back = k - static_cast<int>((w0 >> 27) & 1u) - 6, len = (w0 >> 5) & 7, n_dep = (w0 >> 8) & 7;
                     if (back < 0 || back >= len) continue;
                     bool on_cell = false;
                     for (int d = 0; d < n_dep; ++d) on_cell |= ((w0 >> (11 + 4 * d)) & 15u) == (8u | static_cast<uint32_t>(back));
-                    if (!on_cell) continue;
-                    found = true;
-                    const int last_cell = cell + back * stride;
-                    for (int d = 0; d < n_dep; ++d) {
-                        const int j = (w0 >> (11 + 4 * d)) & 7;
-                        if (j == back) continue;
-                        const int other = last_cell - j * stride;                      // updatePose(delta, other, component, -favour)
-                        set_flag(&cd[other * 3 + ctype], delta, g_opp, cdir);
-                        atomicAdd(&scores[g_opp * kCells + other], static_cast<uint32_t>(delta * 600));
-                    }
+                    if (on_cell) { hit_w0 = w0; hit_back = back; }
                 }
             }
         }
-        set_flags_end(&cd[cell * 3 + ctype], delta, lowers, old);
+        // the scan stops at the first hit: the lowest lane of the component's eight
+        const unsigned long long hits = __ballot(hit_w0 != 0u);
+        const uint32_t mine = static_cast<uint32_t>(hits >> (c.lane & ~7)) & 0xFFu;
+        if (hit_w0 && (mine & ((1u << kk) - 1u)) == 0u) {
+            const int g_opp = group2(pb, pb ^ 1), stride = dir_stride(cdir), n_dep = (hit_w0 >> 8) & 7;
+            const int last_cell = cell + hit_back * stride;
+            for (int d = 0; d < n_dep; ++d) {
+                const int j = (hit_w0 >> (11 + 4 * d)) & 7;
+                if (j == hit_back) continue;
+                const int other = last_cell - j * stride;                              // updatePose(delta, other, component, -favour)
+                set_flag(&cd[other * 3 + ctype], delta, g_opp, cdir);
+                atomicAdd(&scores[g_opp * kCells + other], static_cast<uint32_t>(delta * 600));
+            }
+        }
     }
 }
 

@@ -346,6 +346,35 @@ void PatternAutomaton::flatten() {
         dev_.dev_trans[i] = (next * 16u) | (kinds << 14) | (rec << 17);
     }
     dev_.n_records = static_cast<int>(dev_.dev_records.size() / 4);
+
+    // How many symbols until the automaton has forgotten where it started: the image of the full state set under every
+    // string of that length is a single state.  The incremental evaluator's window matcher (evalstate_device.h) starts
+    // lanes in the middle of a window and relies on this being <= 7.
+    {
+        const int n = dev_.n_states;
+        std::vector<std::vector<uint32_t>> frontier(1), next_frontier;
+        frontier[0].resize(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) frontier[0][static_cast<size_t>(i)] = static_cast<uint32_t>(i);
+        int length = 0;
+        while (!frontier.empty()) {
+            if (++length > 12) throw std::runtime_error("pattern automaton: does not forget its start state within 12 symbols");
+            next_frontier.clear();
+            std::vector<char> seen(static_cast<size_t>(n));
+            for (const std::vector<uint32_t>& set : frontier)
+                for (uint32_t sym = 0; sym < 4; ++sym) {
+                    std::fill(seen.begin(), seen.end(), 0);
+                    std::vector<uint32_t> image;
+                    for (uint32_t st : set) {
+                        const uint32_t to = dev_.trans[st * 4 + sym] & 1023u;
+                        if (!seen[to]) { seen[to] = 1; image.push_back(to); }
+                    }
+                    if (image.size() > 1) next_frontier.push_back(std::move(image));
+                }
+            frontier.swap(next_frontier);
+        }
+        dev_.sync_symbols = length;
+        if (length > 7) throw std::runtime_error("pattern automaton: needs more than 7 symbols to forget its start state");
+    }
 }
 
 std::vector<std::pair<int, int>> PatternAutomaton::scan(const uint8_t* codes, int n) const {

@@ -66,6 +66,7 @@ struct DeviceTables {
     //   w1: as pattern_info w1
     std::vector<uint32_t> dev_records;
     int n_records = 0;
+    int sync_symbols = 0;                // after this many symbols the state no longer depends on the start state (7 for the production table)
     int n_states = 0;
     int n_patterns = 0;
     int max_emissions = 0;
