@@ -20,7 +20,7 @@
 //     compact list of <= 4 score deposits (ds_add_u32) and 4-bit per-(cell, colour, direction, type) counters;
 //   * phase 3: one lane per cell: the 7x7 density stencil as v_dot8_u32_u4 dot products of digit windows with the
 //     block's weight rows, area bonus, compound decision from the counters;
-//   * phase 4: one lane per compound component: 13-symbol window rescan for its counter-move cells;
+//   * phase 4: eight lanes per compound component: its counter-move cells from the 13-symbol window around it;
 //   * phase 5: the 3.6 KB score block leaves LDS as coalesced 16-byte stores.
 // HBM traffic per board: 64 B in, 7 248 B out (7 312 B algorithmic); everything else stays on chip.
 #include <algorithm>
@@ -104,12 +104,12 @@ __device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell
     }
 }
 
-// Compound::updateAntis (Pattern.cpp:520-543) for one match met at window index k: if it is of the wanted type,
-// covers the centre cell q and has '_' there, its other scored blanks get +600 in the opponent's view.
-__device__ __forceinline__ bool try_counter_cells(uint32_t w0, int k, int want, int q, int stride, uint32_t* opp) {
+// Compound::updateAntis (Pattern.cpp:520-543) for one match met at window index k: it qualifies if it is of the wanted
+// type, covers the centre cell q and has '_' there; returns the piece index (from the match's end) lying on q, or -1
+__device__ __forceinline__ int counter_match(uint32_t w0, int k, int want) {
     const int type = w0 & 15, len = (w0 >> 5) & 7;
-    const int back = k - static_cast<int>((w0 >> 27) & 1u) - 6;                     // piece index (from the end) lying on q
-    if (type != want || back < 0 || back >= len) return false;
+    const int back = k - static_cast<int>((w0 >> 27) & 1u) - 6;
+    if (!w0 || type != want || back < 0 || back >= len) return -1;
     const int n_dep = (w0 >> 8) & 7;
     bool on_q = false;
 #pragma unroll
@@ -117,14 +117,17 @@ __device__ __forceinline__ bool try_counter_cells(uint32_t w0, int k, int want, 
         const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
         on_q |= d < n_dep && f == (8u | static_cast<uint32_t>(back));               // '_' on q
     }
-    if (!on_q) return false;
-    const int endcell = q + back * stride;
+    return on_q ? back : -1;
+}
+
+// ... and its other scored blanks get +600 in the opponent's view
+__device__ __forceinline__ void add_counter_cells(uint32_t w0, int back, int q, int stride, uint32_t* opp) {
+    const int n_dep = (w0 >> 8) & 7, endcell = q + back * stride;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
         if (d < n_dep && static_cast<int>(f & 7u) != back) atomicAdd(&opp[endcell - static_cast<int>(f & 7u) * stride], 600u);
     }
-    return true;
 }
 
 __global__ __launch_bounds__(kThreads)
@@ -380,36 +383,46 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         }
         wave_phase_fence();
 
-        // ---- phase 4: one lane per compound component: first match of its type through the cell
-        //      (Compound::updateAntis, Pattern.cpp:520-543): DFA over the 13-symbol window centred on the cell ----
+        // ---- phase 4: the counter-move cells of every compound component: the FIRST match of its type that runs through
+        //      the cell with a blank there (Compound::updateAntis, Pattern.cpp:520-543), scanning the 13-symbol window
+        //      centred on the cell.  Such a match ends at window index 6..12; eight lanes share a component, lane kk looks
+        //      at the transition at index 6 + kk only (the automaton forgets its start state after 7 symbols, so <= 8
+        //      lookups from the root bring it to the right state), and the lowest lane with a hit applies it ----
         if (phase_mask & 16) {
             const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap / 2);
-            for (int m = lane; m < n_comp; m += 64) {
-                const uint32_t ent = s_queue[kQueueCap / 2 + m];
+            for (int m0 = 0; m0 < n_comp; m0 += 8) {
+                const int m = m0 + (lane >> 3), kk = lane & 7, k = 6 + kk;
+                const uint32_t ent = m < n_comp ? s_queue[kQueueCap / 2 + m] : 0u;
                 const int q = ent & 255, c = (ent >> 8) & 1, dir = (ent >> 9) & 3, tslot = (ent >> 11) & 3;
                 const int want = tslot == 0 ? 5 : tslot == 1 ? 4 : 3;
                 const int x = q % 15, y = q / 15, stride = dir_stride(dir);
-                // the line through q in this direction: its word, q's position on it, its length
-                const int diag = x - y + 14, anti = x + y;
-                const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
-                const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
-                const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
-                // six '?' | cells | six '?', then the 13 symbols starting six before q, kept shifted left by 2 as in phase 1
-                const uint64_t syms = ((0xAAAull | (static_cast<uint64_t>(s_lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at)) << 2;
-                uint32_t* opp = s_scores + (c ? 2 : 1) * kCells;
-                uint32_t cur = static_cast<uint32_t>(syms), tw = 0;
-                bool found = false;
-                for (int k = 0; k < 13; ++k) {
-                    const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
-                    cur >>= 2;
-                    tw = *reinterpret_cast<const uint32_t*>(lds_bytes + addr);
-                    // a match covering q ends at window index >= 6; the kinds bits say whether the record holds the wanted type
-                    if (k >= 6 && !found && ((gmk::dev_trans_kinds(tw) >> tslot) & 1u)) {
+                uint32_t hit_w0 = 0;
+                int hit_back = -1;
+                if (m < n_comp && kk < 7) {
+                    // the line through q in this direction: its word, q's position on it, its length
+                    const int diag = x - y + 14, anti = x + y;
+                    const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
+                    const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
+                    const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
+                    // six '?' | cells | six '?', then the 13 symbols starting six before q
+                    const uint64_t syms = (0xAAAull | (static_cast<uint64_t>(s_lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
+                    const int start = k > 7 ? k - 7 : 0;
+                    uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;      // kept shifted left by 2 as in phase 1
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(lds_bytes + ((tw & 0x3FFFu) | (cur & 12u)));
+                        cur >>= 2;
+                    }
+                    if ((gmk::dev_trans_kinds(tw) >> tslot) & 1u) {                     // the record holds the wanted type
                         const uint4 rec = s_rec[gmk::dev_trans_record(tw)];
-                        found = try_counter_cells(rec.x, k, want, q, stride, opp);
-                        if (!found && rec.z) found = try_counter_cells(rec.z, k, want, q, stride, opp);
+                        hit_back = counter_match(rec.x, k, want);
+                        hit_w0 = rec.x;
+                        if (hit_back < 0) { hit_back = counter_match(rec.z, k, want); hit_w0 = rec.z; }
                     }
                 }
+                const unsigned long long hits = __ballot(hit_back >= 0);
+                const uint32_t mine = static_cast<uint32_t>(hits >> (lane & ~7)) & 0xFFu;
+                if (hit_back >= 0 && (mine & ((1u << kk) - 1u)) == 0u) add_counter_cells(hit_w0, hit_back, q, stride, s_scores + (c ? 2 : 1) * kCells);
             }
         }
         wave_phase_fence();
