@@ -197,19 +197,22 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             v = (v | (v << 3)) & 0x11111111u;
             if (i < 90) s_nib[18 + i] = v;
         }
-        if (lane < 15) {                                            // lane y owns row y: a stone turns its cell's blank (3) into black (0) or white (1)
-            const int y = lane;                                     // in the four lines through it: one XOR each
-            atomicAdd(&s_misc[0], static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16));
+        if (lane < 15) atomicAdd(&s_misc[0], static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16));
+        {
+            // a stone turns its cell's blank (3) into black (0) or white (1) in the four lines through it: one XOR each.
+            // Four lanes share a row (cells 0-3, 4-7, 8-11, 12-14), so the loop runs as long as the fullest quarter row.
+            const int y = lane >> 2, part = lane & 3;
+            const uint32_t row = __shfl(my_row, min(y, 14));
             uint32_t row_sym = 0;
-            for (uint32_t m = (my_row | (my_row >> 16)) & 0x7FFFu; m; m &= m - 1u) {
+            for (uint32_t m = lane < 60 ? (row | (row >> 16)) & (0xFu << (4 * part)) & 0x7FFFu : 0u; m; m &= m - 1u) {
                 const int x = __ffs(m) - 1;
-                const uint32_t code = ((my_row >> x) & 1u) ? 3u : 2u;
+                const uint32_t code = ((row >> x) & 1u) ? 3u : 2u;
                 row_sym |= code << (2 * x);
                 atomicXor(&s_lines[kColBase + x], code << (2 * y));
                 atomicXor(&s_lines[kDiagBase + x - y + 14], code << (2 * min(x, y)));
                 atomicXor(&s_lines[kAntiBase + x + y], code << (2 * min(14 - x, y)));
             }
-            s_lines[y] = 0x3FFFFFFFu ^ row_sym;
+            if (row_sym) atomicXor(&s_lines[y], row_sym);
         }
         wave_phase_fence();
 
