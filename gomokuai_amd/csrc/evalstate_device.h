@@ -405,19 +405,20 @@ __device__ __forceinline__ void reset_state(const Ctx& c) {
     wave_phase_fence();
 }
 
-// Evaluator::applyMove (Pattern.cpp:310-313): ignored when the game is over or the cell is taken
-__device__ __forceinline__ void apply_move(const Ctx& c, int mv) {
-    const int32_t* meta = reinterpret_cast<const int32_t*>(c.st + oMeta);
-    const int cur = meta[1];
-    const bool empty = mv >= 0 && mv < kCells && ((c.st[oLines + mv / 15] >> (2 * (mv % 15))) & 3u) == 3u;
-    if (cur != 0 && empty) update_move(c, mv, cur);
-}
-
-// Evaluator::revertMove(1) (Pattern.cpp:337-342)
-__device__ __forceinline__ void revert_move(const Ctx& c) {
+// One step of an evaluator script: Evaluator::applyMove(mv) for mv >= 0 (Pattern.cpp:310-313: ignored when the game is
+// over or the cell is taken), Evaluator::revertMove(1) for mv == kRevert (Pattern.cpp:337-342), nothing otherwise.
+// update_move is a lot of code (~20 KB): every kernel calls it through this one function, from ONE place in a loop, so
+// that it exists once and the kernel stays inside the instruction cache.
+constexpr int kRevert = -2;
+__device__ __forceinline__ void evaluator_step(const Ctx& c, int mv) {
     const int32_t* meta = reinterpret_cast<const int32_t*>(c.st + oMeta);
     const uint8_t* record = reinterpret_cast<const uint8_t*>(c.st + oRecord);
-    if (meta[0] > 0) update_move(c, record[meta[0] - 1], 0);
+    const int n = meta[0], cur = meta[1];
+    int move = mv, src = cur;
+    bool go;
+    if (mv == kRevert) { go = n > 0; move = go ? record[n - 1] : 0; src = 0; }
+    else go = mv >= 0 && mv < kCells && cur != 0 && ((c.st[oLines + mv / 15] >> (2 * (mv % 15))) & 3u) == 3u;
+    if (go) update_move(c, move, src);
 }
 
 // the state of a fresh Evaluator, for the host-side resets

@@ -39,8 +39,7 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
     if (prof && lane < 16) st[kStateWords + kScratchWords + lane] = 0u;
     for (int m = 0; m < moves_per_game; ++m) {
         const int mv = moves[static_cast<size_t>(game) * moves_per_game + m];
-        if (mv >= 0) apply_move(c, mv);
-        else if (mv == -2) revert_move(c);
+        evaluator_step(c, mv);                                  // >= 0 apply, -2 revert, -1 nothing
         wave_phase_fence();
     }
     uint4* dst = reinterpret_cast<uint4*>(states + static_cast<size_t>(game) * kStateWords);

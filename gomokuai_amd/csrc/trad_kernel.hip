@@ -17,6 +17,7 @@
 // independent loads, the next level's issued before the current one is reduced.  Float reductions use one fixed
 // order (sum225, the same as oracle/go_trad.c); PUCB and tanh are evaluated in double like the reference.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -41,7 +42,7 @@ struct TradHeader {                              // 64 B per game in HBM
                                                  // fresh: 1 = new root + evaluator sync, 2 = the tree was re-rooted (kept): evaluator sync only
     uint32_t playouts_done, root_black, pad0, pad1;
     unsigned long long evaluator_updates, pad2;
-    uint32_t pad3[4];
+    uint32_t prof[4];                            // GMK_TRAD_PROFILE: shader clocks (>> 10) in select + evaluator moves, simulate + expand, backup, all
 };
 static_assert(sizeof(TradHeader) == 64, "TradHeader layout");
 
@@ -59,15 +60,53 @@ struct TradParams {
     const uint32_t* g_records;
     int trans_words, record_words;
     int n_games, cap, playouts;
+    int profile;                                 // diagnostic runs only
     double c_puct;
 };
 
+// lane i of a 16-lane row reads lane i + N of the same row (DPP row_shl; 0 beyond the row)
+template <int N>
+__device__ __forceinline__ float row_down(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
+}
+
+// the same for 64-bit and unsigned values; a lane without a source inside its row keeps its own value
+template <int N>
+__device__ __forceinline__ double row_down_keep(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xF, 0xF, false));
+}
+template <int N>
+__device__ __forceinline__ uint32_t row_down_keep(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x100 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// wave-wide maximum of doubles that are never NaN / minimum of unsigned values: DPP inside the rows, the four row leaders by readlane
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, row_down_keep<8>(v)); v = fmax(v, row_down_keep<4>(v)); v = fmax(v, row_down_keep<2>(v)); v = fmax(v, row_down_keep<1>(v));
+    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+    v = min(v, row_down_keep<8>(v)); v = min(v, row_down_keep<4>(v)); v = min(v, row_down_keep<2>(v)); v = min(v, row_down_keep<1>(v));
+    const uint32_t a = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 0)), b = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 16));
+    const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 32)), d = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
+    return min(min(a, b), min(c, d));
+}
+
 // the one summation order (oracle/go_trad.c: sum225): lane l first adds its cells l, l+64, l+128, l+192 in that order
-// (done by the caller into `p`), then a binary tree over the lanes; every lane gets the result
+// (done by the caller into `p`), then a binary tree inside every row of 16 lanes (offsets 8, 4, 2, 1: four DPP adds), then
+// (row 0 + row 1) + (row 2 + row 3); every lane gets the result
 __device__ __forceinline__ float tree_sum(float p) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) p += __shfl_down(p, s);
-    return __shfl(p, 0);
+    p += row_down<8>(p);
+    p += row_down<4>(p);
+    p += row_down<2>(p);
+    p += row_down<1>(p);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 struct Cells {                                   // a per-cell float vector: lane l holds cells l + 64 j
@@ -113,9 +152,19 @@ __device__ __forceinline__ Cells density_weight(const uint32_t* st, int black, i
 // Pattern::Type, otherwise 9 + Compound::Type.  All lanes walk the same automaton; the mask is per cell.
 __device__ __forceinline__ void decisive_filter(const uint32_t* st, int cur_black, Cells& probs, int lane) {
     enum { S4, SL3, STo44, STo43, STo33, SEnd };
-    constexpr int kNext[2][6] = {{S4, STo44, SL3, STo43, STo33, SEnd}, {SL3, STo44, STo43, STo33, SEnd, SEnd}};
-    constexpr int kAnti[2][6] = {{1, 0, 1, 1, 1, 0}, {0, 1, 0, 0, 0, 1}};
+    // AutomataTable[anti][state] (Heuristic.hpp:103-107) as immediates: next state in nibble anti * 6 + state, next "anti" in
+    // bit anti * 6 + state (a table in memory would cost a dependent scalar load per step)
+    //   anti 0: {_4,1} {To44,0} {L3,1} {To43,1} {To33,1} {End,0}     anti 1: {L3,0} {To44,1} {To43,0} {To33,0} {End,0} {End,1}
+    constexpr unsigned long long kNextNibbles = 0x554321543120ull;
+    constexpr uint32_t kAntiBits = 0x89Du;
     int state = S4, anti = 0;
+    // the totals the automaton looks at: pattern types 4..7 and the three compound types (one round of LDS reads)
+    uint32_t totals[12];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) totals[i] = i >= 4 ? st[oPdist + 225 * 8 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) totals[9 + i] = st[oCdist + 225 * 3 + i];
+    totals[8] = 0u;
     while (state != SEnd) {
         const uint32_t black = anti ? cur_black ^ 1 : cur_black;
         // the std::deque as 16-bit entries of one register: pattern | black << 8, entry k at bits 16 k
@@ -126,7 +175,9 @@ __device__ __forceinline__ void decisive_filter(const uint32_t* st, int cur_blac
         else { cands = static_cast<uint32_t>(9 + (STo33 - state)) | black << 8; n = 1; }
         for (; head < n; ++head) {
             const uint32_t pattern = (cands >> (16 * head)) & 0xFFu, pb = (cands >> (16 * head + 8)) & 1u;
-            const uint32_t total = pattern < 9 ? st[oPdist + 225 * 8 + pattern] : st[oCdist + 225 * 3 + pattern - 9];
+            uint32_t total = 0;                                  // totals[pattern], without a dynamically indexed array
+#pragma unroll
+            for (int i = 4; i < 12; ++i) total = pattern == static_cast<uint32_t>(i) ? totals[i] : total;
             if ((total >> (16 * pb)) & 0xFFFFu) {
                 if (anti && state != S4) { cands |= static_cast<uint64_t>(4u | (pb ^ 1u) << 8) << (16 * n); ++n; }       // the own DeadThree counts when answering
                 break;
@@ -147,9 +198,9 @@ __device__ __forceinline__ void decisive_filter(const uint32_t* st, int cur_blac
             normalize225(probs, lane);
             state = SEnd;
         } else {
-            const int s = kNext[anti][state], a = kAnti[anti][state];
-            state = s;
-            anti = a;
+            const int at = anti * 6 + state;
+            state = static_cast<int>((kNextNibbles >> (4 * at)) & 15u);
+            anti = static_cast<int>((kAntiBits >> at) & 1u);
         }
     }
 }
@@ -167,31 +218,6 @@ struct Game {
     int cached, init;
     unsigned long long updates;
 };
-
-// Heuristic::CachedApplyMove (Heuristic.hpp:165-189)
-__device__ __forceinline__ void cached_apply_move(Game& g, int move) {
-    const int32_t* meta = reinterpret_cast<const int32_t*>(g.c.st + oMeta);
-    const uint8_t* record = reinterpret_cast<const uint8_t*>(g.c.st + oRecord);
-    const int nrec = meta[0];
-    if (g.cached == nrec || record[g.cached] != move) {
-        if (nrec - g.cached > g.cached) {                       // too little is cached: rebuild from the empty board
-            if (g.c.lane < kRecordWords) reinterpret_cast<uint32_t*>(g.record_copy)[g.c.lane] = g.c.st[oRecord + g.c.lane];
-            wave_phase_fence();
-            reset_state(g.c);
-            for (int i = 0; i < g.cached; ++i) { apply_move(g.c, g.record_copy[i]); wave_phase_fence(); }
-            g.updates += g.cached;
-        } else {
-            for (int k = nrec - g.cached; k > 0; --k) { revert_move(g.c); wave_phase_fence(); }
-            g.updates += nrec - g.cached;
-        }
-        apply_move(g.c, move);
-        wave_phase_fence();
-        g.updates += 1;
-        if (g.cached < meta[0]) ++g.cached;
-    } else {
-        ++g.cached;
-    }
-}
 
 __global__ __launch_bounds__(kThreads)
 void trad_playouts_kernel(TradParams prm) {
@@ -230,32 +256,27 @@ void trad_playouts_kernel(TradParams prm) {
     const uint32_t fresh_mode = hdr->fresh;
     const bool fresh = fresh_mode == 1u;
 
+    // The evaluator's work of one step is a script: take `n_revert` moves back, then apply script[0 .. n_apply) (bytes in LDS).
+    // It runs at ONE place in the loop below (evaluator_step is ~20 KB of code); iteration -1 of that loop is
+    // Policy::prepare + TraditionalPolicy::prepare, i.e. Evaluator::syncWithBoard (Pattern.cpp:356-368).
+    uint8_t* script = g.record_copy;
+    int n_revert = 0, n_apply = 0;
+    bool rebuild = false;
+    const int n_position = fresh_mode != 0u ? prm.lens[game] : 0;
     if (fresh_mode != 0u) {
-        // Policy::prepare + TraditionalPolicy::prepare: Evaluator::syncWithBoard (Pattern.cpp:356-368), then a fresh root
+        // syncWithBoard: back to the first move that differs (or to the position's length), then the rest of the position
         const uint8_t* mv = prm.moves + static_cast<size_t>(game) * 225;
-        const int n = prm.lens[game];
-        int i = 0;
-        for (; i < n; ++i) {
-            if (i < meta[0]) {
-                if (record[i] == mv[i]) continue;
-                for (int k = meta[0] - i; k > 0; --k) { revert_move(g.c); wave_phase_fence(); ++g.updates; }
-            }
-            apply_move(g.c, mv[i]);
-            wave_phase_fence();
-            ++g.updates;
-        }
-        for (int k = meta[0] - i; k > 0; --k) { revert_move(g.c); wave_phase_fence(); ++g.updates; }
-        g.init = n;
-        root_black = n & 1;                                     // the player of the last move
-        if (fresh) {
-            if (lane == 0) {
-                g.stat[0] = make_uint2(0u, 0u);
-                g.info[0] = make_uint2(kNoParent | ((n ? mv[n - 1] : 255u) << 24), __float_as_uint(1.0f));
-                g.link[0] = 0u;
-            }
-            n_nodes = 1;
-            status = 0;
-        }
+        const int have = meta[0], common = min(have, n_position);
+        int i0 = common;
+        for (int i = lane; i < common; i += 64) if (record[i] != mv[i]) i0 = min(i0, i);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) i0 = min(i0, __shfl_xor(i0, sft));
+        n_revert = have - i0;
+        n_apply = n_position - i0;
+        for (int j = lane; j < n_apply; j += 64) script[j] = mv[i0 + j];
+        g.updates += static_cast<unsigned long long>(n_revert + n_apply);
+        g.init = n_position;
+        root_black = n_position & 1;                            // the player of the last move
     } else {
         g.init = static_cast<int>(hdr->init_acts);
     }
@@ -283,20 +304,80 @@ void trad_playouts_kernel(TradParams prm) {
         return L;
     };
 
-    for (int it = 0; it < prm.playouts && !(status & 1u); ++it) {
-        // ---- select: always the first child in the current order (RAVE::Select); the evaluator follows ----
-        int depth = valid;
-        for (int d = 1; d <= depth; ++d) cached_apply_move(g, static_cast<int>(g.path_node[d] >> 24));
-        uint32_t node = g.path_node[depth] & 0xFFFFFFu, link = g.path_link[depth];
-        while (link >> 24) {
-            const uint2 rec = g.front[node];
-            node = rec.x & 0xFFFFFFu;
-            link = rec.y;
-            ++depth;
-            if (lane == 0) { g.path_node[depth] = rec.x; g.path_link[depth] = link; }
-            cached_apply_move(g, static_cast<int>(rec.x >> 24));
+    unsigned long long prof_sel = 0, prof_sim = 0, prof_back = 0, prof_t0 = 0, prof_all = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;
+    for (int it = fresh_mode != 0u ? -1 : 0; it < prm.playouts && !(status & 1u); ++it) {
+        if (prm.profile) prof_t0 = __builtin_amdgcn_s_memtime();
+        int depth = 0;
+        uint32_t node = 0, link = 0;
+        if (it >= 0) {
+            // ---- select: always the first child in the current order (RAVE::Select): the tree walk needs no evaluator ----
+            depth = valid;
+            node = g.path_node[depth] & 0xFFFFFFu;
+            link = g.path_link[depth];
+            while (link >> 24) {
+                const uint2 rec = g.front[node];
+                node = rec.x & 0xFFFFFFu;
+                link = rec.y;
+                ++depth;
+                if (lane == 0) { g.path_node[depth] = rec.x; g.path_link[depth] = link; }
+            }
+            wave_phase_fence();
+            // ---- Heuristic::CachedApplyMove (Heuristic.hpp:165-189) for the moves of the path: the ones the evaluator's record
+            //      already holds are skipped; at the first one it does not hold, it is rolled back to there (or rebuilt from the
+            //      empty board when less than half of it would survive), and everything from there on is applied ----
+            const int nrec = meta[0];
+            int d0 = depth + 1;
+            for (int d = 1 + lane; d <= depth; d += 64) {
+                const int at = g.init + d - 1;
+                if (at >= nrec || record[at] != (g.path_node[d] >> 24)) d0 = min(d0, d);
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) d0 = min(d0, __shfl_xor(d0, sft));
+            n_revert = n_apply = 0;
+            rebuild = false;
+            if (d0 <= depth) {
+                const int c0 = g.init + d0 - 1, tail = depth - d0 + 1;
+                if (nrec - c0 > c0) {                           // too little is cached: rebuild from the empty board
+                    rebuild = true;
+                    for (int j = lane; j < c0; j += 64) script[j] = record[j];
+                    for (int j = lane; j < tail; j += 64) script[c0 + j] = static_cast<uint8_t>(g.path_node[d0 + j] >> 24);
+                    n_apply = c0 + tail;
+                    g.updates += static_cast<unsigned long long>(c0);
+                } else {
+                    n_revert = nrec - c0;
+                    for (int j = lane; j < tail; j += 64) script[j] = static_cast<uint8_t>(g.path_node[d0 + j] >> 24);
+                    n_apply = tail;
+                    g.updates += static_cast<unsigned long long>(n_revert);
+                }
+                g.updates += static_cast<unsigned long long>(tail);
+            } else {
+                g.cached = g.init + depth;
+            }
+            wave_phase_fence();
         }
-        wave_phase_fence();
+        // ---- the evaluator follows: the one place where moves are applied and taken back ----
+        if (rebuild) reset_state(g.c);
+        for (int i = 0; i < n_revert + n_apply; ++i) {
+            evaluator_step(g.c, i < n_revert ? kRevert : static_cast<int>(script[i - n_revert]));
+            wave_phase_fence();
+        }
+        if (it < 0) {                                           // the prologue ends here: a fresh root where one was asked for
+            if (fresh) {
+                if (lane == 0) {
+                    g.stat[0] = make_uint2(0u, 0u);
+                    g.info[0] = make_uint2(kNoParent | ((n_position ? prm.moves[static_cast<size_t>(game) * 225 + n_position - 1] : 255u) << 24), __float_as_uint(1.0f));
+                    g.link[0] = 0u;
+                    g.path_link[0] = 0u;
+                }
+                n_nodes = 1;
+                status = 0;
+            }
+            n_revert = n_apply = 0;
+            wave_phase_fence();
+            continue;
+        }
+        if (n_revert + n_apply > 0 || rebuild) g.cached = meta[0];      // from the first move it did not hold on, the record follows the path
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
         int path_len = depth;                                   // deepest level with a known node
 
         // ---- TraditionalPolicy::checkGameEnd -> Evaluator::checkGameEnd (Pattern.cpp:344-354) ----
@@ -378,6 +459,7 @@ void trad_playouts_kernel(TradParams prm) {
         }
         wave_phase_fence();
         if (status & 1u) break;
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sim += t - prof_t0; prof_t0 = t; }
 
         // ---- RAVE::BackPropogate<false> (MonteCarlo.hpp:160-184), leaf to root ----
         int swap_level = -1;
@@ -405,13 +487,9 @@ void trad_playouts_kernel(TradParams prm) {
                 // the reference scans the children in their current order and keeps the first maximum
                 if (score > best_score || (score == best_score && cur.co[k] < best_ord)) { best_score = score; best_ord = cur.co[k]; }
             }
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) {
-                const double os = __shfl_down(best_score, s);
-                const uint32_t oo = __shfl_down(best_ord, s);
-                if (os > best_score || (os == best_score && oo < best_ord)) { best_score = os; best_ord = oo; }
-            }
-            best_ord = __shfl(best_ord, 0);
+            // the best score of the wave, then the first child (in the current order) that reaches it
+            const double top = wave_max(best_score);
+            best_ord = wave_min(best_score == top ? best_ord : 0xFFFFFFFFu);
             if (n && best_ord != 0xFFFFFFFFu && best_ord != 0u) {                      // the best child moves to the front: it swaps places with the first one
                 uint2 mine = make_uint2(0u, 0u);
                 bool owner = false;
@@ -444,6 +522,8 @@ void trad_playouts_kernel(TradParams prm) {
         }
         wave_phase_fence();
 
+        if (prm.profile) prof_back += __builtin_amdgcn_s_memtime() - prof_t0;
+
         // ---- Heuristic::CachedRevertMove (Heuristic.hpp:192-200) ----
         if (meta[0] != g.cached) status |= 4u;                  // the reference would take stones off the inner board only: not reproduced
         g.cached = g.init;
@@ -459,6 +539,10 @@ void trad_playouts_kernel(TradParams prm) {
         hdr->root_black = static_cast<uint32_t>(root_black);
         hdr->playouts_done = (fresh ? 0u : hdr->playouts_done) + static_cast<uint32_t>(prm.playouts);
         hdr->evaluator_updates += g.updates;
+        if (prm.profile) {
+            hdr->prof[0] = static_cast<uint32_t>(prof_sel >> 10); hdr->prof[1] = static_cast<uint32_t>(prof_sim >> 10);
+            hdr->prof[2] = static_cast<uint32_t>(prof_back >> 10); hdr->prof[3] = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - prof_all) >> 10);
+        }
     }
     uint4* dst = reinterpret_cast<uint4*>(prm.states + static_cast<size_t>(game) * kStateWords);
     const uint4* src = reinterpret_cast<const uint4*>(g.c.st);
@@ -699,9 +783,20 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     prm.moves = t->d_moves; prm.lens = t->d_lens;
     prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
+    static const bool profile = std::getenv("GMK_TRAD_PROFILE") != nullptr;
+    prm.profile = profile ? 1 : 0;
     const int grid = (t->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
     hipLaunchKernelGGL(trad_playouts_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), prm);
     GMK_HIP_CHECK(hipGetLastError());
+    if (profile) {                                              // share of a search spent per stage, mean over games
+        std::vector<TradHeader> hdr(static_cast<size_t>(t->n_games));
+        GMK_HIP_CHECK(hipDeviceSynchronize());
+        GMK_HIP_CHECK(hipMemcpy(hdr.data(), t->d_hdr, hdr.size() * sizeof(TradHeader), hipMemcpyDeviceToHost));
+        double sum[4] = {};
+        for (const TradHeader& h : hdr) for (int k = 0; k < 4; ++k) sum[k] += h.prof[k];
+        std::fprintf(stderr, "[GMK_TRAD_PROFILE] select + evaluator moves %.1f %%, simulate + expand %.1f %%, backup %.1f %% of the kernel's clocks\n",
+                     100 * sum[0] / sum[3], 100 * sum[1] / sum[3], 100 * sum[2] / sum[3]);
+    }
     return GMK_OK;
 }
 

@@ -44,16 +44,18 @@ void go__gamma_draws(unsigned seed, float alpha, int n, float *out);     /* go_s
 static int group1(int player) { return player == GO_BLACK; }
 static int group2(int favour, int perspective) { return ((favour == GO_BLACK) << 1) | (perspective == GO_BLACK); }
 
-/* the one summation order of this file and of the kernel: 64 strided partial sums, then a binary tree */
+/* the one summation order of this file and of the kernel: 64 strided partial sums; a binary tree inside every group of
+   16 (offsets 8, 4, 2, 1: one DPP row on the GPU); then (group 0 + group 1) + (group 2 + group 3) */
 static float sum225(const float *x) {
     float p[64];
     for (int l = 0; l < 64; ++l) {
         p[l] = x[l];
         for (int k = 1; l + 64 * k < GO_N; ++k) p[l] += x[l + 64 * k];
     }
-    for (int s = 32; s > 0; s >>= 1)
-        for (int l = 0; l < s; ++l) p[l] += p[l + s];
-    return p[0];
+    for (int r = 0; r < 4; ++r)
+        for (int s = 8; s > 0; s >>= 1)
+            for (int l = 0; l < s; ++l) p[16 * r + l] += p[16 * r + l + s];
+    return (p[0] + p[16]) + (p[32] + p[48]);
 }
 
 /* MatrixBase::normalized() / normalize(), Eigen 3.3+ */
