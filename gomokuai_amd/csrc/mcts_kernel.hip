@@ -78,17 +78,23 @@ constexpr int kColBase = 16, kDiagBase = 32, kAntiBase = 61;
 // (Board::checkGameEnd, Game.cpp:88-136) is a run of five in the mover's half of one of those four words.
 __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int stride_log2, int to_move, int stones,
                               uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    uint32_t cells_lo = 0, cells_hi = 0;                              // the next eight draws as bytes y | x << 4
     for (uint32_t k = 0;; ++k) {
         if ((k & 7u) == 0u) {                                         // one Philox block = eight 16-bit draws
             const gmk::Philox4 p = gmk::philox4x32_10(game_id, playout, c2, k >> 3, k0, k1);
-            w0 = p.v[0]; w1 = p.v[1]; w2 = p.v[2]; w3 = p.v[3];
+            // uniform cell draw of Board::getRandomMove (Game.cpp:64-73) for all eight at once: eight independent chains here
+            // instead of one on the critical path of every move
+            cells_lo = cells_hi = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t word = p.v[j >> 1], half = (j & 1) ? (word >> 16) : (word & 0xFFFFu);
+                const uint32_t r = (half * 225u) >> 16, yy = r / 15u, byte = yy | ((r - 15u * yy) << 4);
+                if (j < 4) cells_lo |= byte << (8 * j); else cells_hi |= byte << (8 * (j - 4));
+            }
         }
-        const uint32_t word = (k & 4u) ? ((k & 2u) ? w3 : w2) : ((k & 2u) ? w1 : w0);
-        const uint32_t half = (k & 1u) ? (word >> 16) : (word & 0xFFFFu);
-        const uint32_t r = (half * 225u) >> 16;                       // uniform cell draw of Board::getRandomMove (Game.cpp:64-73)
-        int y = static_cast<int>(r / 15u);
-        int x = static_cast<int>(r - 15u * static_cast<uint32_t>(y));
+        const uint32_t cell_byte = (((k & 4u) ? cells_hi : cells_lo) >> (8u * (k & 3u))) & 0xFFu;
+        int y = static_cast<int>(cell_byte & 15u);
+        int x = static_cast<int>(cell_byte >> 4);
         uint32_t rw = lines[y << stride_log2];
         uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
         while (!open) {                                               // linear probe with wrap
