@@ -79,6 +79,7 @@ constexpr int kColBase = 16, kDiagBase = 32, kAntiBase = 61;
 __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int stride_log2, int to_move, int stones,
                               uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
     uint32_t cells_lo = 0, cells_hi = 0;                              // the next eight draws as bytes y | x << 4
+    uint32_t stone = to_move > 0 ? 1u : 0x10000u, halves = to_move > 0 ? 0x05040100u : 0x07060302u;
     for (uint32_t k = 0;; ++k) {
         if ((k & 7u) == 0u) {                                         // one Philox block = eight 16-bit draws
             const gmk::Philox4 p = gmk::philox4x32_10(game_id, playout, c2, k >> 3, k0, k1);
@@ -103,22 +104,22 @@ __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int s
             open = ~(rw | (rw >> 16)) & 0x7FFFu;
         }
         x = __ffs(open) - 1;
-        const int shift = to_move > 0 ? 0 : 16;
         uint32_t* col = lines + ((kColBase + x) << stride_log2);
         uint32_t* dia = lines + ((kDiagBase + x - y + 14) << stride_log2);
         uint32_t* ant = lines + ((kAntiBase + x + y) << stride_log2);
-        const uint32_t r_new = rw | (1u << (x + shift));
-        const uint32_t c_new = *col | (1u << (y + shift));
-        const uint32_t d_new = *dia | (1u << (min(x, y) + shift));
-        const uint32_t a_new = *ant | (1u << (min(14 - x, y) + shift));
+        const uint32_t r_new = rw | (stone << x);
+        const uint32_t c_new = *col | (stone << y);
+        const uint32_t d_new = *dia | (stone << min(x, y));
+        const uint32_t a_new = *ant | (stone << min(14 - x, y));
         lines[y << stride_log2] = r_new; *col = c_new; *dia = d_new; *ant = a_new;
         ++stones;
-        // two 15-bit lines per register (bit 15 and 31 are gaps), one run test each
-        const uint32_t rc = ((r_new >> shift) & 0x7FFFu) | (((c_new >> shift) & 0x7FFFu) << 16);
-        const uint32_t da = ((d_new >> shift) & 0x7FFFu) | (((a_new >> shift) & 0x7FFFu) << 16);
+        // the mover's halves of two line words side by side (bits 15 and 31 are gaps), one run test each
+        const uint32_t rc = __builtin_amdgcn_perm(c_new, r_new, halves), da = __builtin_amdgcn_perm(a_new, d_new, halves);
         if (run_of_five(rc) || run_of_five(da)) return to_move;
         if (stones == 225) return 0;
         to_move = -to_move;
+        stone ^= 0x10001u;                                            // bit 0 for black, bit 16 for white
+        halves ^= 0x02020202u;                                        // byte selector: the low halves for black, the high halves for white
     }
 }
 
