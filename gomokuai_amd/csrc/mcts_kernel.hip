@@ -115,8 +115,8 @@ __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int s
         ++stones;
         // the mover's halves of two line words side by side (bits 15 and 31 are gaps), one run test each
         const uint32_t rc = __builtin_amdgcn_perm(c_new, r_new, halves), da = __builtin_amdgcn_perm(a_new, d_new, halves);
-        if (run_of_five(rc) || run_of_five(da)) return to_move;
-        if (stones == 225) return 0;
+        const uint32_t fives = (rc & (rc >> 1) & (rc >> 2) & (rc >> 3) & (rc >> 4)) | (da & (da >> 1) & (da >> 2) & (da >> 3) & (da >> 4));
+        if (fives != 0u || stones == 225) return fives ? to_move : 0;   // one exit test per move
         to_move = -to_move;
         stone ^= 0x10001u;                                            // bit 0 for black, bit 16 for white
         halves ^= 0x02020202u;                                        // byte selector: the low halves for black, the high halves for white
