@@ -80,6 +80,10 @@ __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int s
                               uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
     uint32_t cells_lo = 0, cells_hi = 0;                              // the next eight draws as bytes y | x << 4
     uint32_t stone = to_move > 0 ? 1u : 0x10000u, halves = to_move > 0 ? 0x05040100u : 0x07060302u;
+    // All rollouts of the wavefront step together (k is the same for all of them); a finished one is switched off by `live`
+    // and the loop ends on a wave-uniform test, so the back edge is a scalar branch instead of per-lane exec bookkeeping.
+    bool live = true;
+    int result = 0;
     for (uint32_t k = 0;; ++k) {
         if ((k & 7u) == 0u) {                                         // one Philox block = eight 16-bit draws
             const gmk::Philox4 p = gmk::philox4x32_10(game_id, playout, c2, k >> 3, k0, k1);
@@ -93,6 +97,7 @@ __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int s
                 if (j < 4) cells_lo |= byte << (8 * j); else cells_hi |= byte << (8 * (j - 4));
             }
         }
+        if (live) {
         const uint32_t cell_byte = (((k & 4u) ? cells_hi : cells_lo) >> (8u * (k & 3u))) & 0xFFu;
         int y = static_cast<int>(cell_byte & 15u);
         int x = static_cast<int>(cell_byte >> 4);
@@ -116,10 +121,12 @@ __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int s
         // the mover's halves of two line words side by side (bits 15 and 31 are gaps), one run test each
         const uint32_t rc = __builtin_amdgcn_perm(c_new, r_new, halves), da = __builtin_amdgcn_perm(a_new, d_new, halves);
         const uint32_t fives = (rc & (rc >> 1) & (rc >> 2) & (rc >> 3) & (rc >> 4)) | (da & (da >> 1) & (da >> 2) & (da >> 3) & (da >> 4));
-        if (fives != 0u || stones == 225) return fives ? to_move : 0;   // one exit test per move
+        if (fives != 0u || stones == 225) { result = fives ? to_move : 0; live = false; }     // one exit test per move
         to_move = -to_move;
         stone ^= 0x10001u;                                            // bit 0 for black, bit 16 for white
         halves ^= 0x02020202u;                                        // byte selector: the low halves for black, the high halves for white
+        }
+        if (__ballot(live) == 0ull) return result;
     }
 }
 
