@@ -150,24 +150,26 @@ __device__ inline void update_patterns(const Ctx& c, int move, int slot, int del
     const int n_dep = (w0 >> 8) & 7;
     // per scored blank: the flag fields of both views live in one word (one returning atomic starts them all), the score adds
     // need no answer; the second half of the flag updates follows once the answers are back
+    // No branches (this wave has nobody to hide them behind): an unused slot (all zero bits: the match's last cell) and the
+    // owner's view of a '^' piece update nothing -- OR / AND with an empty mask, add 0.
     uint32_t* words[4];
     uint32_t lowers[4], olds[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        if (d >= n_dep) break;
         const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
         const int cell = last_cell - static_cast<int>(f & 7u) * stride;
+        const bool blank = (f & 8u) != 0u;
         words[d] = &c.st[oPdist + cell * 8 + type];
-        lowers[d] = 1u << ((4 * group2(fav, fav ^ 1) + dir) * 2);                      // '_' and '^': the opponent's view
-        if (f & 8u) lowers[d] |= 1u << ((4 * group2(fav, fav) + dir) * 2);             // '_': the owner's view too
+        lowers[d] = (d < n_dep ? 1u << ((4 * group2(fav, fav ^ 1) + dir) * 2) : 0u) |  // '_' and '^': the opponent's view
+                    (blank ? 1u << ((4 * group2(fav, fav) + dir) * 2) : 0u);           // '_': the owner's view too
         olds[d] = set_flags_begin(words[d], delta, lowers[d]);
-        if (f & 8u) atomicAdd(&scores[group2(fav, fav) * kCells + cell], static_cast<uint32_t>(score));
-        atomicAdd(&scores[group2(fav, fav ^ 1) * kCells + cell], static_cast<uint32_t>(score));
+        atomicAdd(&scores[group2(fav, fav) * kCells + cell], blank ? static_cast<uint32_t>(score) : 0u);
+        atomicAdd(&scores[group2(fav, fav ^ 1) * kCells + cell], d < n_dep ? static_cast<uint32_t>(score) : 0u);
     }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        if (d >= n_dep) break;
-        set_flags_end(words[d], delta, lowers[d], olds[d]);
+        if (delta == 1) atomicOr(words[d], (olds[d] & lowers[d]) << 1);
+        else atomicAnd(words[d], ~(lowers[d] & ~(olds[d] >> 1)));
     }
 }
 
