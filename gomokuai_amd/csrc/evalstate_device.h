@@ -108,12 +108,14 @@ __device__ inline void match_patterns_both(const Ctx& c, int move, uint32_t new_
         uint64_t syms = window_symbols(c.st + oLines, move, dir);
         if (w) syms = (syms & ~(3ull << 12)) | (static_cast<uint64_t>(new_sym) << 12);
         const int start = k > 7 ? k - 7 : 0;
-        uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;        // symbol * 4 in bits 2..3, as in eval_kernel.hip
+        uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0, tw7 = 0;        // symbol * 4 in bits 2..3, as in eval_kernel.hip
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
+        for (int i = 0; i < 8; ++i) {                             // eight lookups for everybody; the lane of index 6 stops after seven
+            if (i == 7) tw7 = tw;
+            tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
             cur >>= 2;
         }
+        if (k == 6) tw = tw7;
         const uint32_t rid = gmk::dev_trans_record(tw);
         if (rid) {
             uint32_t* out = c.scratch + (w * 4 + dir) * kResultCap * 2;
@@ -247,12 +249,14 @@ __device__ inline void apply_compound_items(const Ctx& c, int delta) {
             const int want = ct == 0 ? 5 : ct == 1 ? 4 : 3;
             const uint64_t syms = window_symbols(c.st + oLines, cell, cdir);
             const int start = k > 7 ? k - 7 : 0;
-            uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;
+            uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0, tw7 = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
+            for (int i = 0; i < 8; ++i) {                         // eight lookups for everybody; the lane of index 6 stops after seven
+                if (i == 7) tw7 = tw;
+                tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
                 cur >>= 2;
             }
+            if (k == 6) tw = tw7;
             if ((gmk::dev_trans_kinds(tw) >> ct) & 1u) {
                 const uint4 r = c.rec[gmk::dev_trans_record(tw)];
                 const uint32_t w0s[2] = {r.x, r.z};
