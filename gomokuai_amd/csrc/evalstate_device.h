@@ -375,6 +375,7 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     update_patterns(c, move, 0, -1);
     wave_phase_fence();
     prof_mark(c, 2, t_last);
+    // the stone itself (line words, move record, player to move) and the 7x7 block touch different words: one phase
     int block_colour;
     if (src != 0) {
         board_set(c, move, src > 0);
@@ -386,11 +387,9 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
         if (cur == 0) cur = (n % 2 == 0) ? 1 : -1;              // Board::revertMove: back from a finished game (Game.cpp:51-54)
         const int mover = -cur;                                 // the player whose stone is taken back
         board_set(c, move, mover > 0);
-        wave_phase_fence();
         if (c.lane == 0) { meta[0] = n - 1; meta[1] = mover; meta[2] = 0; }
         block_colour = mover > 0;
     }
-    wave_phase_fence();
     update_block(c, move, src != 0 ? 1 : -1, block_colour);
     wave_phase_fence();
     prof_mark(c, 3, t_last);
