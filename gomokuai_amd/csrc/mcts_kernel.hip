@@ -131,6 +131,27 @@ __device__ int random_rollout(uint32_t* lines /* [word << stride_log2] */, int s
 }
 
 // five or more through cell (x, y) for the colour in bits [shift, shift+15), from line words at lines[word * Stride]
+// Quarter-wave (one DPP row of 16 lanes) primitives for the select / expand phases: DPP moves cost an ALU cycle each where
+// a ds_bpermute shuffle is a ~100-cycle LDS round trip, and this kernel runs one wave per SIMD with nothing to hide it.
+template <int N>
+__device__ __forceinline__ void row_best(double& best, int& best_i) {   // rotate the row right by N lanes, keep the better
+    const int lo = __double2loint(best), hi = __double2hiint(best);
+    const double o = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x120 + N, 0xF, 0xF, false),
+                                      __builtin_amdgcn_update_dpp(lo, lo, 0x120 + N, 0xF, 0xF, false));
+    const int oi = __builtin_amdgcn_update_dpp(best_i, best_i, 0x120 + N, 0xF, 0xF, false);
+    const bool take = o > best || (o == best && oi < best_i);
+    best = take ? o : best;
+    best_i = take ? oi : best_i;
+}
+
+__device__ __forceinline__ int row_scan(int v) {                        // inclusive prefix sum over the row (row_shr, zero fill)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    return v;
+}
+
 template <int Stride>
 __device__ __forceinline__ bool five_on_lines(const uint32_t* lines, int x, int y, int shift) {
     const uint32_t rc = ((lines[y * Stride] >> shift) & 0x7FFFu) | (((lines[(kColBase + x) * Stride] >> shift) & 0x7FFFu) << 16);
@@ -218,12 +239,9 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                             if (score > best) { best = score; best_i = i; best_st = st[j]; }
                         }
                     }
-#pragma unroll
-                    for (int m = 8; m >= 1; m >>= 1) {               // first maximum wins (strict > in ascending order)
-                        const double o = __shfl_xor(best, m, 16);
-                        const int oi = __shfl_xor(best_i, m, 16);
-                        if (o > best || (o == best && oi < best_i)) { best = o; best_i = oi; }
-                    }
+                    // first maximum wins (strict > in ascending order): (score, -index) is a total order, so rotating the
+                    // row of 16 lanes by 8, 4, 2, 1 leaves the same winner in every lane - DPP moves, no LDS permute
+                    row_best<8>(best, best_i); row_best<4>(best, best_i); row_best<2>(best, best_i); row_best<1>(best, best_i);
                     bytes += static_cast<unsigned long long>(n_child) * 8ull;
                     cur = first + static_cast<uint32_t>(best_i);
                     // the statistics of the chosen child sit in the lane that scored it (children i = l16 mod 16)
@@ -234,12 +252,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     {
                         const uint32_t open = (l16 < 15) ? (~(row | (row >> 16)) & 0x7FFFu) : 0u;
                         const int mine = __popc(open);
-                        int incl = mine;
-#pragma unroll
-                        for (int d = 1; d < 16; d <<= 1) {
-                            const int t = __shfl_up(incl, d, 16);
-                            if (l16 >= d) incl += t;
-                        }
+                        const int incl = row_scan(mine);
                         const int skip = best_i - (incl - mine);
                         const bool owner = skip >= 0 && skip < mine;
                         uint32_t m = open;
@@ -317,13 +330,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     const uint32_t rw = s_leaf[gs][l16];
                     const uint32_t open = (l16 < 15) ? (~(rw | (rw >> 16)) & 0x7FFFu) : 0u;
                     const int mine = __popc(open);
-                    int before = mine;                               // inclusive scan over the 16 lanes
-#pragma unroll
-                    for (int d = 1; d < 16; d <<= 1) {
-                        const int t = __shfl_up(before, d, 16);
-                        if (l16 >= d) before += t;
-                    }
-                    before -= mine;
+                    const int before = row_scan(mine) - mine;         // exclusive scan over the 16 lanes
                     const uint32_t n_child = 225u - ply;
                     const uint32_t first = s_nodes[gs];
                     if (static_cast<size_t>(first) + n_child <= cap) {
