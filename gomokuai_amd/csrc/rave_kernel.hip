@@ -1,0 +1,344 @@
+// rave_kernel.hip -- K8: the PoolRAVE tree search on the device.
+//
+// PoolRAVEPolicy (core/lib/include/policies/PoolRAVE.h:7-52) = MCTS::playout (core/lib/src/MCTS.cpp:158-177) with
+//   select    RAVE::Select: the first child (core/lib/include/algorithms/MonteCarlo.hpp:149-152)
+//   simulate  defaultSimulate: Default::UniformProbs of the leaf, then ONE Default::RandomRollout whose moves stay on
+//             the board (PoolRAVE.h:29-48, MonteCarlo.hpp:37-47, 50-55)
+//   expand    Default::Expand without the legality check: one AMAFNode per empty cell (MonteCarlo.hpp:71-80, 113-122)
+//   backup    RAVE::BackPropogate<true> on the FINISHED board: every child of a path node whose move its player made
+//             anywhere later in the game takes the result into its all-moves-as-first statistics; the child with the
+//             best PUCB + HandSelect-weighted value moves to the front (MonteCarlo.hpp:124-184)
+// It shares the first-child tree of K6 (trad_tree.h: same arenas, same re-rooting, noise and statistics entry points,
+// plus 8 B of AMAF statistics per node) and the rollout of K3 (rollout_device.h, same Philox counter layout with
+// rollout number 0).  One wavefront per game, four games per workgroup, no workgroup barrier: the position as 92 line
+// words, the root position and the current path live in LDS (2.6 KB per game), the tree in HBM.  The rollout is a serial
+// chain and runs on one lane; everything that touches children (expand, the per-level reductions of backup) runs 64
+// children at a time, the next level's loads in flight while the current one is reduced.  PUCB and the weighting are
+// evaluated in double like the reference, the running means in float.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "capi_common.h"
+#include "rollout_device.h"
+#include "trad_tree.h"
+
+namespace {
+
+using namespace gmk::tree;
+using namespace gmk::rollout;
+
+constexpr int kWaves = 4;                        // games per workgroup
+constexpr int kPathCap = 228;                    // a path has at most 226 nodes
+constexpr int kLinePad = 96;
+constexpr int kPerGame = 2 * kLinePad + 2 * kPathCap;
+
+struct RaveParams {
+    TradArena a;
+    TradHeader* hdr;
+    const uint8_t* moves;                        // [n_games][225] the position of the root
+    const int32_t* lens;
+    int n_games, cap, playouts;
+    uint32_t seed_lo, seed_hi, first_game_id;
+    double c_puct;
+};
+
+__device__ __forceinline__ void wave_phase_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one stone into the four line words through its cell (the layout of rollout_device.h)
+__device__ __forceinline__ void place_stone(uint32_t* lines, uint32_t cell, uint32_t shift) {
+    const uint32_t y = cell / 15u, x = cell - 15u * y;
+    atomicOr(&lines[y], 1u << (x + shift));
+    atomicOr(&lines[kColBase + x], 1u << (y + shift));
+    atomicOr(&lines[kDiagBase + x - y + 14], 1u << (min(x, y) + shift));
+    atomicOr(&lines[kAntiBase + x + y], 1u << (min(14u - x, y) + shift));
+}
+
+__global__ __launch_bounds__(64 * kWaves)
+void rave_playouts_kernel(RaveParams prm) {
+    __shared__ uint32_t s_mem[kWaves][kPerGame];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int game = blockIdx.x * kWaves + wave;
+    if (game >= prm.n_games) return;                            // the waves of a workgroup never wait for each other
+
+    uint32_t* lines = s_mem[wave];
+    uint32_t* root_lines = lines + kLinePad;
+    uint32_t* path_node = root_lines + kLinePad;                // node id | cell << 24
+    uint32_t* path_link = path_node + kPathCap;                 // its child range
+    const size_t arena = static_cast<size_t>(game) * prm.cap;
+    uint2* stat = prm.a.stat + arena;
+    uint2* info = prm.a.info + arena;
+    uint32_t* link_of = prm.a.link + arena;
+    uint2* front = prm.a.front + arena;
+    uint8_t* ord = prm.a.ord + arena;
+    uint2* amaf = prm.a.amaf + arena;
+    TradHeader* hdr = prm.hdr + game;
+    uint32_t n_nodes = hdr->n_nodes, status = hdr->status;
+    const uint32_t fresh_mode = hdr->fresh;
+    const bool fresh = fresh_mode == 1u;
+    const uint8_t* mv = prm.moves + static_cast<size_t>(game) * 225;
+    const int init = prm.lens[game];                            // Policy::m_initActs: stones on the root board
+    const int root_black = init & 1;                            // the player of the last move
+    const uint32_t root_last = init ? mv[init - 1] : 255u;
+    const uint32_t playout0 = fresh_mode != 0u ? 0u : hdr->playouts_done;      // the rollout counter restarts with a new root
+    const uint32_t game_id = prm.first_game_id + static_cast<uint32_t>(game);
+
+    // the root position as line words: move i is black's when i is even
+    for (int w = lane; w < kLinePad; w += 64) root_lines[w] = 0u;
+    wave_phase_fence();
+    for (int i = lane; i < init; i += 64) place_stone(root_lines, mv[i], (i & 1) ? 16u : 0u);
+    if (fresh) {                                                // MCTS::reset / a new search: the root node alone
+        if (lane == 0) {
+            stat[0] = make_uint2(0u, 0u);
+            info[0] = make_uint2(kNoParent | (root_last << 24), __float_as_uint(1.0f));
+            link_of[0] = 0u;
+            amaf[0] = make_uint2(0u, 0u);
+        }
+        n_nodes = 1;
+        status = 0;
+    }
+    // path[0 .. valid] is known to be the chain of first children from the root
+    int valid = 0;
+    if (lane == 0) { path_node[0] = root_last << 24; path_link[0] = fresh ? 0u : link_of[0]; }
+    wave_phase_fence();
+
+    struct Level {                                              // what backup needs of one path node: its statistics and its children
+        uint2 ns, cs[4], ci[4], ca[4];
+        uint32_t cl[4], co[4];
+    };
+    auto load_level = [&](int d) {
+        Level L;
+        const uint32_t nd = path_node[d] & 0xFFFFFFu, lk = path_link[d], first = lk & 0xFFFFFFu, n = lk >> 24;
+        L.ns = stat[nd];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t i = lane + 64 * k, id = first + i;
+            if (i < n) { L.cs[k] = stat[id]; L.ci[k] = info[id]; L.ca[k] = amaf[id]; L.cl[k] = link_of[id]; L.co[k] = ord[id]; }
+            else { L.cs[k] = make_uint2(0u, 0u); L.ci[k] = make_uint2(0u, 0u); L.ca[k] = make_uint2(0u, 0u); L.cl[k] = 0u; L.co[k] = 0xFFFFFFFFu; }
+        }
+        return L;
+    };
+
+    for (int it = 0; it < prm.playouts && !(status & 1u); ++it) {
+        // ---- select: always the first child in the current order (RAVE::Select) ----
+        int depth = valid;
+        uint32_t node = path_node[depth] & 0xFFFFFFu, link = path_link[depth];
+        while (link >> 24) {
+            const uint2 rec = front[node];
+            node = rec.x & 0xFFFFFFu;
+            link = rec.y;
+            ++depth;
+            if (lane == 0) { path_node[depth] = rec.x; path_link[depth] = link; }
+        }
+        wave_phase_fence();
+        // ---- the leaf position: the root's line words plus the moves of the path (Policy::applyMove, no victory check) ----
+        for (int w = lane; w < kLinePad; w += 64) lines[w] = root_lines[w];
+        wave_phase_fence();
+        for (int d = 1 + lane; d <= depth; d += 64) place_stone(lines, path_node[d] >> 24, ((init + d - 1) & 1) ? 16u : 0u);
+        wave_phase_fence();
+        const int ply = init + depth;
+        const uint32_t last = depth ? path_node[depth] >> 24 : root_last;
+        // ---- Policy::checkGameEnd -> Board::checkGameEnd (Game.cpp:88-136): five through the last move, or a full board ----
+        bool five = false;
+        if (ply > 0 && last < 225u) five = five_on_lines<1>(lines, static_cast<int>(last % 15u), static_cast<int>(last / 15u), (ply & 1) ? 0 : 16);
+        const bool over = five || ply == 225;
+        int path_len = depth;                                   // deepest level with a known node
+        float value;                                            // for the player of `node`
+        if (!over) {
+            // ---- Default::UniformProbs of the leaf, before the rollout changes the board ----
+            int total = 0, rank[4], first_cell = -1;
+            bool open[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cell = lane + 64 * j, y = min(cell / 15u, 14u), x = cell - 15u * (cell / 15u);
+                const uint32_t rw = lines[y];
+                open[j] = cell < 225u && (((rw | (rw >> 16)) >> x) & 1u) == 0u;
+                const unsigned long long b = __ballot(open[j]);
+                rank[j] = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
+                if (first_cell < 0 && b) first_cell = 64 * j + __ffsll(static_cast<unsigned long long>(b)) - 1;
+                total += __popcll(b);
+            }
+            const float prior = 1.0f / static_cast<float>(total);
+            // ---- Default::RandomRollout: a serial chain, one lane plays it; the finished game stays in `lines` ----
+            const int to_move = (ply & 1) ? -1 : 1;
+            int winner = 0;
+            if (lane == 0)
+                winner = random_rollout(lines, 0, to_move, ply, game_id, playout0 + static_cast<uint32_t>(it), static_cast<uint32_t>(init) << 8, prm.seed_lo, prm.seed_hi);
+            winner = __builtin_amdgcn_readfirstlane(winner);
+            wave_phase_fence();
+            value = -static_cast<float>(to_move * winner);      // CalcScore(init_player, winner), seen from the player of `node`
+            // ---- Default::Expand, extraCheck = false: children in ascending cell order ----
+            if (n_nodes + static_cast<uint32_t>(total) > static_cast<uint32_t>(prm.cap)) {
+                status |= 1u;                                   // arena full: the search of this game stops here
+                break;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (open[j]) {
+                    const uint32_t child = n_nodes + rank[j];
+                    stat[child] = make_uint2(0u, 0u);
+                    info[child] = make_uint2(node | (static_cast<uint32_t>(lane + 64 * j) << 24), __float_as_uint(prior));
+                    link_of[child] = 0u;
+                    ord[child] = static_cast<uint8_t>(rank[j]);
+                    amaf[child] = make_uint2(0u, 0u);
+                }
+            link = n_nodes | (static_cast<uint32_t>(total) << 24);
+            if (lane == 0) {
+                const uint32_t front_rec = n_nodes | (static_cast<uint32_t>(first_cell) << 24);
+                link_of[node] = link;
+                front[node] = make_uint2(front_rec, 0u);
+                if (depth > 0) front[path_node[depth - 1] & 0xFFFFFFu] = make_uint2(path_node[depth], link);      // the parent's record of this node
+                path_link[depth] = link;
+                path_node[depth + 1] = front_rec;
+                path_link[depth + 1] = 0u;
+            }
+            path_len = depth + 1;
+            n_nodes += total;
+        } else {
+            value = five ? 1.0f : 0.0f;                         // CalcScore(node->player, winner): the mover won, or a tie
+        }
+        wave_phase_fence();
+
+        // ---- RAVE::BackPropogate<true> (MonteCarlo.hpp:154-184), leaf to root, on the finished board ----
+        int swap_level = -1;
+        uint2 swap_rec = make_uint2(0u, 0u);
+        uint32_t updated_id = 0xFFFFFFFFu;                      // the path node one level below: its statistics were just rewritten
+        uint2 updated_stat = make_uint2(0u, 0u);
+        Level cur = load_level(depth);
+        for (int d = depth; d >= 0; --d, value = -value) {
+            Level nxt;
+            if (d > 0) nxt = load_level(d - 1);                 // in flight while this level is reduced
+            const uint32_t nd = path_node[d] & 0xFFFFFFu, lk = path_link[d];
+            const uint32_t first = lk & 0xFFFFFFu, n = lk >> 24;
+            const double sqrt_n = sqrt(static_cast<double>(cur.ns.x));
+            const uint32_t child_shift = (((d + 1) & 1) ? !root_black : root_black) ? 0u : 16u;       // the children's player: black in the low halves
+            double best_score = -INFINITY;
+            uint32_t best_ord = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = lane + 64 * k;
+                if (i >= n) continue;
+                uint2 cs = cur.cs[k];
+                if (first + i == updated_id) cs = updated_stat;
+                const uint32_t cell = cur.ci[k].x >> 24, y = cell / 15u, x = cell - 15u * y;
+                float aq = __uint_as_float(cur.ca[k].y);
+                if ((lines[y] >> (x + child_shift)) & 1u) {     // board.moveState(child.player, child.position): all moves as first
+                    const uint32_t av = cur.ca[k].x + 1u;
+                    aq += (-value - aq) / static_cast<float>(av);
+                    amaf[first + i] = make_uint2(av, __float_as_uint(aq));
+                }
+                const double p_i = __uint_as_float(cur.ci[k].y), n_i = static_cast<double>(cs.x + 1u);
+                double score = prm.c_puct * p_i * sqrt_n / n_i;                        // Default::PUCB (:23-28)
+                const double visits = static_cast<double>(cs.x), eqv = 800.0;
+                const double weight = sqrt(eqv / (3 * visits + eqv));                  // RAVE::HandSelect (:124-128)
+                score += (1 - weight) * __uint_as_float(cs.y) + weight * aq;            // RAVE::WeightedValue (:138-142)
+                // the reference scans the children in their current order and keeps the first maximum
+                if (score > best_score || (score == best_score && cur.co[k] < best_ord)) { best_score = score; best_ord = cur.co[k]; }
+            }
+            const double top = wave_max(best_score);
+            best_ord = wave_min(best_score == top ? best_ord : 0xFFFFFFFFu);
+            if (n && best_ord != 0xFFFFFFFFu && best_ord != 0u) {                      // the best child moves to the front: it swaps places with the first one
+                uint2 mine = make_uint2(0u, 0u);
+                bool owner = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (lane + 64 * k < n && cur.co[k] == best_ord) { owner = true; mine = make_uint2((first + lane + 64 * k) | (cur.ci[k].x & 0xFF000000u), cur.cl[k]); }
+                const int src = __ffsll(static_cast<unsigned long long>(__ballot(owner))) - 1;
+                const uint2 rec = make_uint2(__shfl(mine.x, src), __shfl(mine.y, src));
+                if (lane == 0) {
+                    ord[rec.x & 0xFFFFFFu] = 0;
+                    ord[path_node[d + 1] & 0xFFFFFFu] = static_cast<uint8_t>(best_ord);
+                    front[nd] = rec;
+                }
+                swap_level = d;
+                swap_rec = rec;
+            }
+            const uint32_t visits = cur.ns.x + 1u;
+            const float q = __uint_as_float(cur.ns.y);
+            updated_id = nd;
+            updated_stat = make_uint2(visits, __float_as_uint(q + (value - q) / static_cast<float>(visits)));
+            if (lane == 0) stat[nd] = updated_stat;
+            cur = nxt;
+        }
+        wave_phase_fence();
+        if (swap_level >= 0) {                                  // below the shallowest swap the chain of first children is a different one
+            if (lane == 0) { path_node[swap_level + 1] = swap_rec.x; path_link[swap_level + 1] = swap_rec.y; }
+            valid = swap_level + 1;
+        } else {
+            valid = path_len;
+        }
+        wave_phase_fence();
+    }
+
+    if (lane == 0) {
+        hdr->n_nodes = n_nodes;
+        hdr->init_acts = static_cast<uint32_t>(init);
+        hdr->status = status;
+        hdr->fresh = 0;
+        hdr->root_black = static_cast<uint32_t>(root_black);
+        hdr->playouts_done = playout0 + static_cast<uint32_t>(prm.playouts);
+    }
+}
+
+// the root children's all-moves-as-first statistics by cell
+__global__ __launch_bounds__(64)
+void rave_root_amaf_kernel(TradArena a, const TradHeader* hdrs, int cap, uint32_t* amaf_visits, float* amaf_values) {
+    const int game = blockIdx.x, lane = threadIdx.x;
+    const size_t arena = static_cast<size_t>(game) * cap;
+    if (hdrs[game].fresh == 1u) return;
+    const uint32_t lk = a.link[arena], first = lk & 0xFFFFFFu, n = lk >> 24;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t cell = a.info[arena + first + i].x >> 24;
+        const uint2 am = a.amaf[arena + first + i];
+        amaf_visits[static_cast<size_t>(game) * 225 + cell] = am.x;
+        amaf_values[static_cast<size_t>(game) * 225 + cell] = __uint_as_float(am.y);
+    }
+}
+
+}  // namespace
+
+extern "C" int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, uint64_t seed, uint32_t first_game_id, void* stream) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!t || playouts < 0) { gmk::set_error("gmk_trad_run_poolrave: bad arguments"); return GMK_ERR_ARG; }
+    if (!t->positioned) { gmk::set_error("gmk_trad_run_poolrave: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
+    if (!t->d_amaf) {
+        const size_t nodes = static_cast<size_t>(t->n_games) * static_cast<size_t>(t->cap);
+        GMK_HIP_CHECK(hipMalloc(&t->d_amaf, nodes * 8));
+        GMK_HIP_CHECK(hipMemset(t->d_amaf, 0, nodes * 8));
+    }
+    RaveParams prm;
+    prm.a = t->arena();
+    prm.hdr = t->d_hdr; prm.moves = t->d_moves; prm.lens = t->d_lens;
+    prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts;
+    prm.seed_lo = static_cast<uint32_t>(seed); prm.seed_hi = static_cast<uint32_t>(seed >> 32); prm.first_game_id = first_game_id;
+    prm.c_puct = c_puct;
+    const int grid = (t->n_games + kWaves - 1) / kWaves;
+    hipLaunchKernelGGL(rave_playouts_kernel, dim3(grid), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), prm);
+    GMK_HIP_CHECK(hipGetLastError());
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_root_amaf(gmk_trad* t, uint32_t* h_amaf_visits, float* h_amaf_values) {
+    if (!t || !h_amaf_visits || !h_amaf_values) { gmk::set_error("gmk_trad_root_amaf: bad arguments"); return GMK_ERR_ARG; }
+    if (!t->d_amaf) { gmk::set_error("gmk_trad_root_amaf: gmk_trad_run_poolrave has not been called on this handle"); return GMK_ERR_STATE; }
+    const size_t n = static_cast<size_t>(t->n_games);
+    uint32_t* d_visits = nullptr;
+    float* d_values = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_values); };
+#define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
+    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4));
+    GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4));
+    hipLaunchKernelGGL(rave_root_amaf_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->arena(), t->d_hdr, t->cap, d_visits, d_values);
+    GMK_TRY(hipGetLastError());
+    GMK_TRY(hipDeviceSynchronize());
+    GMK_TRY(hipMemcpy(h_amaf_visits, d_visits, n * 225 * 4, hipMemcpyDeviceToHost));
+    GMK_TRY(hipMemcpy(h_amaf_values, d_values, n * 225 * 4, hipMemcpyDeviceToHost));
+#undef GMK_TRY
+    cleanup();
+    return GMK_OK;
+}

@@ -24,10 +24,12 @@
 
 #include "evalstate_device.h"
 #include "philox.h"
+#include "trad_tree.h"
 
 namespace {
 
 using namespace gmk::evs;
+using namespace gmk::tree;
 
 constexpr int kGamesPerBlock = 7;
 constexpr int kThreads = 64 * kGamesPerBlock;
@@ -35,16 +37,6 @@ constexpr int kPathCap = 228;                    // a path has at most 226 nodes
 constexpr int kRecordWords = 57;
 // per-game LDS: evaluator state | evaluator scratch | path nodes (id | cell << 24) | path child ranges | record copy
 constexpr int kPerGame = (kStateWords + kScratchWords + 2 * kPathCap + kRecordWords + 3) & ~3;
-constexpr uint32_t kNoParent = 0xFFFFFFu;
-
-struct TradHeader {                              // 64 B per game in HBM
-    uint32_t n_nodes, init_acts, status, fresh;  // status: bit 0 node capacity reached, bit 1 evaluator error, bit 2 board-only revert met, bit 3 illegal step
-                                                 // fresh: 1 = new root + evaluator sync, 2 = the tree was re-rooted (kept): evaluator sync only
-    uint32_t playouts_done, root_black, pad0, pad1;
-    unsigned long long evaluator_updates, pad2;
-    uint32_t prof[4];                            // GMK_TRAD_PROFILE: shader clocks (>> 10) in select + evaluator moves, simulate + expand, backup, all
-};
-static_assert(sizeof(TradHeader) == 64, "TradHeader layout");
 
 struct TradParams {
     uint32_t* states;                            // [n_games][kStateWords]
@@ -68,32 +60,6 @@ struct TradParams {
 template <int N>
 __device__ __forceinline__ float row_down(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
-}
-
-// the same for 64-bit and unsigned values; a lane without a source inside its row keeps its own value
-template <int N>
-__device__ __forceinline__ double row_down_keep(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xF, 0xF, false));
-}
-template <int N>
-__device__ __forceinline__ uint32_t row_down_keep(uint32_t v) {
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), 0x100 + N, 0xF, 0xF, false));
-}
-__device__ __forceinline__ double lane_value(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-
-// wave-wide maximum of doubles that are never NaN / minimum of unsigned values: DPP inside the rows, the four row leaders by readlane
-__device__ __forceinline__ double wave_max(double v) {
-    v = fmax(v, row_down_keep<8>(v)); v = fmax(v, row_down_keep<4>(v)); v = fmax(v, row_down_keep<2>(v)); v = fmax(v, row_down_keep<1>(v));
-    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
-}
-__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
-    v = min(v, row_down_keep<8>(v)); v = min(v, row_down_keep<4>(v)); v = min(v, row_down_keep<2>(v)); v = min(v, row_down_keep<1>(v));
-    const uint32_t a = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 0)), b = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 16));
-    const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 32)), d = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
-    return min(min(a, b), min(c, d));
 }
 
 // the one summation order (oracle/go_trad.c: sum225): lane l first adds its cells l, l+64, l+128, l+192 in that order
@@ -553,9 +519,6 @@ void trad_playouts_kernel(TradParams prm) {
 // frees the siblings; here the kept subtree is copied level by level into the other arena so that node indices stay dense
 // (children consecutive, the root at 0).  A copied node carries its OLD child range and OLD first-child record until the
 // scan reaches it, copies its children and rewrites both.  One wavefront per game.
-struct TradArena {
-    uint2* stat; uint2* info; uint32_t* link; uint2* front; uint8_t* ord;
-};
 
 __global__ __launch_bounds__(64)
 void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n_games, const int16_t* forced, uint8_t* moves, int32_t* lens) {
@@ -570,6 +533,7 @@ void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n
             a.stat[base] = make_uint2(0u, 0u);
             a.info[base] = make_uint2(kNoParent | ((len ? mv[len - 1] : 255u) << 24), __float_as_uint(1.0f));
             a.link[base] = 0u;
+            if (a.amaf) a.amaf[base] = make_uint2(0u, 0u);
             hdr.n_nodes = 1; hdr.status = 0; hdr.root_black = static_cast<uint32_t>(len & 1);
         }
         __syncthreads();
@@ -591,7 +555,10 @@ void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n
     best_id = __shfl(best_id, 0);
     const bool found = best_visits != 0u;
     if (want < 0 && !found) {                                   // stepForward() on a childless root: nothing moves (MCTS.cpp:133)
-        if (lane == 0) { b.stat[base] = a.stat[base]; b.info[base] = a.info[base]; b.link[base] = 0u; b.ord[base] = 0; hdr.n_nodes = 1; hdr.fresh = 2; }
+        if (lane == 0) {
+            b.stat[base] = a.stat[base]; b.info[base] = a.info[base]; b.link[base] = 0u; b.ord[base] = 0; hdr.n_nodes = 1; hdr.fresh = 2;
+            if (a.amaf) b.amaf[base] = a.amaf[base];
+        }
         return;
     }
     const uint32_t cell = found ? a.info[base + best_id].x >> 24 : static_cast<uint32_t>(want);
@@ -608,6 +575,7 @@ void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n
         if (lane == 0) {
             b.stat[base] = make_uint2(0u, 0u); b.info[base] = make_uint2(kNoParent | (cell << 24), __float_as_uint(1.0f));
             b.link[base] = 0u; b.ord[base] = 0; hdr.n_nodes = 1;
+            if (a.amaf) b.amaf[base] = make_uint2(0u, 0u);
         }
         return;
     }
@@ -617,6 +585,7 @@ void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n
         b.link[base] = a.link[base + src_root];
         b.front[base] = a.front[base + src_root];
         b.ord[base] = 0;
+        if (a.amaf) b.amaf[base] = a.amaf[base + src_root];
     }
     __syncthreads();
     uint32_t next = 1;
@@ -635,6 +604,7 @@ void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n
                 b.link[base + next + k] = a.link[base + of + k];
                 b.front[base + next + k] = a.front[base + of + k];
                 b.ord[base + next + k] = a.ord[base + of + k];
+                if (a.amaf) b.amaf[base + next + k] = a.amaf[base + of + k];
             }
             if (lane == 0) {
                 const uint32_t new_link = next | (nk << 24);
@@ -698,29 +668,12 @@ void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t
 
 }  // namespace
 
-struct gmk_trad {
-    int n_games = 0, cap = 0;
-    uint32_t* d_states = nullptr;
-    uint2 *d_stat = nullptr, *d_info = nullptr;
-    uint32_t* d_link = nullptr;
-    uint2* d_front = nullptr;
-    uint8_t* d_ord = nullptr;
-    uint2 *d_stat2 = nullptr, *d_info2 = nullptr, *d_front2 = nullptr;      // second arena, allocated by the first gmk_trad_step
-    uint32_t* d_link2 = nullptr;
-    uint8_t* d_ord2 = nullptr;
-    int16_t* d_forced = nullptr;
-    float* d_priors = nullptr;
-    TradHeader* d_hdr = nullptr;
-    uint8_t* d_moves = nullptr;
-    int32_t* d_lens = nullptr;
-    bool attr_set = false, positioned = false;
-};
 
 extern "C" int gmk_trad_destroy(gmk_trad* t) {
     if (!t) return GMK_OK;
     (void)hipFree(t->d_states); (void)hipFree(t->d_stat); (void)hipFree(t->d_info); (void)hipFree(t->d_link);
     (void)hipFree(t->d_front); (void)hipFree(t->d_ord); (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_front2);
-    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
+    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_amaf); (void)hipFree(t->d_amaf2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
     delete t;
     return GMK_OK;
 }
@@ -816,13 +769,14 @@ extern "C" int gmk_trad_step(gmk_trad* t, const int16_t* h_moves) {
     }
     GMK_HIP_CHECK(hipDeviceSynchronize());
     if (h_moves) GMK_HIP_CHECK(hipMemcpy(t->d_forced, h_moves, n * 2, hipMemcpyHostToDevice));
-    const TradArena a{t->d_stat, t->d_info, t->d_link, t->d_front, t->d_ord}, b{t->d_stat2, t->d_info2, t->d_link2, t->d_front2, t->d_ord2};
+    if (t->d_amaf && !t->d_amaf2 && hipMalloc(&t->d_amaf2, nodes * 8) != hipSuccess) { gmk::set_error("gmk_trad_step: hipMalloc of the second arena (%zu nodes) failed", nodes); return GMK_ERR_HIP; }
+    const TradArena a = t->arena(), b = t->arena2();
     hipLaunchKernelGGL(trad_step_kernel, dim3(t->n_games), dim3(64), 0, nullptr, a, b, t->d_hdr, t->cap, t->n_games,
                        h_moves ? t->d_forced : nullptr, t->d_moves, t->d_lens);
     GMK_HIP_CHECK(hipGetLastError());
     GMK_HIP_CHECK(hipDeviceSynchronize());
     std::swap(t->d_stat, t->d_stat2); std::swap(t->d_info, t->d_info2); std::swap(t->d_link, t->d_link2);
-    std::swap(t->d_front, t->d_front2); std::swap(t->d_ord, t->d_ord2);
+    std::swap(t->d_front, t->d_front2); std::swap(t->d_ord, t->d_ord2); std::swap(t->d_amaf, t->d_amaf2);
     return GMK_OK;
 }
 
@@ -858,7 +812,7 @@ extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, 
     }
     if (!t->d_priors) GMK_HIP_CHECK(hipMalloc(&t->d_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(t->d_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
-    const TradArena a{t->d_stat, t->d_info, t->d_link, t->d_front, t->d_ord};
+    const TradArena a = t->arena();
     hipLaunchKernelGGL(trad_set_root_priors_kernel, dim3(t->n_games), dim3(64), 0, nullptr, a, t->d_hdr, t->cap, t->d_priors);
     GMK_HIP_CHECK(hipGetLastError());
     GMK_HIP_CHECK(hipDeviceSynchronize());

@@ -32,7 +32,7 @@ EXPORTS = [
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
     "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_add_root_noise", "gmk_az_root_stats",
-    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators",
+    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf",
 ]
 
 
@@ -110,6 +110,8 @@ def load():
     L.gmk_trad_add_root_noise.argtypes = [vp, C.c_float, C.c_float, C.c_uint64, C.c_uint32]
     L.gmk_trad_root_stats.argtypes = [vp] * 10
     L.gmk_trad_read_evaluators.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.gmk_trad_run_poolrave.argtypes = [vp, C.c_int, C.c_double, C.c_uint64, C.c_uint32, vp]
+    L.gmk_trad_root_amaf.argtypes = [vp, vp, vp]
     L.gmk_samples_from_records.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L
@@ -394,6 +396,28 @@ class TraditionalMCTS:
                "meta": np.zeros((self.n, 4), np.int32), "record": np.zeros((self.n, 228), np.uint8)}
         _check(load().gmk_trad_read_evaluators(self.h, out["scores"].ctypes.data, out["density"].ctypes.data, out["pattern_dist"].ctypes.data,
                                                out["compound_dist"].ctypes.data, out["meta"].ctypes.data, out["record"].ctypes.data))
+        return out
+
+
+class PoolRAVEMCTS(TraditionalMCTS):
+    """n_games searches of MCTS(policy=PoolRAVEPolicy(c_puct)) side by side on the GPU (K8): the tree, step, noise and root
+    statistics of TraditionalMCTS, playouts with one random rollout each and RAVE::BackPropogate<true>."""
+
+    def __init__(self, n_games, node_capacity=1 << 20, c_puct=2.0, seed=DEFAULT_SEED, first_game_id=0):
+        super().__init__(n_games, node_capacity, c_puct)
+        self.seed, self.first_game_id = int(seed), int(first_game_id)
+
+    def run(self, playouts, stream=0):
+        _check(load().gmk_trad_run_poolrave(self.h, int(playouts), self.c_puct, self.seed, self.first_game_id, stream))
+
+    def add_root_noise(self, alpha=0.05, epsilon=0.25, seed=None, first_game_id=None):
+        super().add_root_noise(alpha, epsilon, self.seed if seed is None else seed, self.first_game_id if first_game_id is None else first_game_id)
+
+    def root_stats(self):
+        out = super().root_stats()
+        out["amaf_visits"] = np.zeros((self.n, N), np.uint32)
+        out["amaf_values"] = np.zeros((self.n, N), np.float32)
+        _check(load().gmk_trad_root_amaf(self.h, out["amaf_visits"].ctypes.data, out["amaf_values"].ctypes.data))
         return out
 
 

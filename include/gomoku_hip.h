@@ -216,6 +216,18 @@ int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t se
 int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density, uint32_t* h_pattern_dist,
                              uint32_t* h_compound_dist, int32_t* h_meta, uint8_t* h_record);
 
+/* ---- K8: PoolRAVE tree search on the K6 handle ----
+ * Replaces MCTS(policy = PoolRAVEPolicy(c_puct, c_bias)) : core/lib/include/policies/PoolRAVE.h:7-52 = RAVE::Select,
+ * Default::Expand with AMAFNodes, one Default::RandomRollout per playout that stays on the board, and
+ * RAVE::BackPropogate<true> (core/lib/include/algorithms/MonteCarlo.hpp:113-184).  The tree is the one of K6: create,
+ * set_positions, step, add_root_noise and root_stats are the gmk_trad_* entry points above (the handle's evaluators are
+ * not used); this call runs `playouts` MCTS::playout iterations per game with PoolRAVE's stages.  Rollout draws: Philox4x32-10,
+ * key = seed, counter = (first_game_id + game, playout since the root last changed, stones on the root board << 8, ply >> 3),
+ * as K3 with rollout number 0.  c_bias only reaches RAVE::MinMSE, which the reference leaves unused (:130-139): no argument. */
+int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, uint64_t seed, uint32_t first_game_id, void* stream);
+/* the root children's all-moves-as-first statistics by cell (AMAFNode::amaf_visits / amaf_value), host [n][225] each */
+int gmk_trad_root_amaf(gmk_trad* t, uint32_t* h_amaf_visits, float* h_amaf_values);
+
 /* ---- K7: network-guided tree search, many games in lock step (BASELINE.json configs[4]) ----
  * Replaces MCTS(policy = Policy(eval_state = network.eval_state, c_puct)) (agents/alphazero.py:5-9): Default::Select
  * (core/lib/include/algorithms/MonteCarlo.hpp:57-68), the evaluator call at a new leaf (core/lib/src/MCTS.cpp:164-168),

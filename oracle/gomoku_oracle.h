@@ -184,6 +184,19 @@ const go_evaluator *go_trad_evaluator(const go_trad *t);
 /* EvaluationProbs + DecisiveFilter + EvaluationValue on a fresh in-order replay; returns the value */
 float go_trad_heuristic(const uint8_t *moves, int n_moves, float *probs /*[225]*/);
 
+/* ---------------- PoolRAVE search (PoolRAVE.h:7-52, MonteCarlo.hpp:113-184; go_rave.c) ---------------- */
+typedef struct go_rave go_rave;
+go_rave *go_rave_new(double c_puct, double c_bias, uint64_t seed, uint32_t game_id);
+void go_rave_free(go_rave *t);
+void go_rave_set_noise(go_rave *t, float alpha, float epsilon);
+/* MCTS::runPlayouts on the kept tree from the position reached by `moves` */
+void go_rave_run(go_rave *t, const uint8_t *moves, int n_moves, uint64_t playouts);
+int  go_rave_step_forward(go_rave *t);
+int  go_rave_root_children(const go_rave *t, uint32_t *visits, float *values, float *priors, uint32_t *amaf_visits, float *amaf_values);
+uint64_t go_rave_root_visits(const go_rave *t);
+float    go_rave_root_value(const go_rave *t);
+uint64_t go_rave_size(const go_rave *t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,21 @@ def lib():
     L.go_trad_evaluator.restype = C.c_void_p
     L.go_trad_heuristic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.go_trad_heuristic.restype = C.c_float
+    L.go_rave_new.argtypes = [C.c_double, C.c_double, C.c_uint64, C.c_uint32]
+    L.go_rave_new.restype = C.c_void_p
+    L.go_rave_free.argtypes = [C.c_void_p]
+    L.go_rave_set_noise.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    L.go_rave_set_noise.restype = None
+    L.go_rave_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+    L.go_rave_run.restype = None
+    L.go_rave_step_forward.argtypes = [C.c_void_p]
+    L.go_rave_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.go_rave_root_visits.argtypes = [C.c_void_p]
+    L.go_rave_root_visits.restype = C.c_uint64
+    L.go_rave_root_value.argtypes = [C.c_void_p]
+    L.go_rave_root_value.restype = C.c_float
+    L.go_rave_size.argtypes = [C.c_void_p]
+    L.go_rave_size.restype = C.c_uint64
     L.go_mcts_set_evaluator.argtypes = [C.c_void_p, EVAL_FN, C.c_void_p]
     L.go_mcts_set_evaluator.restype = None
     L.go_mcts_new.argtypes = [C.c_uint64, C.c_double, C.c_int, C.c_uint64, C.c_uint32]
@@ -396,6 +411,50 @@ class TraditionalMCTS:
     @property
     def evaluator_updates(self):
         return self.L.go_trad_evaluator_updates(self.h)
+
+
+class PoolRAVEMCTS:
+    """PoolRAVEPolicy search on a kept tree (go_rave.c)."""
+    def __init__(self, c_puct=2.0, c_bias=0.0, seed=0x9E3779B97F4A7C15, game_id=0):
+        self.L = lib()
+        self.h = self.L.go_rave_new(c_puct, c_bias, seed, game_id)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.go_rave_free(self.h)
+            self.h = None
+
+    def set_noise(self, alpha, epsilon):
+        self.L.go_rave_set_noise(self.h, alpha, epsilon)
+
+    def run(self, moves, playouts):
+        m = np.ascontiguousarray(moves, dtype=np.uint8)
+        self.L.go_rave_run(self.h, m.ctypes.data, len(m), int(playouts))
+
+    def step_forward(self):
+        return self.L.go_rave_step_forward(self.h)
+
+    def root_children(self):
+        """(visits, values, priors, amaf_visits, amaf_values) by cell, and the move stepForward() would make."""
+        v = np.zeros(N, dtype=np.uint32)
+        q = np.zeros(N, dtype=np.float32)
+        p = np.zeros(N, dtype=np.float32)
+        av = np.zeros(N, dtype=np.uint32)
+        aq = np.zeros(N, dtype=np.float32)
+        best = self.L.go_rave_root_children(self.h, v.ctypes.data, q.ctypes.data, p.ctypes.data, av.ctypes.data, aq.ctypes.data)
+        return v, q, p, av, aq, best
+
+    @property
+    def root_visits(self):
+        return self.L.go_rave_root_visits(self.h)
+
+    @property
+    def root_value(self):
+        return self.L.go_rave_root_value(self.h)
+
+    @property
+    def size(self):
+        return self.L.go_rave_size(self.h)
 
 
 def trad_heuristic(moves):
