@@ -144,6 +144,63 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
             "note": "a serial chain per game (one wavefront each): bound by LDS / HBM latency, not by bandwidth; no roofline fraction is claimed"}
 
 
+def rave_positions(G, np, n, first):
+    """K8 workload: the 4-ply random openings of the K3 measurement."""
+    moves, lens, _, _ = mcts_openings(G, np, n, first)
+    return [[int(m) for m in moves[g, :int(lens[g])]] for g in range(n)]
+
+
+def bench_rave(args, G, torch, dev, rank, world, distributed):
+    """MCTS(PoolRAVEPolicy) (agents/mcts.py:36-40, PoolRAVE.h:7-52), n games side by side (K8).  One step = one search of
+    every game (one launch)."""
+    import numpy as np
+    n, P = args.rave_games, args.rave_playouts
+    pos = rave_positions(G, np, n, rank * n)
+    tree = G.PoolRAVEMCTS(n, node_capacity=P * 222 + 512, c_puct=2.0, first_game_id=rank * n)
+    stream = torch.cuda.current_stream().cuda_stream
+    tree.set_positions(pos)
+    tree.run(10, stream)                                   # warm-up
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        tree.set_positions(pos)
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tree.run(P, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    ms = min(times)
+    st = tree.root_stats()
+    if distributed:
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = float(t[0])
+    tree.close()
+    return {"metric": "poolrave-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms,
+            "config": {"workload": "PoolRAVE MCTS (K8, PoolRAVEPolicy c_puct=2), %d games x %d playouts per GPU, 4-ply openings, fresh roots" % (n, P),
+                       "nodes_per_game_mean": float(st["n_nodes"].mean()), "games_stopped_at_node_capacity": int((st["status"] & 1).sum())},
+            "note": "a serial chain per game (tree walk, one random rollout, per-level reductions): bound by latency, not by bandwidth; no roofline fraction is claimed"}
+
+
+def cpu_baseline_rave(G, playouts):
+    """The oracle's restatement of the same search (oracle/go_rave.c), single thread, ~5 s."""
+    import numpy as np
+    from oracle import oracle as O
+    pos = rave_positions(G, np, 2048, 0)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < 5 and k < len(pos):
+        O.PoolRAVEMCTS(2.0, 0.0, game_id=k).run(pos[k], playouts)
+        k += 1
+    dt = time.perf_counter() - t0
+    return {"value": k * playouts / dt, "unit": "playouts/s", "cores": 1, "kind": "port",
+            "sample": "%d searches of %d playouts from the same openings, oracle PoolRAVEPolicy restatement, %.1f s" % (k, playouts, dt)}
+
+
 def bench_az(args, G, torch, dev, rank, world, distributed):
     """BASELINE configs[4]: network-guided MCTS (K7) in lock step, PolicyValueNetwork (PyTorch-ROCm, float32, random weights)
     at the leaves.  One step = one playout of every game = select kernel + network forward + expand kernel."""
@@ -240,6 +297,8 @@ def main():
     ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
+    ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
+    ap.add_argument("--rave-playouts", type=int, default=400)
     args = ap.parse_args()
 
     import numpy as np
@@ -321,6 +380,10 @@ def main():
     if args.trad_games > 0:
         trad = bench_trad(args, G, torch, dev, rank, world, distributed)
 
+    rave = None
+    if args.rave_games > 0:
+        rave = bench_rave(args, G, torch, dev, rank, world, distributed)
+
     az = None
     if args.az_games > 0:
         az = bench_az(args, G, torch, dev, rank, world, distributed)
@@ -354,6 +417,8 @@ def main():
             out["secondary"] = mcts
         if trad is not None:
             out["supervisor"] = trad
+        if rave is not None:
+            out["poolrave"] = rave
         if az is not None:
             out["network_guided"] = az
         if not args.no_cpu_baseline:
@@ -362,6 +427,8 @@ def main():
                 out["secondary"]["cpu_baseline"] = cpu_baseline_mcts(args.mcts_playouts)
             if trad is not None:
                 out["supervisor"]["cpu_baseline"] = cpu_baseline_trad(G, args.trad_playouts)
+            if rave is not None:
+                out["poolrave"]["cpu_baseline"] = cpu_baseline_rave(G, args.rave_playouts)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -8,7 +8,7 @@ from subprocess import PIPE, Popen
 
 import numpy as np
 
-from .core import Board, GameConfig as Game, MCTS, Player, Policy, Position, RandomPolicy, TraditionalPolicy
+from .core import Board, GameConfig as Game, MCTS, Player, Policy, PoolRAVEPolicy, Position, RandomPolicy, TraditionalPolicy
 
 
 class Agent:
@@ -55,6 +55,11 @@ class MCTSAgent(Agent):
 
 def RandomMCTSAgent(c_puct, c_rollouts=5, **constraint):
     return MCTSAgent(policy=RandomPolicy(c_puct, c_rollouts), **constraint)
+
+
+def RAVEAgent(c_puct, c_bias, **constraint):
+    """agents/mcts.py:36-40 of the reference: MCTS with PoolRAVEPolicy (the search runs on the GPU, K8)."""
+    return MCTSAgent(policy=PoolRAVEPolicy(c_puct, c_bias), **constraint)
 
 
 def TraditionalAgent(c_puct, c_bias=0.0, use_rave=False, **constraint):

@@ -285,10 +285,12 @@ private:
         const auto start = std::chrono::system_clock::now();
         auto* random = dynamic_cast<RandomPolicy*>(policy_.get());
         auto* trad = dynamic_cast<TraditionalPolicy*>(policy_.get());
-        if (trad && !trad->use_rave && !policy_->has_python_stages()) { run_traditional(board, *trad, start); return; }
+        auto* rave = dynamic_cast<PoolRAVEPolicy*>(policy_.get());
+        if (trad && !trad->use_rave && !policy_->has_python_stages()) { run_first_child_tree(board, trad->c_puct, trad, start); return; }
+        if (rave && !policy_->has_python_stages()) { run_first_child_tree(board, rave->c_puct, nullptr, start); return; }
         if (!random && !trad && policy_->simulate && !policy_->select && !policy_->expand && !policy_->back_prop) { run_with_evaluator(board, start); return; }
         if (!random || policy_->has_python_stages())
-            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy, TraditionalPolicy(use_rave=False) and Policy(eval_state=...) in this build; ") +
+            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy, PoolRAVEPolicy, TraditionalPolicy(use_rave=False) and Policy(eval_state=...) in this build; ") +
                                      policy_->kind() + " with other host-side stages is not available (no CPU search path)");
         throw_gmk(gmk_init(0));
         sync_with_board(board);
@@ -422,8 +424,12 @@ private:
     }
 
     // MCTS(policy = TraditionalPolicy) on the device (K6, gmk_trad_*): one game; the handle owns the policy's evaluator,
-    // which persists across searches like TraditionalPolicy::m_evaluator (Traditional.h:27-31)
-    void run_traditional(Board& board, TraditionalPolicy& trad, std::chrono::system_clock::time_point start) {
+    // which persists across searches like TraditionalPolicy::m_evaluator (Traditional.h:27-31).  trad == nullptr:
+    // MCTS(policy = PoolRAVEPolicy) on the same tree (K8, gmk_trad_run_poolrave; PoolRAVE.h:7-52)
+    void run_first_child_tree(Board& board, double c_puct, TraditionalPolicy* trad, std::chrono::system_clock::time_point start) {
+        auto run_chunk = [&](int n) {
+            throw_gmk(trad ? gmk_trad_run(trad_handle_, n, c_puct, nullptr) : gmk_trad_run_poolrave(trad_handle_, n, c_puct, g_search_seed, game_id_, nullptr));
+        };
         throw_gmk(gmk_init(0));
         sync_with_board(board);
         policy_->prepare(board);
@@ -463,13 +469,13 @@ private:
         visits_.assign(kN, 0);
         auto read = [&]() { throw_gmk(gmk_trad_root_stats(trad_handle_, visits_.data(), values.data(), priors.data(), &best, &root_visits, &q, &nodes, &status, nullptr)); };
         if (by_iterations_) {
-            throw_gmk(gmk_trad_run(trad_handle_, chunk, trad.c_puct, nullptr));
+            run_chunk(chunk);
             read();
             duration_ = std::chrono::duration_cast<milliseconds>(std::chrono::system_clock::now() - start);
         } else {
             iterations_ = 0;
             for (auto end = start; end - start < duration_; end = std::chrono::system_clock::now()) {
-                throw_gmk(gmk_trad_run(trad_handle_, chunk, trad.c_puct, nullptr));
+                run_chunk(chunk);
                 read();
                 iterations_ += static_cast<size_t>(chunk);
                 if (status & 1) break;                              // node arena full
@@ -488,7 +494,7 @@ private:
             }
         best_in_order_ = best;
         size_ = static_cast<size_t>(nodes);
-        trad.cached_acts = policy_->init_acts;
+        if (trad) trad->cached_acts = policy_->init_acts;
         policy_->cleanup(board);
     }
 

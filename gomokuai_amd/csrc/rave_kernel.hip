@@ -41,6 +41,7 @@ struct RaveParams {
     int n_games, cap, playouts;
     uint32_t seed_lo, seed_hi, first_game_id;
     double c_puct;
+    int profile;                                 // GMK_RAVE_PROFILE: shader clocks per stage into TradHeader::prof (diagnostic runs only)
 };
 
 __device__ __forceinline__ void wave_phase_fence() {
@@ -58,12 +59,14 @@ __device__ __forceinline__ void place_stone(uint32_t* lines, uint32_t cell, uint
     atomicOr(&lines[kAntiBase + x + y], 1u << (min(14u - x, y) + shift));
 }
 
-__global__ __launch_bounds__(64 * kWaves)
+__global__ __launch_bounds__(64 * kWaves, 4)
 void rave_playouts_kernel(RaveParams prm) {
     __shared__ uint32_t s_mem[kWaves][kPerGame];
+    __shared__ uint2 s_cells[kWaves][30];                       // per game and playout: the rollout's cell draws, eight plies per entry
+    __shared__ int s_ply[kWaves], s_winner[kWaves];             // per game and playout: stones at the leaf (-1: no rollout), the rollout's winner
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int game = blockIdx.x * kWaves + wave;
-    if (game >= prm.n_games) return;                            // the waves of a workgroup never wait for each other
+    const bool exists = blockIdx.x * kWaves + wave < prm.n_games;
+    const int game = exists ? blockIdx.x * kWaves + wave : prm.n_games - 1;     // a surplus wave shadows the last game read-only and only keeps the barriers
 
     uint32_t* lines = s_mem[wave];
     uint32_t* root_lines = lines + kLinePad;
@@ -77,7 +80,7 @@ void rave_playouts_kernel(RaveParams prm) {
     uint8_t* ord = prm.a.ord + arena;
     uint2* amaf = prm.a.amaf + arena;
     TradHeader* hdr = prm.hdr + game;
-    uint32_t n_nodes = hdr->n_nodes, status = hdr->status;
+    uint32_t n_nodes = hdr->n_nodes, status = exists ? hdr->status : 1u;
     const uint32_t fresh_mode = hdr->fresh;
     const bool fresh = fresh_mode == 1u;
     const uint8_t* mv = prm.moves + static_cast<size_t>(game) * 225;
@@ -85,21 +88,20 @@ void rave_playouts_kernel(RaveParams prm) {
     const int root_black = init & 1;                            // the player of the last move
     const uint32_t root_last = init ? mv[init - 1] : 255u;
     const uint32_t playout0 = fresh_mode != 0u ? 0u : hdr->playouts_done;      // the rollout counter restarts with a new root
-    const uint32_t game_id = prm.first_game_id + static_cast<uint32_t>(game);
 
     // the root position as line words: move i is black's when i is even
     for (int w = lane; w < kLinePad; w += 64) root_lines[w] = 0u;
     wave_phase_fence();
     for (int i = lane; i < init; i += 64) place_stone(root_lines, mv[i], (i & 1) ? 16u : 0u);
     if (fresh) {                                                // MCTS::reset / a new search: the root node alone
-        if (lane == 0) {
+        if (lane == 0 && exists) {
             stat[0] = make_uint2(0u, 0u);
             info[0] = make_uint2(kNoParent | (root_last << 24), __float_as_uint(1.0f));
             link_of[0] = 0u;
             amaf[0] = make_uint2(0u, 0u);
         }
         n_nodes = 1;
-        status = 0;
+        status = exists ? 0u : 1u;
     }
     // path[0 .. valid] is known to be the chain of first children from the root
     int valid = 0;
@@ -123,85 +125,108 @@ void rave_playouts_kernel(RaveParams prm) {
         return L;
     };
 
-    for (int it = 0; it < prm.playouts && !(status & 1u); ++it) {
-        // ---- select: always the first child in the current order (RAVE::Select) ----
-        int depth = valid;
-        uint32_t node = path_node[depth] & 0xFFFFFFu, link = path_link[depth];
-        while (link >> 24) {
-            const uint2 rec = front[node];
-            node = rec.x & 0xFFFFFFu;
-            link = rec.y;
-            ++depth;
-            if (lane == 0) { path_node[depth] = rec.x; path_link[depth] = link; }
-        }
-        wave_phase_fence();
-        // ---- the leaf position: the root's line words plus the moves of the path (Policy::applyMove, no victory check) ----
-        for (int w = lane; w < kLinePad; w += 64) lines[w] = root_lines[w];
-        wave_phase_fence();
-        for (int d = 1 + lane; d <= depth; d += 64) place_stone(lines, path_node[d] >> 24, ((init + d - 1) & 1) ? 16u : 0u);
-        wave_phase_fence();
-        const int ply = init + depth;
-        const uint32_t last = depth ? path_node[depth] >> 24 : root_last;
-        // ---- Policy::checkGameEnd -> Board::checkGameEnd (Game.cpp:88-136): five through the last move, or a full board ----
-        bool five = false;
-        if (ply > 0 && last < 225u) five = five_on_lines<1>(lines, static_cast<int>(last % 15u), static_cast<int>(last / 15u), (ply & 1) ? 0 : 16);
-        const bool over = five || ply == 225;
-        int path_len = depth;                                   // deepest level with a known node
-        float value;                                            // for the player of `node`
-        if (!over) {
-            // ---- Default::UniformProbs of the leaf, before the rollout changes the board ----
-            int total = 0, rank[4], first_cell = -1;
-            bool open[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t cell = lane + 64 * j, y = min(cell / 15u, 14u), x = cell - 15u * (cell / 15u);
-                const uint32_t rw = lines[y];
-                open[j] = cell < 225u && (((rw | (rw >> 16)) >> x) & 1u) == 0u;
-                const unsigned long long b = __ballot(open[j]);
-                rank[j] = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
-                if (first_cell < 0 && b) first_cell = 64 * j + __ffsll(static_cast<unsigned long long>(b)) - 1;
-                total += __popcll(b);
+    unsigned long long prof_sel = 0, prof_roll = 0, prof_back = 0, prof_t0 = 0, prof_all = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;
+    // The rollout is a serial chain per game that keeps ONE lane busy: the four games of a workgroup meet at a barrier and one
+    // wavefront plays their four rollouts side by side (a quarter of the vector issue slots four separate one-lane loops would
+    // take), the others wait at the next barrier for free.  Every wave makes every iteration, a stopped game just passes through.
+    const int roll_wave = blockIdx.x % kWaves;                  // spread the rollout waves over the SIMDs
+    for (int it = 0; it < prm.playouts; ++it) {
+        if (prm.profile) prof_t0 = __builtin_amdgcn_s_memtime();
+        const bool act = !(status & 1u);
+        int depth = 0, ply = 0, path_len = 0;
+        uint32_t node = 0;
+        bool five = false, rollout = false;
+        if (act) {
+            // ---- select: always the first child in the current order (RAVE::Select) ----
+            depth = valid;
+            node = path_node[depth] & 0xFFFFFFu;
+            uint32_t link = path_link[depth];
+            while (link >> 24) {
+                const uint2 rec = front[node];
+                node = rec.x & 0xFFFFFFu;
+                link = rec.y;
+                ++depth;
+                if (lane == 0) { path_node[depth] = rec.x; path_link[depth] = link; }
             }
-            const float prior = 1.0f / static_cast<float>(total);
-            // ---- Default::RandomRollout: a serial chain, one lane plays it; the finished game stays in `lines` ----
-            const int to_move = (ply & 1) ? -1 : 1;
-            int winner = 0;
-            if (lane == 0)
-                winner = random_rollout(lines, 0, to_move, ply, game_id, playout0 + static_cast<uint32_t>(it), static_cast<uint32_t>(init) << 8, prm.seed_lo, prm.seed_hi);
-            winner = __builtin_amdgcn_readfirstlane(winner);
             wave_phase_fence();
-            value = -static_cast<float>(to_move * winner);      // CalcScore(init_player, winner), seen from the player of `node`
-            // ---- Default::Expand, extraCheck = false: children in ascending cell order ----
-            if (n_nodes + static_cast<uint32_t>(total) > static_cast<uint32_t>(prm.cap)) {
-                status |= 1u;                                   // arena full: the search of this game stops here
-                break;
-            }
+            // ---- the leaf position: the root's line words plus the moves of the path (Policy::applyMove, no victory check) ----
+            for (int w = lane; w < kLinePad; w += 64) lines[w] = root_lines[w];
+            wave_phase_fence();
+            for (int d = 1 + lane; d <= depth; d += 64) place_stone(lines, path_node[d] >> 24, ((init + d - 1) & 1) ? 16u : 0u);
+            wave_phase_fence();
+            ply = init + depth;
+            const uint32_t last = depth ? path_node[depth] >> 24 : root_last;
+            // ---- Policy::checkGameEnd -> Board::checkGameEnd (Game.cpp:88-136): five through the last move, or a full board ----
+            if (ply > 0 && last < 225u) five = five_on_lines<1>(lines, static_cast<int>(last % 15u), static_cast<int>(last / 15u), (ply & 1) ? 0 : 16);
+            path_len = depth;                                   // deepest level with a known node
+            if (!five && ply != 225) {
+                // ---- Default::UniformProbs of the leaf and Default::Expand (extraCheck = false, children in ascending cell order):
+                //      both read the leaf position only, so the children are written before the rollout changes the board ----
+                int total = 0, rank[4], first_cell = -1;
+                bool open[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (open[j]) {
-                    const uint32_t child = n_nodes + rank[j];
-                    stat[child] = make_uint2(0u, 0u);
-                    info[child] = make_uint2(node | (static_cast<uint32_t>(lane + 64 * j) << 24), __float_as_uint(prior));
-                    link_of[child] = 0u;
-                    ord[child] = static_cast<uint8_t>(rank[j]);
-                    amaf[child] = make_uint2(0u, 0u);
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t cell = lane + 64 * j, y = min(cell / 15u, 14u), x = cell - 15u * (cell / 15u);
+                    const uint32_t rw = lines[y];
+                    open[j] = cell < 225u && (((rw | (rw >> 16)) >> x) & 1u) == 0u;
+                    const unsigned long long b = __ballot(open[j]);
+                    rank[j] = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
+                    if (first_cell < 0 && b) first_cell = 64 * j + __ffsll(static_cast<unsigned long long>(b)) - 1;
+                    total += __popcll(b);
                 }
-            link = n_nodes | (static_cast<uint32_t>(total) << 24);
-            if (lane == 0) {
-                const uint32_t front_rec = n_nodes | (static_cast<uint32_t>(first_cell) << 24);
-                link_of[node] = link;
-                front[node] = make_uint2(front_rec, 0u);
-                if (depth > 0) front[path_node[depth - 1] & 0xFFFFFFu] = make_uint2(path_node[depth], link);      // the parent's record of this node
-                path_link[depth] = link;
-                path_node[depth + 1] = front_rec;
-                path_link[depth + 1] = 0u;
+                if (n_nodes + static_cast<uint32_t>(total) > static_cast<uint32_t>(prm.cap)) {
+                    status |= 1u;                               // arena full: the search of this game stops here
+                } else {
+                    const float prior = 1.0f / static_cast<float>(total);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (open[j]) {
+                            const uint32_t child = n_nodes + rank[j];
+                            stat[child] = make_uint2(0u, 0u);
+                            info[child] = make_uint2(node | (static_cast<uint32_t>(lane + 64 * j) << 24), __float_as_uint(prior));
+                            link_of[child] = 0u;
+                            ord[child] = static_cast<uint8_t>(rank[j]);
+                            amaf[child] = make_uint2(0u, 0u);
+                        }
+                    link = n_nodes | (static_cast<uint32_t>(total) << 24);
+                    if (lane == 0) {
+                        const uint32_t front_rec = n_nodes | (static_cast<uint32_t>(first_cell) << 24);
+                        link_of[node] = link;
+                        front[node] = make_uint2(front_rec, 0u);
+                        if (depth > 0) front[path_node[depth - 1] & 0xFFFFFFu] = make_uint2(path_node[depth], link);      // the parent's record of this node
+                        path_link[depth] = link;
+                        path_node[depth + 1] = front_rec;
+                        path_link[depth + 1] = 0u;
+                    }
+                    path_len = depth + 1;
+                    n_nodes += total;
+                    rollout = true;
+                    // the rollout's random cells, one Philox block per lane: off the serial chain of the game itself
+                    if (lane * 8 < 225 - ply)
+                        s_cells[wave][lane] = rollout_cells(prm.first_game_id + static_cast<uint32_t>(game), playout0 + static_cast<uint32_t>(it),
+                                                            static_cast<uint32_t>(init) << 8, static_cast<uint32_t>(lane), prm.seed_lo, prm.seed_hi);
+                }
             }
-            path_len = depth + 1;
-            n_nodes += total;
+        }
+        if (lane == 0) s_ply[wave] = rollout ? ply : -1;
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
+        __syncthreads();
+        // ---- Default::RandomRollout for the games of the workgroup, one lane each; a finished game stays in its `lines` ----
+        if (wave == roll_wave && lane < kWaves) {
+            const int stones = s_ply[lane];
+            if (stones >= 0)
+                s_winner[lane] = random_rollout_cells(s_mem[lane], 0, (stones & 1) ? -1 : 1, stones, s_cells[lane]);
+        }
+        __syncthreads();
+        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_roll += t - prof_t0; prof_t0 = t; }
+        if (!act || (status & 1u)) continue;
+        float value;                                            // for the player of `node`
+        if (rollout) {
+            const int to_move = (ply & 1) ? -1 : 1;
+            value = -static_cast<float>(to_move * s_winner[wave]);      // CalcScore(init_player, winner), seen from the player of `node`
         } else {
             value = five ? 1.0f : 0.0f;                         // CalcScore(node->player, winner): the mover won, or a tie
         }
-        wave_phase_fence();
 
         // ---- RAVE::BackPropogate<true> (MonteCarlo.hpp:154-184), leaf to root, on the finished board ----
         int swap_level = -1;
@@ -272,15 +297,20 @@ void rave_playouts_kernel(RaveParams prm) {
             valid = path_len;
         }
         wave_phase_fence();
+        if (prm.profile) prof_back += __builtin_amdgcn_s_memtime() - prof_t0;
     }
 
-    if (lane == 0) {
+    if (lane == 0 && exists) {
         hdr->n_nodes = n_nodes;
         hdr->init_acts = static_cast<uint32_t>(init);
         hdr->status = status;
         hdr->fresh = 0;
         hdr->root_black = static_cast<uint32_t>(root_black);
         hdr->playouts_done = playout0 + static_cast<uint32_t>(prm.playouts);
+        if (prm.profile) {
+            hdr->prof[0] = static_cast<uint32_t>(prof_sel >> 10); hdr->prof[1] = static_cast<uint32_t>(prof_roll >> 10);
+            hdr->prof[2] = static_cast<uint32_t>(prof_back >> 10); hdr->prof[3] = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - prof_all) >> 10);
+        }
     }
 }
 
@@ -317,9 +347,20 @@ extern "C" int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, u
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts;
     prm.seed_lo = static_cast<uint32_t>(seed); prm.seed_hi = static_cast<uint32_t>(seed >> 32); prm.first_game_id = first_game_id;
     prm.c_puct = c_puct;
+    static const bool profile = std::getenv("GMK_RAVE_PROFILE") != nullptr;
+    prm.profile = profile ? 1 : 0;
     const int grid = (t->n_games + kWaves - 1) / kWaves;
     hipLaunchKernelGGL(rave_playouts_kernel, dim3(grid), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), prm);
     GMK_HIP_CHECK(hipGetLastError());
+    if (profile) {                                              // share of a search spent per stage, mean over games
+        std::vector<TradHeader> hdr(static_cast<size_t>(t->n_games));
+        GMK_HIP_CHECK(hipDeviceSynchronize());
+        GMK_HIP_CHECK(hipMemcpy(hdr.data(), t->d_hdr, hdr.size() * sizeof(TradHeader), hipMemcpyDeviceToHost));
+        double sum[4] = {};
+        for (const TradHeader& h : hdr) for (int k = 0; k < 4; ++k) sum[k] += h.prof[k];
+        std::fprintf(stderr, "[GMK_RAVE_PROFILE] select + leaf position + expand %.1f %%, rollout %.1f %%, backup %.1f %% of the kernel's clocks\n",
+                     100 * sum[0] / sum[3], 100 * sum[1] / sum[3], 100 * sum[2] / sum[3]);
+    }
     return GMK_OK;
 }
 

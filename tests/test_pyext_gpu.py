@@ -96,6 +96,38 @@ def test_traditional_agent_plays_a_game():
         agents.TraditionalAgent(5.0, use_rave=True, c_iterations=10).get_action(core.Board())
 
 
+def test_poolrave_policy_matches_oracle(oracle):
+    """MCTS(policy=PoolRAVEPolicy) searches on the device (K8) and agrees with the oracle restatement move after move of an
+    agent loop with the tree kept and Dirichlet noise at the root, then a whole game through agents.RAVEAgent."""
+    O = oracle
+    core.set_seed(31337)
+    core.set_root_noise(0.05, 0.25)
+    m = core.MCTS(c_iterations=300, policy=core.PoolRAVEPolicy(2.0, 0.0))
+    om = O.PoolRAVEMCTS(2.0, 0.0, seed=31337, game_id=0)
+    om.set_noise(0.05, 0.25)
+    b = core.Board()
+    played = []
+    for mv in (112, 98, 127):
+        b.apply_move(core.Position(mv)); played.append(mv)
+    kept = []
+    for _ in range(4):
+        q, pi = m.eval_state(b)
+        om.run(played, 300)
+        v, oq, p, av, aq, best = om.root_children()
+        assert np.float32(q).tobytes() == np.float32(om.root_value).tobytes()
+        kids = {c.position.id: c for c in m.root.children}
+        assert sorted(kids) == [int(i) for i in np.nonzero(p)[0]]
+        assert all(kids[i].node_visits == int(v[i]) and np.float32(kids[i].state_value).tobytes() == oq[i].tobytes() for i in kids)
+        kept.append(int(m.root.node_visits))
+        m.step_forward()
+        assert m.root.position.id == best == om.step_forward()
+        b.apply_move(m.root.position); played.append(best)
+    assert max(kept[1:]) > 300
+    agent = agents.RAVEAgent(2.0, 0.0, c_iterations=100)
+    data = agents.dual_play({core.Player.black: agent, core.Player.white: agent}, verbose=True)
+    assert len(data) >= 9 and "PoolRAVEPolicy" in repr(agent)
+
+
 def test_agent_loop_keeps_the_tree_and_adds_root_noise(oracle):
     """The reference's MCTSAgent keeps its tree from move to move (syncWithBoard / stepForward, MCTS.cpp:119-147) and mixes
     Dirichlet noise into the root priors before every search (MCTS.cpp:182).  CorePyExt.MCTS does both on the device; the
