@@ -24,6 +24,15 @@ def test_out_of_order_and_bad_arguments():
     with pytest.raises(RuntimeError, match="set_positions"):
         t.step()
     t.close()
+    r = G.PoolRAVEMCTS(2, node_capacity=1024)
+    with pytest.raises(RuntimeError, match="set_positions"):
+        r.run(10)
+    with pytest.raises(RuntimeError, match="run_poolrave"):
+        r.root_stats()                                           # no AMAF statistics before the first PoolRAVE search
+    r.set_positions([[112], [112, 113]])
+    r.run(2)                                                     # 225 + 224 + 223 nodes do not fit in 1024... the second expansion does not
+    assert (r.root_stats()["n_nodes"] <= 1024).all()
+    r.close()
     a = G.AlphaZeroMCTS(2, node_capacity=1024)
     with pytest.raises(RuntimeError, match="set_roots"):
         a.select()

@@ -42,3 +42,26 @@ for g in range(n):
     v, qq, p, best = o.root_children()
     bad += int((v != st["visits"][g]).any()) + int((qq.view(np.uint32) != st["values"][g].view(np.uint32)).any()) + int(best != st["best"][g]) + int(o.n_nodes != st["n_nodes"][g]) + int(o.evaluator_updates != st["evaluator_updates"][g])
 print("K6: %d games x %d playouts, mismatches %d, status %s  (%.1f s)" % (n, P, bad, st["status"].tolist(), time.time() - t0), flush=True)
+# K8: 64 games x 3000 playouts, then a step and 1000 more from the kept subtrees
+n, P = 64, 3000
+moves, lens, _ = G.synth_boards(n, 0, first_board=777)
+pos = [[int(m) for m in moves[g, :min(int(lens[g]), g % 30)]] for g in range(n)]
+t = G.PoolRAVEMCTS(n, node_capacity=(P + 1200) * 225, c_puct=2.0, first_game_id=300); t.set_positions(pos); t.run(P)
+orcs = [O.PoolRAVEMCTS(2.0, 0.0, seed=G.DEFAULT_SEED, game_id=300 + g) for g in range(n)]
+def rave_bad(st):
+    bad = 0
+    for g in range(n):
+        v, qq, p, av, aq, best = orcs[g].root_children()
+        bad += int((v != st["visits"][g]).any()) + int((qq.view(np.uint32) != st["values"][g].view(np.uint32)).any()) + int(best != st["best"][g]) \
+             + int((av != st["amaf_visits"][g]).any()) + int((aq.view(np.uint32) != st["amaf_values"][g].view(np.uint32)).any())
+    return bad
+for g in range(n): orcs[g].run(pos[g], P)
+st = t.root_stats(); bad = rave_bad(st)
+print("K8: %d games x %d playouts, mismatches %d, status %s  (%.1f s)" % (n, P, bad, sorted(set(st["status"].tolist())), time.time() - t0), flush=True)
+t.step()
+for g in range(n):
+    if st["best"][g] >= 0: pos[g] = pos[g] + [orcs[g].step_forward()]
+t.run(1000)
+for g in range(n): orcs[g].run(pos[g], 1000)
+st = t.root_stats(); bad = rave_bad(st)
+print("K8 after a step: +1000 playouts from the kept subtrees, mismatches %d, root visits max %d  (%.1f s)" % (bad, int(st["root_visits"].max()), time.time() - t0), flush=True)
