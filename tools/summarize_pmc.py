@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 --pmc passes (one directory per pass, as tools/profile.sh leaves them under gpurun_out/) into the
 text summary committed under profiles/.
-Usage: summarize_pmc.py <dir with pmc_*/ subdirs> <boards per K1 launch> <playouts per K3 launch> [<playouts per K6 launch>]"""
+Usage: summarize_pmc.py <dir with pmc_*/ subdirs> <boards per K1 launch> <playouts per K3 launch> [<playouts per K6 launch> [<playouts per K8 launch>]]"""
 import collections
 import csv
 import glob
@@ -9,23 +9,26 @@ import sys
 
 root, n_boards, n_playouts = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 n_trad = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+n_rave = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 vals = collections.defaultdict(dict)
 for path in sorted(glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        k = "eval_positions_kernel" if "eval_positions" in name else "mcts_playouts_kernel" if "mcts_playouts" in name else "trad_playouts_kernel" if "trad_playouts" in name else None
+        k = "eval_positions_kernel" if "eval_positions" in name else "mcts_playouts_kernel" if "mcts_playouts" in name else "trad_playouts_kernel" if "trad_playouts" in name else "rave_playouts_kernel" if "rave_playouts" in name else None
         if k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k in agg:
         for c, v in agg[k].items():
             if k == "trad_playouts_kernel":                    # bench.py launches a short warm-up search first: keep the two full searches
                 v = sorted(v)[-2:]
+            if k == "rave_playouts_kernel":                    # likewise: the three full searches
+                v = sorted(v)[-3:]
             vals[k][c] = sum(v) / len(v)
 print("# rocprofv3 --pmc, one pass per counter group (separate runs), command: python3 bench.py --steps 5 --warmup 2 --mcts-reps 1 --no-cpu-baseline --az-games 0")
 print("# FETCH_SIZE / WRITE_SIZE are in KB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half the bytes of wide coalesced reads (x2 below);")
 print("# narrower accesses are uncalibrated (the 8-byte node reads of the MCTS kernel are given uncorrected and corrected).")
-for k, unit, per in (("eval_positions_kernel", "board", n_boards), ("mcts_playouts_kernel", "playout", n_playouts), ("trad_playouts_kernel", "playout", n_trad)):
+for k, unit, per in (("eval_positions_kernel", "board", n_boards), ("mcts_playouts_kernel", "playout", n_playouts), ("trad_playouts_kernel", "playout", n_trad), ("rave_playouts_kernel", "playout", n_rave)):
     v = vals.get(k)
     if not v:
         continue
