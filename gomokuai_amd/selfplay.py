@@ -119,14 +119,15 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
 
 
 def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None):
+                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional"):
     """n_games complete games of the reference's self-play SUPERVISOR against itself (config.py:9-12: "traditional_mcts",
     MCTS(TraditionalPolicy) on both sides), all games side by side on the current GPU: every move = one K6 search of
     `playouts` playouts per unfinished game (the games' evaluators are kept and synchronised like the policy objects of
     the reference; with reuse_subtree the chosen child's subtree is kept too, MCTS::stepForward, and root_noise =
     (alpha, epsilon) mixes Default::AddNoise into the root priors before every search), then MCTS::stepForward's choice
     is played.  Without noise the search is deterministic; variety then comes from the openings (synthetic generator,
-    `opening_plies` plies of game first_game_id + g).  Returns the same
+    `opening_plies` plies of game first_game_id + g).  policy="poolrave" plays the same loop with MCTS(PoolRAVEPolicy)
+    (agents/mcts.py:36-40) on both sides: K8 searches, random rollouts seeded by (seed, first_game_id + g).  Returns the same
     GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
     from . import core
     G.init(torch.cuda.current_device() if device is None else device.index)
@@ -145,7 +146,12 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
     visits = np.zeros((n_games, N, N), dtype=np.uint16)
     over = np.array([b.status["is_end"] for b in boards], dtype=bool)
     cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * 226 + 1, (1 << 24) - 1)
-    tree = G.TraditionalMCTS(n_games, node_capacity=cap, c_puct=c_puct)
+    if policy == "poolrave":
+        tree = G.PoolRAVEMCTS(n_games, node_capacity=cap, c_puct=c_puct, seed=seed, first_game_id=first_game_id)
+    elif policy == "traditional":
+        tree = G.TraditionalMCTS(n_games, node_capacity=cap, c_puct=c_puct)
+    else:
+        raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
     overflow = False
     for ply in range(max_moves):
         if over.all():

@@ -157,3 +157,23 @@ def test_supervisor_self_play(oracle):
             assert oracle.lib().go_board_check_move(C.byref(b), int(ra.moves[g, i]))
             oracle.lib().go_board_apply(C.byref(b), int(ra.moves[g, i]), 1)
         assert b.cur_player == 0 and b.winner == int(ra.winner[g])
+
+
+def test_poolrave_self_play(oracle):
+    """The same loop with MCTS(PoolRAVEPolicy) on both sides (K8 per move, subtree kept, root noise): legal, finished,
+    reproducible games."""
+    import ctypes as C
+    from gomokuai_amd import selfplay
+    kw = dict(opening_plies=2, first_game_id=21, c_puct=2.0, reuse_subtree=True, root_noise=(0.05, 0.25), seed=9, policy="poolrave")
+    a = selfplay.play_supervisor_games(5, 120, **kw)
+    b2 = selfplay.play_supervisor_games(5, 120, **kw)
+    assert (a.moves.cpu() == b2.moves.cpu()).all() and (a.winner.cpu() == b2.winner.cpu()).all() and not a.overflow
+    ra = a.cpu()
+    for g in range(len(a)):
+        b = oracle.new_board()
+        for i in range(int(ra.lens[g])):
+            assert oracle.lib().go_board_check_move(C.byref(b), int(ra.moves[g, i]))
+            oracle.lib().go_board_apply(C.byref(b), int(ra.moves[g, i]), 1)
+        assert b.cur_player == 0 and b.winner == int(ra.winner[g])
+    with pytest.raises(ValueError):
+        selfplay.play_supervisor_games(1, 10, policy="other")
