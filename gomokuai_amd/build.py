@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgomoku_hip.so")
 
-LIB_SOURCES = ["capi.hip", "eval_kernel.hip", "evalstate_kernel.hip", "trad_kernel.hip", "rave_kernel.hip", "az_kernel.hip", "mcts_kernel.hip", "records_kernel.hip", "pattern_tables.cpp", "synth.cpp"]
+LIB_SOURCES = ["capi.hip", "eval_kernel.hip", "evalstate_kernel.hip", "trad_kernel.hip", "rave_kernel.hip", "az_kernel.hip", "pvnet_kernel.hip", "mcts_kernel.hip", "records_kernel.hip", "pattern_tables.cpp", "synth.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: MCTS numerics (f64 PUCB from f32 operands, f32 running mean) must match the CPU
 # restatement bit for bit; hipcc fuses multiply-add by default.

@@ -1,0 +1,332 @@
+// pvnet_kernel.hip -- K9: the convolutional trunk of the policy-value network as ONE fused kernel on the f32 matrix cores.
+//
+// The network the network-guided search (K7) calls at every leaf is the reference's PolicyValueNetwork
+// (network/model_tf.py:28-66): conv3x3 6->32->64->128 (+ReLU), a 1x1 policy head (128->4, ReLU) and a 1x1 value head
+// (128->2, ReLU) on 15x15 boards, then small dense layers.  The convolutions are 99 % of its arithmetic (43 MFLOP per
+// position).  This kernel runs them for a batch of positions in float32 on v_mfma_f32_32x32x2_f32 (exact f32, same rate as
+// the vector FMA peak, MI355X_MICROARCH.md): one workgroup (4 wavefronts, one per SIMD) takes one position at a time and
+// keeps every activation in LDS; nothing but the 6 input planes is read from and nothing but the 1 350 head activations is
+// written to HBM per position.  The dense layers stay with the caller (a batched GEMM over all positions, PyTorch-ROCm).
+//
+// Formulation: every layer is Out^T[cout][pixel] = sum_k W^T[cout][k] * Act[k][pixel], k = (channel pair, tap):
+//   A operand (lane l: A[i = l & 31][k = l >> 5]) = weights, packed on the host in exactly that lane order, read from L2;
+//   B operand (lane l: B[k = l >> 5][j = l & 31]) = activations of 32 pixels for two adjacent input channels at one tap,
+//     one ds_read_b32 per MFMA: activations live in LDS as act[channel][17 x 17] with a zero border, so a tap is a
+//     constant address offset and "same" padding costs nothing;
+//   C/D (column = pixel on the lane, rows = 16 output channels in registers per lane half) -> bias, ReLU, one LDS write per
+//     register, conflict-free (lanes = consecutive pixels).
+// The 1x1 heads reuse the layer-3 accumulators as B operands directly (rows = channels = the summation index, the idiom
+// of cdna_hip_programming.md "An accumulator tile as the next MFMA's operand"): no transpose, no LDS round trip.
+// Wave w owns output channels [32 w, 32 w + 32) of layer 3 for all 8 pixel tiles (128 accumulator registers); layer 2
+// splits 2 channel tiles x 2 pixel halves over the waves, layer 1 the 8 pixel tiles.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "capi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPix = 225;
+constexpr int kPad = 289;                        // 17 x 17: the image with a zero border, per channel
+constexpr int kTiles = 8;                        // pixel tiles of 32 (225 -> 256)
+constexpr int kHeadRows = 6;                     // 4 policy + 2 value channels
+// LDS (floats): input planes | layer-1 activations | layer-2 activations | the four waves' partial head outputs [4][8][256]
+constexpr int oIn = 0, oAct1 = oIn + 6 * kPad, oAct2 = oAct1 + 32 * kPad, oPart = oAct2 + 64 * kPad, kLdsFloats = oPart + 4 * 8 * 256;
+constexpr int kInPerThread = (6 * kPix + 255) / 256;
+
+struct PvParams {
+    const float* states;                         // [n][6][225]
+    int n;
+    const float* w1;                             // packed A operands, see pack_layer(): [1 tile][27 k-pairs][64 lanes]
+    const float* w2;                             // [2 tiles][144][64]
+    const float* w3;                             // [4 tiles][288][64]
+    const float* wh;                             // heads: [4 waves][16 registers][64 lanes]
+    const float* b1; const float* b2; const float* b3; const float* bh;      // biases [32], [64], [128], [6]
+    float* pflat;                                // [n][900]  relu(policy conv), flattened (pixel, channel) like tf.layers.flatten of NHWC
+    float* vflat;                                // [n][450]  relu(value conv), flattened (pixel, channel)
+    unsigned long long* prof;                    // GMK_PVNET_PROFILE: shader clocks of workgroup 0 per stage (diagnostic runs only), else null
+};
+
+__device__ __forceinline__ int padded_index(int p) { return (p / 15 + 1) * 17 + (p % 15) + 1; }
+// row of the 32 x 32 C/D tile that register r of this lane holds (cdna_hip_programming.md, fragment layout)
+__device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// One convolution layer for NP pixel tiles and one tile of 32 output channels: acc[t] += W^T * Act over all k-pairs.
+// k-pair order (= the order pack_layer() writes): channel chunks of 2 * CP channels, inside a chunk the 9 taps, inside a tap
+// CP channel pairs.  `in` points at the layer's input activations in LDS, base[t] is this lane's byte offset for tile t:
+// ((lane >> 5) * kPad + padded_index(pixel) - 18) * 4, so that tap (ky, kx) of channel c adds (c * kPad + ky * 17 + kx) * 4.
+template <int CIN, int NP>
+__device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP], f32x16 (&acc)[NP]) {
+    constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
+    constexpr int STEPS = CIN / 2 / CP * 9;                      // one step = one tap of one chunk = CP k-pairs
+    static_assert(STEPS % 3 == 0, "the step loop is unrolled by three");
+    // Operands are fetched AHEAD of the MFMAs that use them, and the scheduling barriers keep the fetches where they are written
+    // (left alone, the compiler sinks every load to just before its use, and each MFMA then waits for LDS or L2 behind it):
+    //   * a step's CP weights two steps ahead, one global load per k-pair block, into one of three rotating register sets;
+    //   * the NP activation reads of a k-pair one k-pair ahead, one read behind each MFMA of the current k-pair.
+    // Three steps per loop iteration make the rotation of the weight sets free of register moves.
+    auto step_src = [in](int step) {
+        const int chunk = step / 9, tap = step - 9 * chunk;
+        return in + (chunk * 2 * CP * kPad + (tap / 3) * 17 + (tap % 3)) * 4;
+    };
+    float wA[CP], wB[CP], wC[CP], b[2][NP];
+#pragma unroll
+    for (int i = 0; i < CP; ++i) { wA[i] = w[i * 64 + lane]; wB[i] = w[(CP + i) * 64 + lane]; }
+#pragma unroll
+    for (int t = 0; t < NP; ++t) b[0][t] = *reinterpret_cast<const float*>(in + base[t]);
+    auto do_step = [&](int step, const float (&wc)[CP], float (&wl)[CP]) {
+        const char* src = step_src(step);
+        const char* src_next = step_src(min(step + 1, STEPS - 1));
+        const float* w_ahead = w + min(step + 2, STEPS - 1) * CP * 64 + lane;
+#pragma unroll
+        for (int cp = 0; cp < CP; ++cp) {
+            const int cur = cp & 1;
+#pragma unroll
+            for (int t = 0; t < NP; ++t)
+                b[cur ^ 1][t] = *reinterpret_cast<const float*>((cp + 1 < CP ? src + 2 * (cp + 1) * kPad * 4 : src_next) + base[t]);
+            wl[cp] = w_ahead[cp * 64];
+#pragma unroll
+            for (int t = 0; t < NP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
+            // issue order inside this block: MFMA, one LDS read (for the next k-pair), MFMA, one LDS read, ... then the weight load:
+            // every fetch sits in the 64-cycle shadow of the MFMA before it
+#pragma unroll
+            for (int t = 0; t < NP; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (CP & 1) {                                            // an odd number of k-pairs leaves the current operands in b[1]
+#pragma unroll
+            for (int t = 0; t < NP; ++t) b[0][t] = b[1][t];
+        }
+    };
+#pragma unroll 1
+    for (int step = 0; step < STEPS; step += 3) {
+        do_step(step, wA, wC);
+        do_step(step + 1, wB, wA);
+        do_step(step + 2, wC, wB);
+    }
+}
+
+// bias + ReLU on a C/D tile of 32 channels x 32 pixels and its store into the next layer's activations (valid pixels only)
+__device__ __forceinline__ void store_tile(float* out /* [channel][kPad] */, const f32x16& acc, const float (&bias)[16] /* of cd_row(r, lane) */, int cout0, int tile, int lane) {
+    const int p = tile * 32 + (lane & 31);
+    const int q = padded_index(min(p, kPix - 1));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = cout0 + cd_row(r, lane);
+        const float v = fmaxf(acc[r] + bias[r], 0.0f);
+        if (p < kPix) out[c * kPad + q] = v;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void pvnet_trunk_kernel(PvParams prm) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = 0.0f;       // the zero borders are written once
+    // this lane's read offset for pixel tile t (a pixel past the image reads pixel 224's neighbourhood; its column is never stored)
+    auto tile_base = [lane](int t) { return static_cast<uint32_t>(((lane >> 5) * kPad + padded_index(min(t * 32 + (lane & 31), kPix - 1)) - 18) * 4); };
+    uint32_t base_all[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) base_all[t] = tile_base(t);
+    __syncthreads();
+
+    // the input planes of a position travel through registers: fetched while the previous position computes, written into LDS
+    // (float32 [6][225] -> [6][17 x 17]) once layer 1 has read the previous ones
+    float in_next[kInPerThread];
+    auto fetch_input = [&](int img) {
+        const float* src = prm.states + static_cast<size_t>(min(img, prm.n - 1)) * 6 * kPix;
+#pragma unroll
+        for (int j = 0; j < kInPerThread; ++j) { const int i = threadIdx.x + 256 * j; in_next[j] = i < 6 * kPix ? src[i] : 0.0f; }
+    };
+    auto store_input = [&]() {
+#pragma unroll
+        for (int j = 0; j < kInPerThread; ++j) { const int i = threadIdx.x + 256 * j; if (i < 6 * kPix) lds[oIn + (i / kPix) * kPad + padded_index(i % kPix)] = in_next[j]; }
+    };
+    fetch_input(blockIdx.x);
+    store_input();
+    __syncthreads();
+
+    unsigned long long t_mark = 0, t_stage[6] = {};
+    auto stamp = [&](int stage) {
+        if (prm.prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage[stage] += t - t_mark; t_mark = t; }
+    };
+    if (prm.prof) t_mark = __builtin_amdgcn_s_memtime();
+    for (int img = blockIdx.x; img < prm.n; img += gridDim.x) {
+        fetch_input(img + gridDim.x);
+
+        // ---- layer 1: 6 -> 32, wave w takes pixel tiles 2w, 2w+1 ----
+        {
+            f32x16 acc[2] = {};
+            const uint32_t base[2] = {tile_base(2 * wave), tile_base(2 * wave + 1)};
+            float bias1[16];                                                  // of the channels this lane's accumulator registers hold; fetched before
+#pragma unroll                                                                // the layer so that their latency hides behind it
+            for (int r = 0; r < 16; ++r) bias1[r] = prm.b1[cd_row(r, lane)];
+            conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc);
+            store_tile(lds + oAct1, acc[0], bias1, 0, 2 * wave, lane);
+            store_tile(lds + oAct1, acc[1], bias1, 0, 2 * wave + 1, lane);
+        }
+        __syncthreads();
+        store_input();                                                        // layer 1 is done with the current planes
+        stamp(0);
+
+        // ---- layer 2: 32 -> 64, wave w takes channel tile w & 1 and pixel tiles 4 (w >> 1) .. + 3 ----
+        {
+            f32x16 acc[4] = {};
+            uint32_t base[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) base[t] = tile_base(4 * (wave >> 1) + t);
+            float bias2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias2[r] = prm.b2[32 * (wave & 1) + cd_row(r, lane)];
+            conv_tiles<32, 4>(reinterpret_cast<const char*>(lds + oAct1), prm.w2 + static_cast<size_t>(wave & 1) * 144 * 64, lane, base, acc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) store_tile(lds + oAct2, acc[t], bias2, 32 * (wave & 1), 4 * (wave >> 1) + t, lane);
+        }
+        stamp(1);
+        __syncthreads();
+        stamp(2);
+
+        // ---- layer 3: 64 -> 128, wave w takes channel tile w and all 8 pixel tiles; its output never leaves the registers ----
+        f32x16 acc[kTiles] = {};
+        float bias3[16], wh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bias3[r] = prm.b3[32 * wave + cd_row(r, lane)];
+            wh[r] = prm.wh[(wave * 16 + r) * 64 + lane];
+        }
+        conv_tiles<64, kTiles>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc);
+        stamp(3);
+
+        // ---- heads: Out6^T[j][pixel] = sum_c W6^T[j][c] * relu(Out3^T[c][pixel] + b3[c]); register r of the accumulators holds
+        //      channels cd_row(r, .) of this wave's 32 for the two lane halves = the two k of one MFMA ----
+        float* part = lds + oPart;                                            // [wave][8 rows][256 pixels]
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            f32x16 h = {};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r], fmaxf(acc[t][r] + bias3[r], 0.0f), h, 0, 0, 0);
+            // rows 0..3 sit in registers 0..3 of lanes 0..31, rows 4..7 in registers 0..3 of lanes 32..63
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(wave * 8 + cd_row(r, lane)) * 256 + t * 32 + (lane & 31)] = h[r];
+        }
+        __syncthreads();
+        stamp(4);
+        // ---- sum the four waves' partial head outputs, bias, ReLU, flatten (pixel, channel) ----
+        float* pf = prm.pflat + static_cast<size_t>(img) * 4 * kPix;
+        float* vf = prm.vflat + static_cast<size_t>(img) * 2 * kPix;
+        for (int i = threadIdx.x; i < kHeadRows * kPix; i += 256) {
+            // policy outputs first (index = pixel * 4 + channel), then value outputs (pixel * 2 + channel): coalesced stores
+            const bool policy = i < 4 * kPix;
+            const int k = policy ? i : i - 4 * kPix;
+            const int p = policy ? k >> 2 : k >> 1, j = policy ? (k & 3) : 4 + (k & 1);
+            const float s = ((part[(0 * 8 + j) * 256 + p] + part[(1 * 8 + j) * 256 + p]) + part[(2 * 8 + j) * 256 + p]) + part[(3 * 8 + j) * 256 + p];
+            const float v = fmaxf(s + prm.bh[j], 0.0f);
+            if (policy) pf[k] = v; else vf[k] = v;
+        }
+        // no barrier here: the partials are next written behind the two barriers of the next position's layers 1 and 2
+        stamp(5);
+    }
+    if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k) prm.prof[k] = t_stage[k];
+}
+
+// A operands of one layer in lane order: [cout tile][k-pair][64 lanes]; k-pair order as conv_tiles() walks it
+void pack_layer(const float* w /* [cout][cin][3][3] */, int cin, int cout, std::vector<float>& out) {
+    const int CP = cin >= 16 ? 8 : cin / 2, chunks = cin / 2 / CP, kps = chunks * 9 * CP;
+    out.assign(static_cast<size_t>(cout / 32) * kps * 64, 0.0f);
+    for (int tile = 0; tile < cout / 32; ++tile)
+        for (int chunk = 0; chunk < chunks; ++chunk)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int cp = 0; cp < CP; ++cp) {
+                    const int kp = (chunk * 9 + tap) * CP + cp;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = tile * 32 + (lane & 31), ci = chunk * 2 * CP + 2 * cp + (lane >> 5);
+                        out[(static_cast<size_t>(tile) * kps + kp) * 64 + lane] = w[(static_cast<size_t>(co) * cin + ci) * 9 + tap];
+                    }
+                }
+}
+
+}  // namespace
+
+struct gmk_pvnet {
+    float *d_w1 = nullptr, *d_w2 = nullptr, *d_w3 = nullptr, *d_wh = nullptr, *d_b = nullptr;
+    bool attr_set = false;
+};
+
+extern "C" int gmk_pvnet_destroy(gmk_pvnet* net) {
+    if (!net) return GMK_OK;
+    (void)hipFree(net->d_w1); (void)hipFree(net->d_w2); (void)hipFree(net->d_w3); (void)hipFree(net->d_wh); (void)hipFree(net->d_b);
+    delete net;
+    return GMK_OK;
+}
+
+extern "C" int gmk_pvnet_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                                const float* wp, const float* bp, const float* wv, const float* bv, gmk_pvnet** out) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !wp || !bp || !wv || !bv || !out) { gmk::set_error("gmk_pvnet_create: bad arguments"); return GMK_ERR_ARG; }
+    std::vector<float> p1, p2, p3, ph(4 * 16 * 64, 0.0f), bias(32 + 64 + 128 + 8, 0.0f);
+    pack_layer(w1, 6, 32, p1);
+    pack_layer(w2, 32, 64, p2);
+    pack_layer(w3, 64, 128, p3);
+    for (int wave = 0; wave < 4; ++wave)                         // A[i = head row j][k = lane >> 5] for accumulator register r of wave `wave`
+        for (int r = 0; r < 16; ++r)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int c = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
+                ph[(wave * 16 + r) * 64 + lane] = j < 4 ? wp[j * 128 + c] : j < 6 ? wv[(j - 4) * 128 + c] : 0.0f;
+            }
+    std::memcpy(&bias[0], b1, 32 * 4); std::memcpy(&bias[32], b2, 64 * 4); std::memcpy(&bias[96], b3, 128 * 4);
+    std::memcpy(&bias[224], bp, 4 * 4); std::memcpy(&bias[228], bv, 2 * 4);
+    gmk_pvnet* net = new gmk_pvnet;
+    const bool ok = hipMalloc(&net->d_w1, p1.size() * 4) == hipSuccess && hipMalloc(&net->d_w2, p2.size() * 4) == hipSuccess &&
+                    hipMalloc(&net->d_w3, p3.size() * 4) == hipSuccess && hipMalloc(&net->d_wh, ph.size() * 4) == hipSuccess &&
+                    hipMalloc(&net->d_b, bias.size() * 4) == hipSuccess &&
+                    hipMemcpy(net->d_w1, p1.data(), p1.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                    hipMemcpy(net->d_w2, p2.data(), p2.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                    hipMemcpy(net->d_w3, p3.data(), p3.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                    hipMemcpy(net->d_wh, ph.data(), ph.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                    hipMemcpy(net->d_b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { gmk_pvnet_destroy(net); gmk::set_error("gmk_pvnet_create: device allocation or copy failed"); return GMK_ERR_HIP; }
+    *out = net;
+    return GMK_OK;
+}
+
+extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, float* d_pflat, float* d_vflat, void* stream) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!net || n < 0 || (n > 0 && (!d_states || !d_pflat || !d_vflat))) { gmk::set_error("gmk_pvnet_forward: bad arguments"); return GMK_ERR_ARG; }
+    if (n == 0) return GMK_OK;
+    const size_t lds = static_cast<size_t>(kLdsFloats) * 4;
+    if (!net->attr_set) {
+        GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pvnet_trunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        net->attr_set = true;
+    }
+    PvParams prm;
+    prm.states = d_states; prm.n = n;
+    prm.w1 = net->d_w1; prm.w2 = net->d_w2; prm.w3 = net->d_w3; prm.wh = net->d_wh;
+    prm.b1 = net->d_b; prm.b2 = net->d_b + 32; prm.b3 = net->d_b + 96; prm.bh = net->d_b + 224;
+    prm.pflat = d_pflat; prm.vflat = d_vflat;
+    static const bool profile = std::getenv("GMK_PVNET_PROFILE") != nullptr;
+    prm.prof = nullptr;
+    if (profile) GMK_HIP_CHECK(hipMalloc(&prm.prof, 6 * sizeof(unsigned long long)));
+    const int grid = std::min(n, st.cu_count > 0 ? st.cu_count : 256);        // one workgroup per CU, each takes every grid-th position
+    hipLaunchKernelGGL(pvnet_trunk_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), prm);
+    GMK_HIP_CHECK(hipGetLastError());
+    if (profile) {
+        unsigned long long t[6];
+        GMK_HIP_CHECK(hipDeviceSynchronize());
+        GMK_HIP_CHECK(hipMemcpy(t, prm.prof, sizeof t, hipMemcpyDeviceToHost));
+        (void)hipFree(prm.prof);
+        const double per = 1.0 / ((n + grid - 1) / grid);
+        std::fprintf(stderr, "[GMK_PVNET_PROFILE] shader clocks per position (workgroup 0): layer 1 %.0f, layer 2 %.0f, wait %.0f, layer 3 %.0f, heads %.0f, output %.0f\n",
+                     t[0] * per, t[1] * per, t[2] * per, t[3] * per, t[4] * per, t[5] * per);
+    }
+    return GMK_OK;
+}

@@ -53,3 +53,48 @@ class PolicyValueNetwork(nn.Module):
         states = torch.from_numpy(np.asarray(board.encoded_states(), dtype=np.float32)[None]).to(dev)
         value, probs = self(states)
         return float(value[0]), probs[0].cpu().numpy()
+
+
+class FusedPolicyValueNetwork:
+    """The same function as PolicyValueNetwork.forward with the convolutions (99 % of the arithmetic) in ONE fused HIP kernel on
+    the f32 matrix cores (K9, gmk_pvnet_forward: activations never leave LDS) and the three small dense layers as batched
+    GEMMs in PyTorch-ROCm.  float32 throughout; sums run in a different order than MIOpen's, so outputs agree with the module's
+    to rounding (tests/test_pvnet_gpu.py: 2e-5), not bit for bit.  Takes the weights of `net` at construction."""
+
+    def __init__(self, net):
+        import ctypes as C
+        from . import lib as G
+        G.init()
+        self.net, self.G, self.h = net, G, C.c_void_p()
+        host = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy())
+        arrays = [host(net.conv[0].weight), host(net.conv[0].bias), host(net.conv[1].weight), host(net.conv[1].bias),
+                  host(net.conv[2].weight), host(net.conv[2].bias), host(net.policy_conv.weight).reshape(4, 128), host(net.policy_conv.bias),
+                  host(net.value_conv.weight).reshape(2, 128), host(net.value_conv.bias)]
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        G._check(G.load().gmk_pvnet_create(*[a.ctypes.data for a in arrays], C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self, "G", None) is not None and self.G.load is not None:
+            self.G.load().gmk_pvnet_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @torch.no_grad()
+    def trunk(self, states):
+        """states float32 [B, 6, 15, 15] on the GPU -> (relu(policy conv) [B, 900], relu(value conv) [B, 450]), flattened (pixel, channel)."""
+        assert states.is_cuda and states.dtype == torch.float32 and states.is_contiguous() and tuple(states.shape[1:]) == (6, 15, 15)
+        n = states.shape[0]
+        pflat = torch.empty((n, 900), dtype=torch.float32, device=states.device)
+        vflat = torch.empty((n, 450), dtype=torch.float32, device=states.device)
+        self.G._check(self.G.load().gmk_pvnet_forward(self.h, states.data_ptr(), n, pflat.data_ptr(), vflat.data_ptr(),
+                                                      torch.cuda.current_stream(states.device).cuda_stream))
+        return pflat, vflat
+
+    @torch.no_grad()
+    def __call__(self, states):
+        """states float32 [B, 6, 15, 15] -> (value [B], probs [B, 225])."""
+        pflat, vflat = self.trunk(states)
+        probs = F.softmax(self.net.policy_dense(pflat), dim=1)
+        value = torch.tanh(self.net.value_out(F.relu(self.net.value_hidden(vflat)))).reshape(-1)
+        return value, probs

@@ -256,6 +256,19 @@ int gmk_az_expand_host(gmk_az* a, const float* h_values, const float* h_probs);
 int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
                       float* h_root_value, int32_t* h_n_nodes, int32_t* h_status);
 
+/* ---- K9: the convolutional trunk of the policy-value network (the evaluator K7 calls at every leaf) as one fused kernel ----
+ * Replaces the convolution layers of PolicyValueNetwork (network/model_tf.py:28-66: conv3x3 6->32->64->128 with ReLU, the 1x1
+ * policy head 128->4 and the 1x1 value head 128->2, both with ReLU) for a batch of positions, in float32 on the f32 matrix cores.
+ * Weights are host arrays in PyTorch's conv layout [cout][cin][3][3] ([cout][cin] for the 1x1 heads), packed once at creation.
+ * gmk_pvnet_forward: d_states float32 [n][6][225] (Board.encoded_states(), game_ext.hpp:87-104) ->
+ *   d_pflat float32 [n][900] = relu(policy conv) flattened (pixel, channel), d_vflat float32 [n][450] likewise for the value head:
+ * the inputs of the network's dense layers (tf.layers.flatten of the NHWC tensors), which stay with the caller. */
+typedef struct gmk_pvnet gmk_pvnet;
+int gmk_pvnet_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                     const float* w_policy, const float* b_policy, const float* w_value, const float* b_value, gmk_pvnet** out);
+int gmk_pvnet_destroy(gmk_pvnet* net);
+int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, float* d_pflat, float* d_vflat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

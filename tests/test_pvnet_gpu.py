@@ -1,0 +1,101 @@
+"""K9: the fused convolution trunk of the policy-value network (gmk_pvnet_forward, f32 MFMA) against the plain PyTorch float32
+module of the same architecture (gomokuai_amd/network.py, network/model_tf.py:28-66).  Both compute in float32; the sums run in
+different orders, so the bar is a tolerance: 2e-5 absolute on activations of order 1 and on the final value / probabilities."""
+import numpy as np
+import pytest
+import torch
+
+from gomokuai_amd import lib as G
+from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _reference_trunk(net, states):
+    x = states
+    for conv in net.conv:
+        x = torch.relu(conv(x))
+    p = torch.relu(net.policy_conv(x)).permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+    v = torch.relu(net.value_conv(x)).permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+    return p, v
+
+
+def _encoded_states(n, first=0):
+    """real inputs: the six feature planes of positions from the synthetic generator"""
+    from oracle import oracle as O
+    import ctypes as C
+    moves, lens, _ = G.synth_boards(n, 1, first_board=first)
+    out = np.zeros((n, 6, 15, 15), np.float32)
+    for g in range(n):
+        b = O.new_board()
+        for i in range(int(lens[g]) - 1):
+            O.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        planes = np.zeros(6 * 225, np.uint8)
+        O.lib().go_board_encoded_states(C.byref(b), planes.ctypes.data)
+        out[g] = planes.reshape(6, 15, 15)
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 5, 300, 1029])
+def test_trunk_matches_torch(n):
+    G.init()
+    torch.manual_seed(n)
+    net = PolicyValueNetwork(seed=3).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():                                  # non-zero biases: the initialiser leaves them at zero
+            if hasattr(m, "bias") and m.bias is not None:
+                m.bias.uniform_(-0.2, 0.2)
+    fused = FusedPolicyValueNetwork(net)
+    states = torch.rand((n, 6, 15, 15), device="cuda") * 2 - 0.5
+    with torch.no_grad():
+        rp, rv = _reference_trunk(net, states)
+        rvalue, rprobs = net(states)
+    p, v = fused.trunk(states)
+    assert float((p - rp).abs().max()) < TOL * max(1.0, float(rp.abs().max())), float((p - rp).abs().max())
+    assert float((v - rv).abs().max()) < TOL * max(1.0, float(rv.abs().max()))
+    value, probs = fused(states)
+    assert float((value - rvalue).abs().max()) < TOL and float((probs - rprobs).abs().max()) < TOL
+    assert float(rp.abs().max()) > 0.1 and (rp > 0).any() and (rp == 0).any()          # the comparison is not vacuous
+    fused.close()
+
+
+def test_real_positions_and_search(oracle):
+    """Feature planes of real positions (zeros, ones, the border effects of 'same' padding at every edge), and a lock-step
+    search (K7) that calls the fused network: same visit counts as with the PyTorch module unless two children tie to rounding."""
+    G.init()
+    net = PolicyValueNetwork(seed=1).cuda().eval()
+    fused = FusedPolicyValueNetwork(net)
+    states = torch.from_numpy(_encoded_states(64)).cuda()
+    with torch.no_grad():
+        rvalue, rprobs = net(states)
+    value, probs = fused(states)
+    assert float((value - rvalue).abs().max()) < TOL and float((probs - rprobs).abs().max()) < TOL
+    n, playouts = 32, 40
+    moves, lens, _ = G.synth_boards(n, 0)
+    lens = np.minimum(lens, 4).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.stack([moves[np.arange(n), lens - 1], moves[np.arange(n), lens - 2]], 1).astype(np.int16)
+    stats = []
+    for network in (net, fused):
+        tree = G.AlphaZeroMCTS(n, node_capacity=playouts * 225 + 1)
+        tree.set_roots(planes, last)
+        with torch.no_grad():
+            tree.search(network, playouts)
+        stats.append(tree.root_stats())
+        tree.close()
+    assert (stats[0]["root_visits"] == stats[1]["root_visits"]).all()
+    assert (stats[0]["visits"] == stats[1]["visits"]).mean() > 0.99
+    assert np.abs(stats[0]["root_value"] - stats[1]["root_value"]).max() < 1e-4
+    fused.close()
+
+
+def test_errors():
+    G.init()
+    net = PolicyValueNetwork(seed=1).cuda().eval()
+    fused = FusedPolicyValueNetwork(net)
+    with pytest.raises(AssertionError):
+        fused.trunk(torch.zeros((2, 6, 15, 15), device="cuda", dtype=torch.float64))
+    p, v = fused.trunk(torch.zeros((0, 6, 15, 15), device="cuda"))
+    assert p.shape == (0, 900) and v.shape == (0, 450)
+    fused.close()
