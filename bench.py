@@ -205,40 +205,53 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
     """BASELINE configs[4]: network-guided MCTS (K7) in lock step, PolicyValueNetwork (PyTorch-ROCm, float32, random weights)
     at the leaves.  One step = one playout of every game = select kernel + network forward + expand kernel."""
     import numpy as np
-    from gomokuai_amd.network import PolicyValueNetwork
+    from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
     n, P = args.az_games, args.az_playouts
     moves, lens, planes, _ = mcts_openings(G, np, n, rank * n)
     last = np.stack([moves[np.arange(n), lens - 1], moves[np.arange(n), lens - 2]], 1).astype(np.int16)
     net = PolicyValueNetwork(seed=1).to(dev).eval()
+    fused = FusedPolicyValueNetwork(net)                   # K9: the convolutions as one fused f32-MFMA kernel, the dense layers in PyTorch
     tree = G.AlphaZeroMCTS(n, node_capacity=(P + 4) * 225 + 1)
     tree.set_roots(planes, last)
     with torch.no_grad():
-        tree.search(net, 3)                                # warm-up (MIOpen picks its kernels here)
+        tree.search(fused, 3)                              # warm-up
         torch.cuda.synchronize()
         if distributed:
             torch.distributed.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        tree.search(net, P)
+        tree.search(fused, P)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         s = tree.states.clone()
-        e0.record()
-        for _ in range(10):
-            net(s)
-        e1.record()
-        torch.cuda.synchronize()
-        net_ms = e0.elapsed_time(e1) / 10
+        def timed(fn, reps=10):
+            fn()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        net_ms, trunk_ms, torch_ms = timed(lambda: fused(s)), timed(lambda: fused.trunk(s)), timed(lambda: net(s))
+        dv, dp = fused(s), net(s)
+        err = max(float((dv[0] - dp[0]).abs().max()), float((dv[1] - dp[1]).abs().max()))
     if distributed:
         t = torch.tensor([ms], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     tree.close()
+    fused.close()
+    conv_flop = 2.0 * 225 * (54 * 32 + 288 * 64 + 576 * 128 + 128 * 6) * n
     return {"metric": "network-guided-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_step": ms / P,
             "network_ms_per_step": net_ms,
             "config": {"workload": "network-guided MCTS (K7), %d games x %d lock-step playouts per GPU, PolicyValueNetwork float32 with random weights, 4-ply openings" % (n, P)},
-            "note": "the step is the network's forward pass (MIOpen convolutions through PyTorch-ROCm); the select and expand kernels take the remainder"}
+            "roofline": {"bound": "mfma", "achieved": conv_flop / (trunk_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": conv_flop / (trunk_ms * 1e-3) / 1e12 / 157.3, "traffic": None, "kernel": "pvnet_trunk_kernel", "kernel_ms": trunk_ms,
+                         "alg_flop_per_launch": conv_flop, "note": "dense f32-input MFMA peak (MI355X_MICROARCH.md); the convolution FLOPs of the 225 real pixels"},
+            "pytorch_module_ms_per_step": torch_ms, "max_abs_diff_vs_pytorch_module": err,
+            "note": "the step is the network's forward pass: K9 (one fused kernel for the convolutions, float32 MFMA) + three small dense layers through PyTorch-ROCm; "
+                    "the select and expand kernels take the remainder"}
 
 
 def cpu_baseline_trad(G, playouts):
