@@ -21,6 +21,7 @@
 // splits 2 channel tiles x 2 pixel halves over the waves, layer 1 the 8 pixel tiles.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "capi_common.h"
@@ -54,11 +55,21 @@ __device__ __forceinline__ int padded_index(int p) { return (p / 15 + 1) * 17 + 
 // row of the 32 x 32 C/D tile that register r of this lane holds (cdna_hip_programming.md, fragment layout)
 __device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// The order in which a layer's k-pairs are walked (and packed): steps of CP k-pairs = one tap of one chunk of 2 * CP channels.
+// First the kernel rows ky = 0, 1 of every chunk, then the row ky = 2 of every chunk: the taps that the corner tile may skip
+// (see CORNER below) form one loop of their own.
+__host__ __device__ inline void step_chunk_tap(int step, int chunks, int& chunk, int& tap) {
+    const int first = 6 * chunks;
+    if (step < first) { chunk = step / 6; tap = step - 6 * chunk; }
+    else { chunk = (step - first) / 3; tap = 6 + (step - first) - 3 * chunk; }
+}
+
 // One convolution layer for NP pixel tiles and one tile of 32 output channels: acc[t] += W^T * Act over all k-pairs.
-// k-pair order (= the order pack_layer() writes): channel chunks of 2 * CP channels, inside a chunk the 9 taps, inside a tap
-// CP channel pairs.  `in` points at the layer's input activations in LDS, base[t] is this lane's byte offset for tile t:
+// k-pair order (= the order pack_layer() writes): steps as step_chunk_tap() numbers them, inside a step CP channel pairs.  `in` points at the layer's input activations in LDS, base[t] is this lane's byte offset for tile t:
 // ((lane >> 5) * kPad + padded_index(pixel) - 18) * 4, so that tap (ky, kx) of channel c adds (c * kPad + ky * 17 + kx) * 4.
-template <int CIN, int NP>
+// CORNER: the last tile is pixel tile 7, whose only real pixel is the corner (14, 14): its taps with ky = 2 or kx = 2 read the zero
+// border, so their MFMAs (5 of 9) add exact zeros and are left out.
+template <int CIN, int NP, bool CORNER = false>
 __device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP], f32x16 (&acc)[NP]) {
     constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
     constexpr int STEPS = CIN / 2 / CP * 9;                      // one step = one tap of one chunk = CP k-pairs
@@ -69,7 +80,8 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
     //   * the NP activation reads of a k-pair one k-pair ahead, one read behind each MFMA of the current k-pair.
     // Three steps per loop iteration make the rotation of the weight sets free of register moves.
     auto step_src = [in](int step) {
-        const int chunk = step / 9, tap = step - 9 * chunk;
+        int chunk, tap;
+        step_chunk_tap(step, STEPS / 9, chunk, tap);
         return in + (chunk * 2 * CP * kPad + (tap / 3) * 17 + (tap % 3)) * 4;
     };
     float wA[CP], wB[CP], wC[CP], b[2][NP];
@@ -77,26 +89,29 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
     for (int i = 0; i < CP; ++i) { wA[i] = w[i * 64 + lane]; wB[i] = w[(CP + i) * 64 + lane]; }
 #pragma unroll
     for (int t = 0; t < NP; ++t) b[0][t] = *reinterpret_cast<const float*>(in + base[t]);
-    auto do_step = [&](int step, const float (&wc)[CP], float (&wl)[CP]) {
+    auto do_step = [&](int step, const float (&wc)[CP], float (&wl)[CP], auto skip_last) {
+        constexpr int NT = decltype(skip_last)::value ? NP - 1 : NP;         // tiles that take part in this step
         const char* src = step_src(step);
         const char* src_next = step_src(min(step + 1, STEPS - 1));
         const float* w_ahead = w + min(step + 2, STEPS - 1) * CP * 64 + lane;
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
             const int cur = cp & 1;
+            const int nr = cp + 1 < CP ? NT : NP;                           // the next step may need the last tile again: always fetch it at the boundary
 #pragma unroll
-            for (int t = 0; t < NP; ++t)
+            for (int t = 0; t < nr; ++t)
                 b[cur ^ 1][t] = *reinterpret_cast<const float*>((cp + 1 < CP ? src + 2 * (cp + 1) * kPad * 4 : src_next) + base[t]);
             wl[cp] = w_ahead[cp * 64];
 #pragma unroll
-            for (int t = 0; t < NP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
             // issue order inside this block: MFMA, one LDS read (for the next k-pair), MFMA, one LDS read, ... then the weight load:
             // every fetch sits in the 64-cycle shadow of the MFMA before it
 #pragma unroll
-            for (int t = 0; t < NP; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            if (nr > NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -105,11 +120,19 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
             for (int t = 0; t < NP; ++t) b[0][t] = b[1][t];
         }
     };
+    constexpr std::integral_constant<bool, false> all_tiles{};
+    constexpr std::integral_constant<bool, CORNER> corner_out{};
 #pragma unroll 1
-    for (int step = 0; step < STEPS; step += 3) {
-        do_step(step, wA, wC);
-        do_step(step + 1, wB, wA);
-        do_step(step + 2, wC, wB);
+    for (int step = 0; step < STEPS / 9 * 6; step += 3) {        // three steps = the taps kx = 0, 1, 2 of one kernel row ky < 2
+        do_step(step, wA, wC, all_tiles);
+        do_step(step + 1, wB, wA, all_tiles);
+        do_step(step + 2, wC, wB, corner_out);                   // kx = 2
+    }
+#pragma unroll 1
+    for (int step = STEPS / 9 * 6; step < STEPS; step += 3) {    // ky = 2
+        do_step(step, wA, wC, corner_out);
+        do_step(step + 1, wB, wA, corner_out);
+        do_step(step + 2, wC, wB, corner_out);
     }
 }
 
@@ -201,7 +224,7 @@ void pvnet_trunk_kernel(PvParams prm) {
             bias3[r] = prm.b3[32 * wave + cd_row(r, lane)];
             wh[r] = prm.wh[(wave * 16 + r) * 64 + lane];
         }
-        conv_tiles<64, kTiles>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc);
+        conv_tiles<64, kTiles, true>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc);
         stamp(3);
 
         // ---- heads: Out6^T[j][pixel] = sum_c W6^T[j][c] * relu(Out3^T[c][pixel] + b3[c]); register r of the accumulators holds
@@ -239,18 +262,20 @@ void pvnet_trunk_kernel(PvParams prm) {
 
 // A operands of one layer in lane order: [cout tile][k-pair][64 lanes]; k-pair order as conv_tiles() walks it
 void pack_layer(const float* w /* [cout][cin][3][3] */, int cin, int cout, std::vector<float>& out) {
-    const int CP = cin >= 16 ? 8 : cin / 2, chunks = cin / 2 / CP, kps = chunks * 9 * CP;
+    const int CP = cin >= 16 ? 8 : cin / 2, chunks = cin / 2 / CP, steps = chunks * 9, kps = steps * CP;
     out.assign(static_cast<size_t>(cout / 32) * kps * 64, 0.0f);
     for (int tile = 0; tile < cout / 32; ++tile)
-        for (int chunk = 0; chunk < chunks; ++chunk)
-            for (int tap = 0; tap < 9; ++tap)
-                for (int cp = 0; cp < CP; ++cp) {
-                    const int kp = (chunk * 9 + tap) * CP + cp;
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int co = tile * 32 + (lane & 31), ci = chunk * 2 * CP + 2 * cp + (lane >> 5);
-                        out[(static_cast<size_t>(tile) * kps + kp) * 64 + lane] = w[(static_cast<size_t>(co) * cin + ci) * 9 + tap];
-                    }
+        for (int step = 0; step < steps; ++step) {
+            int chunk, tap;
+            step_chunk_tap(step, chunks, chunk, tap);
+            for (int cp = 0; cp < CP; ++cp) {
+                const int kp = step * CP + cp;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = tile * 32 + (lane & 31), ci = chunk * 2 * CP + 2 * cp + (lane >> 5);
+                    out[(static_cast<size_t>(tile) * kps + kp) * 64 + lane] = w[(static_cast<size_t>(co) * cin + ci) * 9 + tap];
                 }
+            }
+        }
 }
 
 }  // namespace
