@@ -98,3 +98,12 @@ class FusedPolicyValueNetwork:
         probs = F.softmax(self.net.policy_dense(pflat), dim=1)
         value = torch.tanh(self.net.value_out(F.relu(self.net.value_hidden(vflat)))).reshape(-1)
         return value, probs
+
+    @torch.no_grad()
+    def eval_state(self, board):
+        """PolicyValueNetwork.eval_state (model_tf.py:136-145) through the fused kernel: one position -> (value, probs[225]) on the
+        host; what agents.PyConvNetAgent(network, c_puct) calls once per playout."""
+        dev = next(self.net.parameters()).device
+        states = torch.from_numpy(np.asarray(board.encoded_states(), dtype=np.float32)[None]).to(dev)
+        value, probs = self(states)
+        return float(value[0]), probs[0].cpu().numpy()

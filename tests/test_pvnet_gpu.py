@@ -90,6 +90,24 @@ def test_real_positions_and_search(oracle):
     fused.close()
 
 
+def test_eval_state_for_agents():
+    """FusedPolicyValueNetwork.eval_state(board) is what PyConvNetAgent calls per playout (agents/alphazero.py:5-9)."""
+    from gomokuai_amd import agents, core
+    G.init()
+    net = PolicyValueNetwork(seed=2).cuda().eval()
+    fused = FusedPolicyValueNetwork(net)
+    b = core.Board()
+    for mv in (112, 113, 97):
+        b.apply_move(core.Position(mv))
+    v0, p0 = net.eval_state(b)
+    v1, p1 = fused.eval_state(b)
+    assert abs(v0 - v1) < TOL and np.abs(p0 - p1).max() < TOL and abs(float(p1.sum()) - 1) < 1e-4
+    agent = agents.PyConvNetAgent(fused, 5.0, c_iterations=30)
+    move = agent.get_action(b)
+    assert b.check_move(move)
+    fused.close()
+
+
 def test_errors():
     G.init()
     net = PolicyValueNetwork(seed=1).cuda().eval()
