@@ -20,6 +20,7 @@
 #include "board_device.h"
 #include "capi_common.h"
 #include "philox.h"
+#include "root_noise.h"
 
 namespace {
 
@@ -417,22 +418,11 @@ extern "C" int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint
     if (rc != GMK_OK) return rc;
     std::vector<AzHeader> hdr(n);
     GMK_HIP_CHECK(hipMemcpy(hdr.data(), a->t.hdr, n * sizeof(AzHeader), hipMemcpyDeviceToHost));
-    const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
     for (size_t g = 0; g < n; ++g) {
         float* p = &priors[g * 225];
-        int n_child = 0;
-        for (int i = 0; i < 225; ++i) n_child += p[i] != 0.0f;
-        if (!n_child) continue;
-        std::mt19937 engine(gmk::philox4x32_10(first_game_id + static_cast<uint32_t>(g), hdr[g].stones, 0x6E6F6973u, 0u, k0, k1).v[0]);
-        std::gamma_distribution<float> gamma(alpha, 1.0f);
-        float noise[225], sq = 0.0f;
-        for (int i = 0; i < 225; ++i) {
-            p[i] *= 1 - epsilon;
-            noise[i] = p[i] ? gamma(engine) : 0.0f;
-            sq += noise[i] * noise[i];
-        }
-        const float norm = sq > 0.0f ? std::sqrt(sq) : 1.0f;
-        for (int i = 0; i < 225; ++i) p[i] += epsilon * (sq > 0.0f ? noise[i] / norm : noise[i]);
+        bool any = false;
+        for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
+        if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + static_cast<uint32_t>(g), hdr[g].stones));
     }
     if (!a->d_noise_priors) GMK_HIP_CHECK(hipMalloc(&a->d_noise_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(a->d_noise_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));

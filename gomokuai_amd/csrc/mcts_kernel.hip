@@ -28,6 +28,7 @@
 #include "board_device.h"
 #include "philox.h"
 #include "rollout_device.h"
+#include "root_noise.h"
 
 namespace {
 
@@ -652,9 +653,7 @@ extern "C" int gmk_mcts_step_host(gmk_mcts* m, const int16_t* h_moves, int reuse
 
 // Default::AddNoise (MonteCarlo.hpp:97-108) for every unfinished game whose root already has children:
 //   P <- (1 - epsilon) * P + epsilon * normalized(gamma(alpha, 1) per child)        (Statistical.hpp:29-34)
-// The draws use the toolchain's own std::gamma_distribution<float> over std::mt19937, exactly the distribution
-// code the reference runs; only the engine's seed differs (the reference: random_device; here: Philox of
-// (seed; game id, stones on the root board, 'nois')), so searches stay reproducible.  Host side: 225 floats a game.
+// (root_noise.h).  Host side: 225 floats a game.
 extern "C" int gmk_mcts_add_root_noise(gmk_mcts* m, float alpha, float epsilon, void* stream) {
     if (!m || !(alpha > 0.0f)) { gmk::set_error("gmk_mcts_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -668,24 +667,15 @@ extern "C" int gmk_mcts_add_root_noise(gmk_mcts* m, float alpha, float epsilon, 
     GMK_HIP_CHECK(hipMemcpyAsync(hdr.data(), m->d_headers, sizeof(GameHeader) * n, hipMemcpyDeviceToHost, s));
     GMK_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<float> prior(n * 225, 0.0f);
-    const uint32_t k0 = static_cast<uint32_t>(m->seed), k1 = static_cast<uint32_t>(m->seed >> 32);
     for (size_t g = 0; g < n; ++g) {
         GameHeader& h = hdr[g];
         h.noise = 0;
         if ((h.status & 1u) || !h.root_expanded) continue;           // AddNoise is a no-op on a childless root
         const int n_child = 225 - static_cast<int>(h.stones);
         float* p = &prior[g * 225];
-        std::mt19937 engine(gmk::philox4x32_10(h.game_id, h.stones, 0x6E6F6973u, 0u, k0, k1).v[0]);
-        std::gamma_distribution<float> gamma(alpha, 1.0f);
-        float noise[225], sq = 0.0f;
-        const float uniform = 1.0f / static_cast<float>(n_child);
-        for (int i = 0; i < n_child; ++i) {
-            p[i] = uniform * (1 - epsilon);                           // prior_probs *= 1 - epsilon
-            noise[i] = p[i] ? gamma(engine) : 0.0f;
-            sq += noise[i] * noise[i];
-        }
-        const float norm = sq > 0.0f ? std::sqrt(sq) : 1.0f;          // VectorXf::normalized()
-        for (int i = 0; i < n_child; ++i) p[i] += epsilon * (sq > 0.0f ? noise[i] / norm : noise[i]);
+        const float uniform = 1.0f / static_cast<float>(n_child);     // Default::UniformProbs: the priors Expand gave the children
+        for (int i = 0; i < n_child; ++i) p[i] = uniform;
+        gmk::mix_root_noise(p, n_child, alpha, epsilon, gmk::root_noise_engine_seed(m->seed, h.game_id, h.stones));
         h.noise = 1;
     }
     GMK_HIP_CHECK(hipMemcpyAsync(m->d_root_prior, prior.data(), prior.size() * sizeof(float), hipMemcpyHostToDevice, s));

@@ -24,6 +24,7 @@
 
 #include "evalstate_device.h"
 #include "philox.h"
+#include "root_noise.h"
 #include "trad_tree.h"
 
 namespace {
@@ -780,10 +781,7 @@ extern "C" int gmk_trad_step(gmk_trad* t, const int16_t* h_moves) {
     return GMK_OK;
 }
 
-// Default::AddNoise (MonteCarlo.hpp:97-108) on every root that has children:
-//   P <- (1 - epsilon) * P + epsilon * normalized(gamma(alpha, 1) per child, ascending cell)   (Statistical.hpp:29-34)
-// drawn with the toolchain's std::gamma_distribution<float> over std::mt19937 like the reference; the engine is seeded with
-// Philox(seed; game id, stones on the root board, 'nois') instead of random_device (as gmk_mcts_add_root_noise does).
+// Default::AddNoise (MonteCarlo.hpp:97-108) on every root that has children (root_noise.h)
 extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id) {
     if (!t || !(alpha > 0.0f)) { gmk::set_error("gmk_trad_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
     if (!t->positioned) { gmk::set_error("gmk_trad_add_root_noise: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
@@ -793,22 +791,11 @@ extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, 
     int rc = gmk_trad_root_stats(t, nullptr, nullptr, priors.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc != GMK_OK) return rc;
     GMK_HIP_CHECK(hipMemcpy(lens.data(), t->d_lens, n * 4, hipMemcpyDeviceToHost));
-    const uint32_t k0 = static_cast<uint32_t>(seed), k1 = static_cast<uint32_t>(seed >> 32);
     for (size_t g = 0; g < n; ++g) {
         float* p = &priors[g * 225];
-        int n_child = 0;
-        for (int i = 0; i < 225; ++i) n_child += p[i] != 0.0f;
-        if (!n_child) continue;
-        std::mt19937 engine(gmk::philox4x32_10(first_game_id + static_cast<uint32_t>(g), static_cast<uint32_t>(lens[g]), 0x6E6F6973u, 0u, k0, k1).v[0]);
-        std::gamma_distribution<float> gamma(alpha, 1.0f);
-        float noise[225], sq = 0.0f;
-        for (int i = 0; i < 225; ++i) {
-            p[i] *= 1 - epsilon;
-            noise[i] = p[i] ? gamma(engine) : 0.0f;
-            sq += noise[i] * noise[i];
-        }
-        const float norm = sq > 0.0f ? std::sqrt(sq) : 1.0f;
-        for (int i = 0; i < 225; ++i) p[i] += epsilon * (sq > 0.0f ? noise[i] / norm : noise[i]);
+        bool any = false;
+        for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
+        if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + static_cast<uint32_t>(g), static_cast<uint32_t>(lens[g])));
     }
     if (!t->d_priors) GMK_HIP_CHECK(hipMalloc(&t->d_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(t->d_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
