@@ -52,6 +52,18 @@ def cases():
         v, q, p, best = t.root_children()
         stats += [v, q.view(np.uint32), p.view(np.uint32), np.array([best, t.n_nodes], np.int64)]
     out["mcts_traditional"] = {"games": 6, "playouts": 500, "first_board": 999, "sha256": digest(*stats)}
+    # K8: PoolRAVE searches, a step to the most visited child in between
+    moves, lens, _ = G.synth_boards(5, 0, first_board=1234)
+    stats = []
+    for g in range(5):
+        pos = [int(x) for x in moves[g, :min(int(lens[g]), 3 + g)]]
+        t = O.PoolRAVEMCTS(2.0, 0.0, seed=G.DEFAULT_SEED, game_id=60 + g)
+        t.run(pos, 300)
+        pos.append(t.step_forward())
+        t.run(pos, 200)
+        v, q, p, av, aq, best = t.root_children()
+        stats += [v, q.view(np.uint32), p.view(np.uint32), av, aq.view(np.uint32), np.array([best, t.root_visits], np.int64)]
+    out["mcts_poolrave"] = {"games": 5, "playouts": [300, 200], "first_board": 1234, "first_game_id": 60, "sha256": digest(*stats)}
     return out
 
 

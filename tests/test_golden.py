@@ -52,3 +52,18 @@ def test_device_reproduces_the_golden_digests():
         stats += [st["visits"][g], st["values"][g].view(np.uint32), st["priors"][g].view(np.uint32), np.array([st["best"][g], st["n_nodes"][g]], np.int64)]
     assert mk.digest(*stats) == case["sha256"]
     t.close()
+    case = GOLDEN["mcts_poolrave"]
+    n = case["games"]
+    moves, lens, _ = G.synth_boards(n, 0, first_board=case["first_board"])
+    t = G.PoolRAVEMCTS(n, node_capacity=1 << 18, c_puct=2.0, first_game_id=case["first_game_id"])
+    t.set_positions([[int(x) for x in moves[g, :min(int(lens[g]), 3 + g)]] for g in range(n)])
+    t.run(case["playouts"][0])
+    t.step()
+    t.run(case["playouts"][1])
+    st = t.root_stats()
+    stats = []
+    for g in range(n):
+        stats += [st["visits"][g], st["values"][g].view(np.uint32), st["priors"][g].view(np.uint32), st["amaf_visits"][g], st["amaf_values"][g].view(np.uint32),
+                  np.array([st["best"][g], st["root_visits"][g]], np.int64)]
+    assert mk.digest(*stats) == case["sha256"]
+    t.close()
