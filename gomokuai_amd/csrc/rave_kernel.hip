@@ -336,6 +336,8 @@ extern "C" int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, u
     if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
     if (!t || playouts < 0) { gmk::set_error("gmk_trad_run_poolrave: bad arguments"); return GMK_ERR_ARG; }
     if (!t->positioned) { gmk::set_error("gmk_trad_run_poolrave: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
+    if (t->policy == 1) { gmk::set_error("gmk_trad_run_poolrave: this handle searches with gmk_trad_run (its nodes carry no AMAF statistics)"); return GMK_ERR_STATE; }
+    t->policy = 2;
     if (!t->d_amaf) {
         const size_t nodes = static_cast<size_t>(t->n_games) * static_cast<size_t>(t->cap);
         GMK_HIP_CHECK(hipMalloc(&t->d_amaf, nodes * 8));

@@ -726,6 +726,8 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     gmk::DeviceState& st = gmk::device_state();
     if (!t || playouts < 0) { gmk::set_error("gmk_trad_run: bad arguments"); return GMK_ERR_ARG; }
     if (!t->positioned) { gmk::set_error("gmk_trad_run: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
+    if (t->policy == 2) { gmk::set_error("gmk_trad_run: this handle searches with gmk_trad_run_poolrave (its evaluators are not kept in step)"); return GMK_ERR_STATE; }
+    t->policy = 1;
     const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4) * 4;
     if (lds > 160u * 1024u) { gmk::set_error("gmk_trad_run: tables do not fit in LDS (%zu bytes)", lds); return GMK_ERR_CAPACITY; }
     if (!t->attr_set) {

@@ -79,6 +79,7 @@ struct gmk_trad {
     uint8_t* d_moves = nullptr;
     int32_t* d_lens = nullptr;
     bool attr_set = false, positioned = false;
+    int policy = 0;                                                          // 0 not searched yet, 1 TraditionalPolicy (gmk_trad_run), 2 PoolRAVEPolicy (gmk_trad_run_poolrave): one per handle
 
     gmk::tree::TradArena arena() const { return {d_stat, d_info, d_link, d_front, d_ord, d_amaf}; }
     gmk::tree::TradArena arena2() const { return {d_stat2, d_info2, d_link2, d_front2, d_ord2, d_amaf2}; }

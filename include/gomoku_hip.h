@@ -223,7 +223,8 @@ int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density,
  * set_positions, step, add_root_noise and root_stats are the gmk_trad_* entry points above (the handle's evaluators are
  * not used); this call runs `playouts` MCTS::playout iterations per game with PoolRAVE's stages.  Rollout draws: Philox4x32-10,
  * key = seed, counter = (first_game_id + game, playout since the root last changed, stones on the root board << 8, ply >> 3),
- * as K3 with rollout number 0.  c_bias only reaches RAVE::MinMSE, which the reference leaves unused (:130-139): no argument. */
+ * as K3 with rollout number 0.  c_bias only reaches RAVE::MinMSE, which the reference leaves unused (:130-139): no argument.
+ * A handle searches with ONE policy: mixing gmk_trad_run and gmk_trad_run_poolrave on it returns GMK_ERR_STATE. */
 int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, uint64_t seed, uint32_t first_game_id, void* stream);
 /* the root children's all-moves-as-first statistics by cell (AMAFNode::amaf_visits / amaf_value), host [n][225] each */
 int gmk_trad_root_amaf(gmk_trad* t, uint32_t* h_amaf_visits, float* h_amaf_values);

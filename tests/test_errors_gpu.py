@@ -32,6 +32,8 @@ def test_out_of_order_and_bad_arguments():
     r.set_positions([[112], [112, 113]])
     r.run(2)                                                     # 225 + 224 + 223 nodes do not fit in 1024... the second expansion does not
     assert (r.root_stats()["n_nodes"] <= 1024).all()
+    with pytest.raises(RuntimeError, match="run_poolrave"):
+        G.TraditionalMCTS.run(r, 5)                              # one policy per handle
     r.close()
     a = G.AlphaZeroMCTS(2, node_capacity=1024)
     with pytest.raises(RuntimeError, match="set_roots"):
