@@ -115,8 +115,54 @@ class MCTSAgent(Agent):
             self.mcts.reset()
 
 
+class PatternEvalAgent(Agent):
+    """Agent.h:108-161: no search, the move with the largest Heuristic::EvaluationProbs after DecisiveFilter on the agent's own
+    incremental evaluator (Heuristic.hpp:16-28, 94-161); the centre on an empty board.  On the GPU that is the policy head of K6:
+    the root priors after one playout of a one-game handle, whose evaluator persists and is synchronised like the reference's.
+    The debug message gives the pattern and compound counts before and after the move (K1 on the two positions)."""
+
+    def __init__(self):
+        self.tree, self.moves, self.this_move = None, [], None
+
+    def name(self):
+        return "PatternEvalAgent"
+
+    def sync_with_board(self, board):
+        self.moves = [int(p.id) for p in board.move_record]
+
+    def get_action(self, board):
+        from . import lib as G
+        core = _core()
+        if not self.moves:
+            self.this_move = core.Position(7, 7)
+        else:
+            if self.tree is None:
+                self.tree = G.TraditionalMCTS(1, node_capacity=1024)
+            self.tree.set_positions([self.moves])
+            self.tree.run(1)
+            self.this_move = core.Position(int(np.argmax(self.tree.root_stats()["priors"][0])))      # maxCoeff: the first maximum
+        return self.this_move
+
+    def debug_message(self):
+        from . import lib as G
+        after = self.moves + [int(self.this_move.id)]
+        moves = np.zeros((2, 64 if len(after) <= 64 else 225), np.uint8)
+        moves[0, :len(self.moves)] = self.moves
+        moves[1, :len(after)] = after
+        planes = G.moves_to_planes(moves, np.array([len(self.moves), len(after)], np.int32))
+        totals = G.eval_batch_host(planes)[2]
+        def message(t):                                            # Record: white in the low, black in the high 16 bits (Pattern.cpp:390-393)
+            return {name: [[int((t[i] >> sh) & 0xFFFF) for i in range(8)], [int((t[8 + i] >> sh) & 0xFFFF) for i in range(3)]]
+                    for name, sh in (("black", 16), ("white", 0))}
+        return {"before": message(totals[0]), "current": message(totals[1])}
+
+    def reset(self):
+        if self.tree is not None:
+            self.tree.reset_evaluators()
+
+
 def make_agent(spec, milliseconds=960, iterations=None, quiet=False):
-    """'random', 'human', 'random-mcts[:c_puct[:c_rollouts]]', 'traditional[:c_puct]', 'poolrave[:c_puct[:c_bias]]'."""
+    """'random', 'human', 'pattern', 'random-mcts[:c_puct[:c_rollouts]]', 'traditional[:c_puct]', 'poolrave[:c_puct[:c_bias]]'."""
     core = _core()
     kind, *args = spec.split(":")
     num = [float(a) for a in args]
@@ -124,6 +170,8 @@ def make_agent(spec, milliseconds=960, iterations=None, quiet=False):
         return RandomAgent()
     if kind == "human":
         return HumanAgent()
+    if kind == "pattern":
+        return PatternEvalAgent()
     if kind == "random-mcts":
         policy = core.RandomPolicy(num[0] if num else 5.0, int(num[1]) if len(num) > 1 else 5)
     elif kind == "traditional":

@@ -42,3 +42,34 @@ def test_keep_alive_and_console_with_searches():
                                       interface.make_agent("random-mcts:5:5", iterations=120, quiet=True), out, black_player=0)
     record = json.loads(out.getvalue().strip().splitlines()[-1])
     assert tie in (0, 1) and len(record["responses"]) >= 5 and ("Game end" in out.getvalue() or "Tie." in out.getvalue())
+
+
+def test_pattern_eval_agent(oracle):
+    """PatternEvalAgent (Agent.h:108-161) = the policy head of K6 without a search: its move is the first maximum of the oracle's
+    EvaluationProbs + DecisiveFilter on the same position, its debug message the pattern / compound counts of K1."""
+    import numpy as np
+    from gomokuai_amd import lib as G
+    agent = interface.make_agent("pattern")
+    b = core.Board()
+    agent.sync_with_board(b)
+    first = agent.get_action(b)
+    assert (first.x, first.y) == (7, 7)
+    moves, lens, _ = G.synth_boards(12, 1, first_board=4000)
+    checked = 0
+    for g in range(12):
+        ml = [int(m) for m in moves[g, :max(1, int(lens[g]) - 2)]]
+        b = core.Board()
+        for m in ml:
+            b.apply_move(core.Position(m))
+        if b.status["is_end"]:
+            continue
+        agent.sync_with_board(b)
+        mv = agent.get_action(b)
+        probs, _ = oracle.trad_heuristic(ml)
+        assert mv.id == int(np.argmax(probs)) and b.check_move(mv), "game %d" % g
+        dbg = agent.debug_message()
+        mm = np.zeros((1, 64), np.uint8); mm[0, :len(ml)] = ml
+        totals = oracle.replay_batch(mm, np.array([len(ml)], np.int32))[2][0]
+        assert dbg["before"]["black"][0] == [int(t >> 16) for t in totals[:8]] and dbg["before"]["white"][1] == [int(t & 0xFFFF) for t in totals[8:11]]
+        checked += 1
+    assert checked >= 8
