@@ -185,6 +185,112 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
                        torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
 
 
+class _Searcher:
+    """One side of play_match_games: a batched searcher for a fixed set of games, fresh roots every move."""
+
+    def __init__(self, spec, n, playouts, seed, first_game_id):
+        kind, kw = spec
+        self.kind, self.n, self.playouts = kind, n, int(kw.get("c_iterations", playouts))
+        c_puct = float(kw.get("c_puct", 5.0))
+        if kind == "traditional_mcts":                       # AGENT_MAP names of the reference (agents/__init__.py, config.py:9-19)
+            self.tree = G.TraditionalMCTS(n, node_capacity=min(self.playouts * 226 + 256, (1 << 24) - 1), c_puct=c_puct)
+        elif kind == "rave_mcts":
+            self.tree = G.PoolRAVEMCTS(n, node_capacity=min(self.playouts * 226 + 256, (1 << 24) - 1), c_puct=c_puct, seed=seed, first_game_id=first_game_id)
+        elif kind == "random_mcts":
+            self.tree = G.BatchedMCTS(n, playouts_capacity=self.playouts, c_puct=c_puct, c_rollouts=int(kw.get("c_rollouts", 5)), seed=seed)
+            self.first_game_id = first_game_id
+        else:
+            raise ValueError("play_match_games: unknown agent '%s' (traditional_mcts, rave_mcts, random_mcts)" % kind)
+
+    def search(self, moves, lens, stream):
+        """Root visit counts [n, 225] and the move MCTS::stepForward() would make per game (-1: none), from fresh roots."""
+        if self.kind == "random_mcts":
+            planes = G.moves_to_planes(moves, lens)
+            last = np.array([moves[g, lens[g] - 1] if lens[g] > 0 else -1 for g in range(self.n)], dtype=np.int16)
+            self.tree.set_roots(planes, last, self.first_game_id)
+            self.tree.run(self.playouts, stream)
+            visits = self.tree.root_stats()[0]
+            best = np.where(visits.max(1) > 0, visits.argmax(1), -1).astype(np.int32)        # max_element: the first maximum in child (= cell) order
+            return visits, best, False
+        self.tree.set_positions([moves[g, :lens[g]] for g in range(self.n)])
+        self.tree.run(self.playouts, stream)
+        st = self.tree.root_stats()
+        return st["visits"], st["best"], bool((st["status"] & 1).any())
+
+    def close(self):
+        self.tree.close()
+
+
+def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0,
+                     max_moves=N, device=None):
+    """The reference's data generation pairing (network/data_helper.py:15-22, 56-63; config.py:6-20): every game is played by
+    the SUPERVISOR against a CANDIDATE, sides drawn at random per game, and both players' searches are recorded.  supervisor /
+    candidate = (name, kwargs) as in DATA_CONFIG["schedule"]: ("traditional_mcts" | "rave_mcts" | "random_mcts", {"c_puct": ..,
+    "c_iterations": .., "c_rollouts": ..}).  All games run side by side on the current GPU: the games in which the supervisor
+    has black and the games in which it has white form two groups, each with one batched searcher per agent (K6 / K8 / K3), so
+    that every ply is two searches (one per group) covering all unfinished games; roots are fresh at every move and the
+    candidates' random streams are numbered within their group.
+    Returns (GameRecords, supervisor_is_black bool[n]); the records' visit counts at move i are those of the player who made it."""
+    from . import core
+    G.init(torch.cuda.current_device() if device is None else device.index)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rng = np.random.RandomState(int((seed ^ (seed >> 32) ^ first_game_id) & 0xFFFFFFFF))
+    sup_black = rng.randint(0, 2, n_games).astype(bool)           # random.shuffle(players) per game (data_helper.py:57-58)
+    moves = np.zeros((n_games, N), dtype=np.uint8)
+    lens = np.zeros(n_games, dtype=np.int32)
+    boards = [core.Board() for _ in range(n_games)]
+    if opening_plies > 0:
+        m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+        for g in range(n_games):
+            for i in range(min(int(l[g]), opening_plies)):
+                boards[g].apply_move(core.Position(int(m[g, i])))
+                moves[g, i] = m[g, i]
+            lens[g] = min(int(l[g]), opening_plies)
+    visits = np.zeros((n_games, N, N), dtype=np.uint16)
+    over = np.array([b.status["is_end"] for b in boards], dtype=bool)
+    groups = [np.nonzero(sup_black)[0], np.nonzero(~sup_black)[0]]
+    searchers = []                                                # [group][0 supervisor, 1 candidate]
+    for idx in groups:
+        first = first_game_id + (int(idx[0]) if len(idx) else 0)
+        searchers.append([_Searcher(spec, len(idx), playouts, seed, first) if len(idx) else None for spec in (supervisor, candidate)])
+    overflow = False
+    for _ in range(max_moves):
+        if over.all():
+            break
+        for gi, idx in enumerate(groups):
+            live = [g for g in idx if not over[g]]
+            if not live:
+                continue
+            for who in (0, 1):                                    # normally one of the two: the games of a group move in lock step
+                # group 0: the supervisor has black, i.e. it moves on even stone counts
+                sel = [g for g in live if ((int(lens[g]) % 2 == 0) == (gi == 0)) == (who == 0)]
+                if not sel:
+                    continue
+                v, best, full = searchers[gi][who].search(moves[idx], lens[idx], stream)
+                overflow |= full
+                at = {int(g): k for k, g in enumerate(idx)}
+                for g in sel:
+                    k = at[int(g)]
+                    mv = int(best[k])
+                    if mv < 0:
+                        over[g] = True
+                        continue
+                    visits[g, lens[g]] = np.minimum(v[k], 65535)
+                    boards[g].apply_move(core.Position(mv))
+                    moves[g, lens[g]] = mv
+                    lens[g] += 1
+                    over[g] = boards[g].status["is_end"]
+    for pair in searchers:
+        for srch in pair:
+            if srch is not None:
+                srch.close()
+    winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
+    rec = GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),
+                      torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
+    return rec, sup_black
+
+
 def dump_batches(samples, path, batch_size=512):
     """The reference appends mini-batches to `latest.train.hdf5` as three growing datasets `state_batch`, `value_batch`,
     `probs_batch` of shape (batches, batch_size, ...) (network/data_helper.py:176-194).  h5py is written when it can be

@@ -177,3 +177,34 @@ def test_poolrave_self_play(oracle):
         assert b.cur_player == 0 and b.winner == int(ra.winner[g])
     with pytest.raises(ValueError):
         selfplay.play_supervisor_games(1, 10, policy="other")
+
+
+def test_supervisor_against_candidates(oracle):
+    """The reference's data generation pairing (network/data_helper.py:15-63, config.py:6-20): supervisor vs candidate with random
+    sides, both players' searches recorded -- batched: legal, finished, reproducible games and training tuples for every move."""
+    import ctypes as C
+    from gomokuai_amd import selfplay
+    sup = ("traditional_mcts", {"c_puct": 5.0, "c_iterations": 150})
+    for cand in (("random_mcts", {"c_puct": 5.0, "c_iterations": 120}), ("rave_mcts", {"c_puct": 5.0, "c_iterations": 120})):
+        rec, sup_black = selfplay.play_match_games(10, sup, cand, seed=77, first_game_id=5, opening_plies=2)
+        again, sb2 = selfplay.play_match_games(10, sup, cand, seed=77, first_game_id=5, opening_plies=2)
+        assert (rec.moves.cpu() == again.moves.cpu()).all() and (sup_black == sb2).all() and not rec.overflow
+        assert sup_black.any() and (~sup_black).any()
+        r = rec.cpu()
+        visits = r.visits.numpy().view(np.uint16)
+        for g in range(len(rec)):
+            b = oracle.new_board()
+            L = int(r.lens[g])
+            for i in range(L):
+                assert oracle.lib().go_board_check_move(C.byref(b), int(r.moves[g, i]))
+                oracle.lib().go_board_apply(C.byref(b), int(r.moves[g, i]), 1)
+            assert b.cur_player == 0 and b.winner == int(r.winner[g]) and L >= 9
+            for i in range(2, L):                                # every recorded move carries the visit counts of the player who made it
+                mover_is_sup = (i % 2 == 0) == bool(sup_black[g])
+                n = int(visits[g, i].sum())
+                assert n == (150 if mover_is_sup else 120) - 1 or n == 0 or n < 150, (g, i, n)
+                assert visits[g, i, int(r.moves[g, i])] == visits[g, i].max()
+        states, values, pi = rec.to_samples(first_move=2)
+        assert states.shape[0] == int((r.lens - 2).sum())
+    with pytest.raises(ValueError):
+        selfplay.play_match_games(2, sup, ("botzone", {"program": "x"}))
