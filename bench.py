@@ -220,7 +220,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
             torch.distributed.barrier()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        tree.search(fused, P)
+        tree.search(fused, P)                              # (a hipGraph of the step, search(..., graph=True), gains nothing: the queue never runs dry)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)

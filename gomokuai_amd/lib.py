@@ -478,11 +478,28 @@ class AlphaZeroMCTS:
     def add_root_noise(self, alpha=0.05, epsilon=0.25, seed=DEFAULT_SEED, first_game_id=0):
         _check(load().gmk_az_add_root_noise(self.h, alpha, epsilon, seed, first_game_id))
 
-    def search(self, network, playouts):
-        """`playouts` lock-step playouts; network(states) -> (value [n], probs [n, 225]) on the GPU."""
-        for _ in range(playouts):
+    def search(self, network, playouts, graph=False):
+        """`playouts` lock-step playouts; network(states) -> (value [n], probs [n, 225]) on the GPU.  graph=True: the first playout
+        runs eagerly, then ONE playout step (select kernel, the network's kernels, expand kernel) is captured into a hipGraph and
+        replayed for the rest, which removes the launch gaps between the ~10 kernels of a step; the network must be capturable
+        (no host synchronisation; PolicyValueNetwork and FusedPolicyValueNetwork are)."""
+        import torch
+
+        def step():
             values, probs = network(self.select())
             self.expand(values.contiguous(), probs.contiguous())
+
+        if not graph or playouts < 3:
+            for _ in range(playouts):
+                step()
+            return
+        step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for _ in range(playouts - 1):
+            g.replay()
 
     def root_stats(self):
         out = {"visits": np.zeros((self.n, N), np.uint32), "values": np.zeros((self.n, N), np.float32), "priors": np.zeros((self.n, N), np.float32),

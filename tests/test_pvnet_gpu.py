@@ -86,6 +86,16 @@ def test_real_positions_and_search(oracle):
         tree.close()
     assert (stats[0]["root_visits"] == stats[1]["root_visits"]).all()
     assert (stats[0]["visits"] == stats[1]["visits"]).mean() > 0.99
+    # the same search with the playout step replayed from a hipGraph: identical trees
+    tree = G.AlphaZeroMCTS(n, node_capacity=playouts * 225 + 1)
+    tree.set_roots(planes, last)
+    with torch.no_grad():
+        tree.search(fused, playouts, graph=True)
+    replayed = tree.root_stats()
+    tree.close()
+    for k in ("visits", "root_visits", "n_nodes"):
+        assert (replayed[k] == stats[1][k]).all()
+    assert (replayed["values"].view(np.uint32) == stats[1]["values"].view(np.uint32)).all()
     assert np.abs(stats[0]["root_value"] - stats[1]["root_value"]).max() < 1e-4
     fused.close()
 
