@@ -185,6 +185,76 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
                        torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
 
 
+def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
+                       device=None, node_capacity=None, reuse_subtree=True, root_noise=(0.05, 0.25)):
+    """n_games complete games of the network-guided searcher against itself (agents/alphazero.py:5-9 on both sides: the
+    reference's AlphaZero self-play), all games in lock step on the current GPU: every move = `playouts` lock-step playouts of
+    K7 with `network(states [n,6,15,15]) -> (value [n], probs [n,225])` at the leaves (network.FusedPolicyValueNetwork = K9),
+    then every game plays its most visited child (MCTSAgent.eval_state -> MCTS::stepForward); with reuse_subtree the child's
+    subtree is kept and root_noise = (alpha, epsilon) is mixed into the root priors before every search (MCTS.cpp:182).
+    Returns GameRecords like play_games."""
+    from . import core
+    G.init(torch.cuda.current_device() if device is None else device.index)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    moves = np.zeros((n_games, N), dtype=np.uint8)
+    lens = np.zeros(n_games, dtype=np.int32)
+    boards = [core.Board() for _ in range(n_games)]
+    if opening_plies > 0:
+        m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+        for g in range(n_games):
+            for i in range(min(int(l[g]), opening_plies)):
+                boards[g].apply_move(core.Position(int(m[g, i])))
+                moves[g, i] = m[g, i]
+            lens[g] = min(int(l[g]), opening_plies)
+    visits = np.zeros((n_games, N, N), dtype=np.uint16)
+    over = np.array([b.status["is_end"] for b in boards], dtype=bool)
+    cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * N + 1, (1 << 24) - 1)
+    tree = G.AlphaZeroMCTS(n_games, node_capacity=cap, c_puct=c_puct)
+
+    def set_roots():
+        last = np.full((n_games, 2), -1, dtype=np.int16)
+        for g in range(n_games):
+            if lens[g] > 0:
+                last[g, 0] = moves[g, lens[g] - 1]
+            if lens[g] > 1:
+                last[g, 1] = moves[g, lens[g] - 2]
+        tree.set_roots(G.moves_to_planes(moves, lens), last)
+
+    set_roots()
+    overflow = False
+    with torch.no_grad():
+        for ply in range(max_moves):
+            if over.all():
+                break
+            if ply > 0 and not reuse_subtree:
+                set_roots()
+            if root_noise is not None:
+                tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
+            tree.search(network, playouts)
+            st = tree.root_stats()
+            overflow |= bool((st["status"] & 1).any())
+            played = np.full(n_games, -1, dtype=np.int16)
+            for g in range(n_games):
+                if over[g]:
+                    continue
+                if not st["visits"][g].any():                     # no child was visited: nothing to play (cannot happen on a live board)
+                    over[g] = True
+                    continue
+                best = int(np.argmax(st["visits"][g]))            # max_element: the first maximum in child (= cell) order
+                played[g] = best
+                visits[g, lens[g]] = np.minimum(st["visits"][g], 65535)
+                boards[g].apply_move(core.Position(best))
+                moves[g, lens[g]] = best
+                lens[g] += 1
+                over[g] = boards[g].status["is_end"]
+            if reuse_subtree:
+                tree.step(played)
+    tree.close()
+    winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
+    return GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),
+                       torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
+
+
 class _Searcher:
     """One side of play_match_games: a batched searcher for a fixed set of games, fresh roots every move."""
 

@@ -208,3 +208,31 @@ def test_supervisor_against_candidates(oracle):
         assert states.shape[0] == int((r.lens - 2).sum())
     with pytest.raises(ValueError):
         selfplay.play_match_games(2, sup, ("botzone", {"program": "x"}))
+
+
+def test_network_self_play(oracle):
+    """AlphaZero-style self-play: K7 in lock step with the fused network K9 at the leaves, subtree kept, root noise: legal,
+    finished, reproducible games; the same games with the plain PyTorch module (the two networks agree to 1e-7, ties aside)."""
+    import ctypes as C
+    import torch
+    from gomokuai_amd import selfplay
+    from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
+    net = PolicyValueNetwork(seed=4).cuda().eval()
+    fused = FusedPolicyValueNetwork(net)
+    a = selfplay.play_network_games(6, fused, 40, opening_plies=2, first_game_id=9, seed=3)
+    b2 = selfplay.play_network_games(6, fused, 40, opening_plies=2, first_game_id=9, seed=3)
+    assert (a.moves.cpu() == b2.moves.cpu()).all() and not a.overflow
+    ra = a.cpu()
+    for g in range(len(a)):
+        b = oracle.new_board()
+        for i in range(int(ra.lens[g])):
+            assert oracle.lib().go_board_check_move(C.byref(b), int(ra.moves[g, i]))
+            oracle.lib().go_board_apply(C.byref(b), int(ra.moves[g, i]), 1)
+        assert b.cur_player == 0 and b.winner == int(ra.winner[g])
+    states, values, pi = a.to_samples(first_move=2)
+    assert states.shape[0] == int((ra.lens - 2).sum()) and float(pi.sum(1).sub(1).abs().max()) < 1e-3
+    c = selfplay.play_network_games(6, net, 40, opening_plies=2, first_game_id=9, seed=3, reuse_subtree=False, root_noise=None)
+    d = selfplay.play_network_games(6, fused, 40, opening_plies=2, first_game_id=9, seed=3, reuse_subtree=False, root_noise=None)
+    same = (c.moves.cpu() == d.moves.cpu()).all(1)
+    assert int(same.sum()) >= 4                              # a tie between two children decided by 1e-7 may send a game elsewhere
+    fused.close()
