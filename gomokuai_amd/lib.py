@@ -361,13 +361,19 @@ class TraditionalMCTS:
     def reset_evaluators(self):
         _check(load().gmk_trad_reset_evaluators(self.h))
 
-    def set_positions(self, move_lists):
-        moves = np.zeros((self.n, N), np.uint8)
-        lens = np.zeros(self.n, np.int32)
-        assert len(move_lists) == self.n
-        for g, ml in enumerate(move_lists):
-            lens[g] = len(ml)
-            moves[g, :len(ml)] = ml
+    def set_positions(self, move_lists, lens=None):
+        """One move list per game, or (with lens) the arrays themselves: moves uint8[n, 225], lens int32[n]."""
+        if lens is not None:
+            moves = np.ascontiguousarray(move_lists, dtype=np.uint8)
+            lens = np.ascontiguousarray(lens, dtype=np.int32)
+            assert moves.shape == (self.n, N) and lens.shape == (self.n,)
+        else:
+            moves = np.zeros((self.n, N), np.uint8)
+            lens = np.zeros(self.n, np.int32)
+            assert len(move_lists) == self.n
+            for g, ml in enumerate(move_lists):
+                lens[g] = len(ml)
+                moves[g, :len(ml)] = ml
         _check(load().gmk_trad_set_positions(self.h, moves.ctypes.data, lens.ctypes.data))
 
     def run(self, playouts, stream=0):

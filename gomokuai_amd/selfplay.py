@@ -118,8 +118,64 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, bool((status & 2).any()))
 
 
+class _HostGames:
+    """The boards of n games on the host, all games handled at once with numpy (no Python loop per game): Board::applyMove with
+    its victory check (Game.cpp:37-49, 88-136: five or more through the new stone wins, a full board is a tie) for the moves a
+    batched searcher just chose.  The searchers only propose legal moves; `over` games take none."""
+
+    def __init__(self, n):
+        self.n = n
+        self.moves = np.zeros((n, N), dtype=np.uint8)
+        self.lens = np.zeros(n, dtype=np.int32)
+        self.stones = np.zeros((n, 15, 15), dtype=np.int8)      # +1 black, -1 white
+        self.over = np.zeros(n, dtype=bool)
+        self.winner = np.zeros(n, dtype=np.int8)
+
+    def apply(self, played):
+        """played int[n]: the cell each game plays, -1 for none; returns the indices of the games that moved."""
+        played = np.asarray(played)
+        idx = np.nonzero((played >= 0) & ~self.over)[0]
+        if len(idx) == 0:
+            return idx
+        cells = played[idx].astype(np.int64)
+        y, x = cells // 15, cells % 15
+        colour = np.where(self.lens[idx] % 2 == 0, 1, -1).astype(np.int8)      # black moves on even stone counts
+        assert (self.stones[idx, y, x] == 0).all(), "a searcher proposed an occupied cell"
+        self.stones[idx, y, x] = colour
+        self.moves[idx, self.lens[idx]] = cells
+        self.lens[idx] += 1
+        five = np.zeros(len(idx), dtype=bool)
+        for dy, dx in ((0, 1), (1, 0), (1, 1), (1, -1)):
+            run = np.ones(len(idx), dtype=np.int32)
+            for sign in (1, -1):
+                alive = np.ones(len(idx), dtype=bool)
+                for k in range(1, 5):
+                    yy, xx = y + sign * k * dy, x + sign * k * dx
+                    inside = (yy >= 0) & (yy < 15) & (xx >= 0) & (xx < 15)
+                    alive &= inside
+                    alive[alive] = self.stones[idx[alive], yy[alive], xx[alive]] == colour[alive]
+                    run += alive
+            five |= run >= 5
+        self.winner[idx[five]] = colour[five]
+        self.over[idx] = five | (self.lens[idx] == N)
+        return idx
+
+    def open_with(self, moves, lens, plies):
+        for i in range(plies):
+            played = np.where(lens > i, moves[:, i].astype(np.int64), -1)
+            self.apply(played)
+
+    def last_two(self):
+        last = np.full((self.n, 2), -1, dtype=np.int16)
+        g = np.arange(self.n)
+        has1, has2 = self.lens > 0, self.lens > 1
+        last[has1, 0] = self.moves[g[has1], self.lens[has1] - 1]
+        last[has2, 1] = self.moves[g[has2], self.lens[has2] - 2]
+        return last
+
+
 def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional"):
+                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional", slots=None):
     """n_games complete games of the reference's self-play SUPERVISOR against itself (config.py:9-12: "traditional_mcts",
     MCTS(TraditionalPolicy) on both sides), all games side by side on the current GPU: every move = one K6 search of
     `playouts` playouts per unfinished game (the games' evaluators are kept and synchronised like the policy objects of
@@ -127,24 +183,23 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
     (alpha, epsilon) mixes Default::AddNoise into the root priors before every search), then MCTS::stepForward's choice
     is played.  Without noise the search is deterministic; variety then comes from the openings (synthetic generator,
     `opening_plies` plies of game first_game_id + g).  policy="poolrave" plays the same loop with MCTS(PoolRAVEPolicy)
-    (agents/mcts.py:36-40) on both sides: K8 searches, random rollouts seeded by (seed, first_game_id + g).  Returns the same
-    GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
-    from . import core
+    (agents/mcts.py:36-40) on both sides: K8 searches, random rollouts seeded by (seed, first_game_id + g).
+    slots (fresh roots only): at most that many games are in flight; a game that ends hands its slot -- tree arena, evaluator,
+    wavefront -- to the next unstarted game, so the GPU stays full instead of waiting for the longest game of the batch (a search
+    costs the same time however many of its games are still alive: one wavefront per game, latency bound).
+    Returns the same GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
+    if slots is not None and slots < n_games:
+        if reuse_subtree:
+            raise ValueError("play_supervisor_games: slots need fresh roots (reuse_subtree=False)")
+        return _play_supervisor_slots(n_games, int(slots), playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy)
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
-    moves = np.zeros((n_games, N), dtype=np.uint8)
-    lens = np.zeros(n_games, dtype=np.int32)
-    boards = [core.Board() for _ in range(n_games)]           # host boards: legality and Board::checkGameEnd (Game.cpp:88-136)
+    games = _HostGames(n_games)                                  # host boards: Board::applyMove / checkGameEnd for all games at once
     if opening_plies > 0:
         m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
-        for g in range(n_games):
-            for i in range(min(int(l[g]), opening_plies)):
-                boards[g].apply_move(core.Position(int(m[g, i])))
-                moves[g, i] = m[g, i]
-            lens[g] = min(int(l[g]), opening_plies)
+        games.open_with(m, l, opening_plies)
     visits = np.zeros((n_games, N, N), dtype=np.uint16)
-    over = np.array([b.status["is_end"] for b in boards], dtype=bool)
     cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * 226 + 1, (1 << 24) - 1)
     if policy == "poolrave":
         tree = G.PoolRAVEMCTS(n_games, node_capacity=cap, c_puct=c_puct, seed=seed, first_game_id=first_game_id)
@@ -154,34 +209,69 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
         raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
     overflow = False
     for ply in range(max_moves):
-        if over.all():
+        if games.over.all():
             break
         if ply == 0 or not reuse_subtree:
-            tree.set_positions([moves[g, :lens[g]] for g in range(n_games)])
+            tree.set_positions(games.moves, games.lens)
         if root_noise is not None:
             tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
         tree.run(playouts, stream)
         st = tree.root_stats()
         overflow |= bool((st["status"] & 1).any())
-        played = np.full(n_games, -1, dtype=np.int16)
-        for g in range(n_games):
-            if over[g]:
-                continue
-            best = int(st["best"][g])
-            if best < 0:                                    # no child: nothing the policy wants to play (cannot happen on a live board)
-                over[g] = True
-                continue
-            played[g] = best
-            visits[g, lens[g]] = np.minimum(st["visits"][g], 65535)
-            boards[g].apply_move(core.Position(best))
-            moves[g, lens[g]] = best
-            lens[g] += 1
-            over[g] = boards[g].status["is_end"]
+        played = np.where(games.over, -1, st["best"]).astype(np.int16)
+        games.over |= played < 0                                 # no child: nothing the policy wants to play (cannot happen on a live board)
+        at = games.lens.copy()
+        moved = games.apply(played)
+        visits[moved, at[moved]] = np.minimum(st["visits"][moved], 65535)
         if reuse_subtree:
             tree.step(played)                               # finished games ask for -1 on a childless root: nothing moves
     tree.close()
-    winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
-    return GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),
+    return GameRecords(torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev), torch.from_numpy(games.winner).to(dev),
+                       torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
+
+
+def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy):
+    G.init(torch.cuda.current_device() if device is None else device.index)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    games = _HostGames(n_games)
+    if opening_plies > 0:
+        m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+        games.open_with(m, l, opening_plies)
+    visits = np.zeros((n_games, N, N), dtype=np.uint16)
+    cap = node_capacity if node_capacity is not None else min(playouts * 226 + 1, (1 << 24) - 1)
+    if policy == "poolrave":
+        tree = G.PoolRAVEMCTS(slots, node_capacity=cap, c_puct=c_puct, seed=seed, first_game_id=first_game_id)
+    elif policy == "traditional":
+        tree = G.TraditionalMCTS(slots, node_capacity=cap, c_puct=c_puct)
+    else:
+        raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
+    active = np.arange(slots)                                    # the game in each slot
+    next_game = slots
+    overflow = False
+    for _ in range((n_games // slots + 2) * N):
+        # a finished game hands its slot to the next unstarted one
+        done = np.nonzero(games.over[active])[0]
+        take = min(len(done), n_games - next_game)
+        active[done[:take]] = np.arange(next_game, next_game + take)
+        next_game += take
+        if games.over[active].all():
+            break
+        tree.set_positions(games.moves[active], games.lens[active])
+        tree.run(playouts, stream)
+        st = tree.root_stats()
+        overflow |= bool((st["status"] & 1).any())
+        best = np.where(games.over[active], -1, st["best"])
+        games.over[active[(best < 0) & ~games.over[active]]] = True
+        played = np.full(n_games, -1, dtype=np.int64)
+        played[active] = best
+        at = games.lens.copy()
+        moved = games.apply(played)
+        slot_of = np.full(n_games, -1, dtype=np.int64)
+        slot_of[active] = np.arange(slots)
+        visits[moved, at[moved]] = np.minimum(st["visits"][slot_of[moved]], 65535)
+    tree.close()
+    return GameRecords(torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev), torch.from_numpy(games.winner).to(dev),
                        torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
 
 
@@ -193,65 +283,38 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
     then every game plays its most visited child (MCTSAgent.eval_state -> MCTS::stepForward); with reuse_subtree the child's
     subtree is kept and root_noise = (alpha, epsilon) is mixed into the root priors before every search (MCTS.cpp:182).
     Returns GameRecords like play_games."""
-    from . import core
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    moves = np.zeros((n_games, N), dtype=np.uint8)
-    lens = np.zeros(n_games, dtype=np.int32)
-    boards = [core.Board() for _ in range(n_games)]
+    games = _HostGames(n_games)
     if opening_plies > 0:
         m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
-        for g in range(n_games):
-            for i in range(min(int(l[g]), opening_plies)):
-                boards[g].apply_move(core.Position(int(m[g, i])))
-                moves[g, i] = m[g, i]
-            lens[g] = min(int(l[g]), opening_plies)
+        games.open_with(m, l, opening_plies)
     visits = np.zeros((n_games, N, N), dtype=np.uint16)
-    over = np.array([b.status["is_end"] for b in boards], dtype=bool)
     cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * N + 1, (1 << 24) - 1)
     tree = G.AlphaZeroMCTS(n_games, node_capacity=cap, c_puct=c_puct)
-
-    def set_roots():
-        last = np.full((n_games, 2), -1, dtype=np.int16)
-        for g in range(n_games):
-            if lens[g] > 0:
-                last[g, 0] = moves[g, lens[g] - 1]
-            if lens[g] > 1:
-                last[g, 1] = moves[g, lens[g] - 2]
-        tree.set_roots(G.moves_to_planes(moves, lens), last)
-
-    set_roots()
+    tree.set_roots(G.moves_to_planes(games.moves, games.lens), games.last_two())
     overflow = False
     with torch.no_grad():
         for ply in range(max_moves):
-            if over.all():
+            if games.over.all():
                 break
             if ply > 0 and not reuse_subtree:
-                set_roots()
+                tree.set_roots(G.moves_to_planes(games.moves, games.lens), games.last_two())
             if root_noise is not None:
                 tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
             tree.search(network, playouts)
             st = tree.root_stats()
             overflow |= bool((st["status"] & 1).any())
-            played = np.full(n_games, -1, dtype=np.int16)
-            for g in range(n_games):
-                if over[g]:
-                    continue
-                if not st["visits"][g].any():                     # no child was visited: nothing to play (cannot happen on a live board)
-                    over[g] = True
-                    continue
-                best = int(np.argmax(st["visits"][g]))            # max_element: the first maximum in child (= cell) order
-                played[g] = best
-                visits[g, lens[g]] = np.minimum(st["visits"][g], 65535)
-                boards[g].apply_move(core.Position(best))
-                moves[g, lens[g]] = best
-                lens[g] += 1
-                over[g] = boards[g].status["is_end"]
+            visited = st["visits"].max(1) > 0                    # no child was visited: nothing to play (cannot happen on a live board)
+            played = np.where(games.over | ~visited, -1, st["visits"].argmax(1)).astype(np.int16)      # max_element: the first maximum in child (= cell) order
+            games.over |= played < 0
+            at = games.lens.copy()
+            moved = games.apply(played)
+            visits[moved, at[moved]] = np.minimum(st["visits"][moved], 65535)
             if reuse_subtree:
                 tree.step(played)
     tree.close()
-    winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
-    return GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),
+    return GameRecords(torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev), torch.from_numpy(games.winner).to(dev),
                        torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
 
 
@@ -276,13 +339,13 @@ class _Searcher:
         """Root visit counts [n, 225] and the move MCTS::stepForward() would make per game (-1: none), from fresh roots."""
         if self.kind == "random_mcts":
             planes = G.moves_to_planes(moves, lens)
-            last = np.array([moves[g, lens[g] - 1] if lens[g] > 0 else -1 for g in range(self.n)], dtype=np.int16)
+            last = np.where(lens > 0, moves[np.arange(self.n), np.maximum(lens, 1) - 1].astype(np.int16), np.int16(-1))
             self.tree.set_roots(planes, last, self.first_game_id)
             self.tree.run(self.playouts, stream)
             visits = self.tree.root_stats()[0]
             best = np.where(visits.max(1) > 0, visits.argmax(1), -1).astype(np.int32)        # max_element: the first maximum in child (= cell) order
             return visits, best, False
-        self.tree.set_positions([moves[g, :lens[g]] for g in range(self.n)])
+        self.tree.set_positions(moves, lens)
         self.tree.run(self.playouts, stream)
         st = self.tree.root_stats()
         return st["visits"], st["best"], bool((st["status"] & 1).any())
@@ -301,24 +364,16 @@ def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAUL
     that every ply is two searches (one per group) covering all unfinished games; roots are fresh at every move and the
     candidates' random streams are numbered within their group.
     Returns (GameRecords, supervisor_is_black bool[n]); the records' visit counts at move i are those of the player who made it."""
-    from . import core
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
     rng = np.random.RandomState(int((seed ^ (seed >> 32) ^ first_game_id) & 0xFFFFFFFF))
     sup_black = rng.randint(0, 2, n_games).astype(bool)           # random.shuffle(players) per game (data_helper.py:57-58)
-    moves = np.zeros((n_games, N), dtype=np.uint8)
-    lens = np.zeros(n_games, dtype=np.int32)
-    boards = [core.Board() for _ in range(n_games)]
+    games = _HostGames(n_games)
     if opening_plies > 0:
         m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
-        for g in range(n_games):
-            for i in range(min(int(l[g]), opening_plies)):
-                boards[g].apply_move(core.Position(int(m[g, i])))
-                moves[g, i] = m[g, i]
-            lens[g] = min(int(l[g]), opening_plies)
+        games.open_with(m, l, opening_plies)
     visits = np.zeros((n_games, N, N), dtype=np.uint16)
-    over = np.array([b.status["is_end"] for b in boards], dtype=bool)
     groups = [np.nonzero(sup_black)[0], np.nonzero(~sup_black)[0]]
     searchers = []                                                # [group][0 supervisor, 1 candidate]
     for idx in groups:
@@ -326,37 +381,33 @@ def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAUL
         searchers.append([_Searcher(spec, len(idx), playouts, seed, first) if len(idx) else None for spec in (supervisor, candidate)])
     overflow = False
     for _ in range(max_moves):
-        if over.all():
+        if games.over.all():
             break
         for gi, idx in enumerate(groups):
-            live = [g for g in idx if not over[g]]
-            if not live:
+            if len(idx) == 0 or games.over[idx].all():
                 continue
             for who in (0, 1):                                    # normally one of the two: the games of a group move in lock step
                 # group 0: the supervisor has black, i.e. it moves on even stone counts
-                sel = [g for g in live if ((int(lens[g]) % 2 == 0) == (gi == 0)) == (who == 0)]
-                if not sel:
+                turn = ((games.lens[idx] % 2 == 0) == (gi == 0)) == (who == 0)
+                sel = turn & ~games.over[idx]
+                if not sel.any():
                     continue
-                v, best, full = searchers[gi][who].search(moves[idx], lens[idx], stream)
+                v, best, full = searchers[gi][who].search(games.moves[idx], games.lens[idx], stream)
                 overflow |= full
-                at = {int(g): k for k, g in enumerate(idx)}
-                for g in sel:
-                    k = at[int(g)]
-                    mv = int(best[k])
-                    if mv < 0:
-                        over[g] = True
-                        continue
-                    visits[g, lens[g]] = np.minimum(v[k], 65535)
-                    boards[g].apply_move(core.Position(mv))
-                    moves[g, lens[g]] = mv
-                    lens[g] += 1
-                    over[g] = boards[g].status["is_end"]
+                played = np.full(n_games, -1, dtype=np.int64)
+                played[idx[sel]] = best[sel]
+                games.over[idx[sel & (best < 0)]] = True
+                at = games.lens.copy()
+                moved = games.apply(played)
+                where = {int(g): k for k, g in enumerate(idx)}
+                rows = np.array([where[int(g)] for g in moved], dtype=np.int64)
+                if len(moved):
+                    visits[moved, at[moved]] = np.minimum(v[rows], 65535)
     for pair in searchers:
         for srch in pair:
             if srch is not None:
                 srch.close()
-    winner = np.array([int(b.status["winner"]) for b in boards], dtype=np.int8)
-    rec = GameRecords(torch.from_numpy(moves).to(dev), torch.from_numpy(lens).to(dev), torch.from_numpy(winner).to(dev),
+    rec = GameRecords(torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev), torch.from_numpy(games.winner).to(dev),
                       torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
     return rec, sup_black
 

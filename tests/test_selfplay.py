@@ -97,3 +97,50 @@ def test_gather_world_size_2_gloo(tmp_path):
 def test_gather_single_process_is_identity():
     rec = _fake_records(2, 5, 3)
     assert selfplay.gather_records(rec) is rec
+
+
+def test_host_games_match_the_board():
+    """selfplay._HostGames (all games of a batch at once, numpy) against CorePyExt.Board move by move: end detection and winner
+    (Game.cpp:37-49, 88-136), including overlines and a full board without a five (the reference's tie order)."""
+    from gomokuai_amd import core
+    from gomokuai_amd.selfplay import _HostGames
+    rng = np.random.RandomState(7)
+    n = 120
+    hg = _HostGames(n)
+    boards = [core.Board() for _ in range(n)]
+    for ply in range(225):
+        played = np.full(n, -1)
+        for g in range(n):
+            if boards[g].status["is_end"]:
+                continue
+            free = [c for c in range(225) if boards[g].check_move(core.Position(c))]
+            played[g] = free[rng.randint(len(free))] if (g % 3 and rng.rand() < 0.6) else free[0]
+        moved = hg.apply(played)
+        assert sorted(moved) == [g for g in range(n) if played[g] >= 0]
+        for g in range(n):
+            if played[g] >= 0:
+                boards[g].apply_move(core.Position(int(played[g])))
+        assert all(bool(hg.over[g]) == bool(boards[g].status["is_end"]) for g in range(n)), ply
+        if hg.over.all():
+            break
+    assert all(int(hg.winner[g]) == int(boards[g].status["winner"]) for g in range(n))
+    assert (hg.winner == 1).any() and (hg.winner == -1).any()
+    # the tie: a full board without five in a row (the pattern of core/test/integration/board_integrationtest.cpp)
+    tie = _HostGames(1)
+    b = core.Board()
+    order = [y * 15 + x for y in range(15) for x in range(15)]
+    cells = sorted(order, key=lambda c: (((c % 15) // 2 + (c // 15)) % 2, c))      # colour classes that never line up five
+    blacks, whites = [c for c in cells if ((c % 15) // 2 + c // 15) % 2 == 0], [c for c in cells if ((c % 15) // 2 + c // 15) % 2 == 1]
+    seq = []
+    while blacks or whites:
+        if blacks: seq.append(blacks.pop())
+        if whites: seq.append(whites.pop())
+    ok = True
+    for c in seq:
+        if b.status["is_end"]:
+            ok = False
+            break
+        tie.apply(np.array([c]))
+        b.apply_move(core.Position(c))
+        assert bool(tie.over[0]) == bool(b.status["is_end"])
+    assert int(tie.winner[0]) == int(b.status["winner"])

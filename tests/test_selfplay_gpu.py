@@ -236,3 +236,28 @@ def test_network_self_play(oracle):
     same = (c.moves.cpu() == d.moves.cpu()).all(1)
     assert int(same.sum()) >= 4                              # a tie between two children decided by 1e-7 may send a game elsewhere
     fused.close()
+
+
+def test_supervisor_self_play_with_slots(oracle):
+    """Continuous batching: 14 games through 4 slots (a finished game hands its slot to the next one): every game is legal and
+    finished, and the pattern-guided games are the ones the all-at-once run plays unless the evaluator's history-dependent flag
+    words (which differ between a fresh and a handed-over slot) tip a search."""
+    import ctypes as C
+    from gomokuai_amd import selfplay
+    a = selfplay.play_supervisor_games(14, 80, opening_plies=3, first_game_id=30, slots=4)
+    b2 = selfplay.play_supervisor_games(14, 80, opening_plies=3, first_game_id=30, slots=4)
+    full = selfplay.play_supervisor_games(14, 80, opening_plies=3, first_game_id=30)
+    assert (a.moves.cpu() == b2.moves.cpu()).all() and not a.overflow
+    ra = a.cpu()
+    for g in range(len(a)):
+        b = oracle.new_board()
+        for i in range(int(ra.lens[g])):
+            assert oracle.lib().go_board_check_move(C.byref(b), int(ra.moves[g, i]))
+            oracle.lib().go_board_apply(C.byref(b), int(ra.moves[g, i]), 1)
+        assert b.cur_player == 0 and b.winner == int(ra.winner[g]) and int(ra.lens[g]) >= 9
+    same = (a.moves.cpu() == full.moves.cpu()).all(1)
+    assert int(same.sum()) >= 10
+    states, _, _ = a.to_samples(first_move=3)
+    assert states.shape[0] == int((ra.lens - 3).sum())
+    with pytest.raises(ValueError):
+        selfplay.play_supervisor_games(8, 10, slots=4, reuse_subtree=True)

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--reuse", action="store_true", help="keep the subtree of the played move (MCTS::stepForward)")
     ap.add_argument("--noise", action="store_true", help="Default::AddNoise(0.05, 0.25) before every search (needs --reuse)")
     ap.add_argument("--augment", action="store_true")
+    ap.add_argument("--slots", type=int, default=None, help="traditional / poolrave: games in flight (finished games hand their slot to the next one)")
+    ap.add_argument("--policy", default="random", choices=["random", "traditional", "poolrave", "network"],
+                    help="who plays: RandomPolicy (K3), TraditionalPolicy (K6), PoolRAVEPolicy (K8), the fused policy-value network (K7 + K9)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -32,8 +35,16 @@ def main():
     first, n = selfplay.shard(args.games, rank, world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse,
-                              root_noise=(0.05, 0.25) if args.noise else None)
+    noise = (0.05, 0.25) if args.noise else None
+    if args.policy == "random":
+        rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse, root_noise=noise)
+    elif args.policy == "network":
+        from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
+        net = FusedPolicyValueNetwork(PolicyValueNetwork(seed=1).cuda().eval())
+        rec = selfplay.play_network_games(n, net, args.playouts, first_game_id=first, opening_plies=2, reuse_subtree=args.reuse, root_noise=noise)
+    else:
+        rec = selfplay.play_supervisor_games(n, args.playouts, c_puct=5.0 if args.policy == "traditional" else 2.0, first_game_id=first, opening_plies=2,
+                                             reuse_subtree=args.reuse, root_noise=noise, policy=args.policy, slots=args.slots)
     torch.cuda.synchronize()
     t_play = time.perf_counter() - t0
     t1 = time.perf_counter()
@@ -52,7 +63,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         t_play, t_samples, t_gather, moves = float(mx[0]), float(mx[1]), float(mx[2]), int(tt[3])
     if rank == 0:
-        print(json.dumps({"workload": "self-play pipeline", "games": args.games, "n_gpus": world, "playouts_per_move": args.playouts,
+        print(json.dumps({"workload": "self-play pipeline", "policy": args.policy, "games": args.games, "n_gpus": world, "playouts_per_move": args.playouts,
                           "moves": moves, "samples": moves * (8 if args.augment else 1), "arena_overflow": rec.overflow,
                           "play_s": t_play, "samples_s": t_samples, "gather_s": t_gather,
                           "games_per_s": args.games / (t_play + t_samples + t_gather),
