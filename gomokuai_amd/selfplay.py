@@ -355,14 +355,15 @@ class _Searcher:
 
 
 def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0,
-                     max_moves=N, device=None):
+                     max_moves=N, device=None, slots=None):
     """The reference's data generation pairing (network/data_helper.py:15-22, 56-63; config.py:6-20): every game is played by
     the SUPERVISOR against a CANDIDATE, sides drawn at random per game, and both players' searches are recorded.  supervisor /
     candidate = (name, kwargs) as in DATA_CONFIG["schedule"]: ("traditional_mcts" | "rave_mcts" | "random_mcts", {"c_puct": ..,
     "c_iterations": .., "c_rollouts": ..}).  All games run side by side on the current GPU: the games in which the supervisor
     has black and the games in which it has white form two groups, each with one batched searcher per agent (K6 / K8 / K3), so
     that every ply is two searches (one per group) covering all unfinished games; roots are fresh at every move and the
-    candidates' random streams are numbered within their group.
+    candidates' random streams are numbered within their group.  slots: games in flight per group (default: all of them); a
+    finished game hands its slot to the next unstarted game of its group, which keeps the searches full (see play_supervisor_games).
     Returns (GameRecords, supervisor_is_black bool[n]); the records' visit counts at move i are those of the player who made it."""
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -375,34 +376,42 @@ def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAUL
         games.open_with(m, l, opening_plies)
     visits = np.zeros((n_games, N, N), dtype=np.uint16)
     groups = [np.nonzero(sup_black)[0], np.nonzero(~sup_black)[0]]
-    searchers = []                                                # [group][0 supervisor, 1 candidate]
+    active, waiting, searchers = [], [], []                      # per group: the game in each slot, the games not started yet, [supervisor, candidate]
     for idx in groups:
+        k = len(idx) if slots is None else min(int(slots), len(idx))
+        active.append(idx[:k].copy())
+        waiting.append(list(idx[k:]))
         first = first_game_id + (int(idx[0]) if len(idx) else 0)
-        searchers.append([_Searcher(spec, len(idx), playouts, seed, first) if len(idx) else None for spec in (supervisor, candidate)])
+        searchers.append([_Searcher(spec, k, playouts, seed, first) if k else None for spec in (supervisor, candidate)])
     overflow = False
-    for _ in range(max_moves):
+    for _ in range((2 + (0 if slots is None else n_games // max(1, int(slots)))) * max_moves):
         if games.over.all():
             break
-        for gi, idx in enumerate(groups):
-            if len(idx) == 0 or games.over[idx].all():
+        for gi in (0, 1):
+            act = active[gi]
+            if len(act) == 0:
+                continue
+            done = np.nonzero(games.over[act])[0]                 # a finished game hands its slot to the next one of the group
+            for slot in done[:len(waiting[gi])]:
+                act[slot] = waiting[gi].pop(0)
+            if games.over[act].all():
                 continue
             for who in (0, 1):                                    # normally one of the two: the games of a group move in lock step
                 # group 0: the supervisor has black, i.e. it moves on even stone counts
-                turn = ((games.lens[idx] % 2 == 0) == (gi == 0)) == (who == 0)
-                sel = turn & ~games.over[idx]
+                turn = ((games.lens[act] % 2 == 0) == (gi == 0)) == (who == 0)
+                sel = turn & ~games.over[act]
                 if not sel.any():
                     continue
-                v, best, full = searchers[gi][who].search(games.moves[idx], games.lens[idx], stream)
+                v, best, full = searchers[gi][who].search(games.moves[act], games.lens[act], stream)
                 overflow |= full
                 played = np.full(n_games, -1, dtype=np.int64)
-                played[idx[sel]] = best[sel]
-                games.over[idx[sel & (best < 0)]] = True
+                played[act[sel]] = best[sel]
+                games.over[act[sel & (best < 0)]] = True
                 at = games.lens.copy()
                 moved = games.apply(played)
-                where = {int(g): k for k, g in enumerate(idx)}
-                rows = np.array([where[int(g)] for g in moved], dtype=np.int64)
-                if len(moved):
-                    visits[moved, at[moved]] = np.minimum(v[rows], 65535)
+                slot_of = np.full(n_games, -1, dtype=np.int64)
+                slot_of[act] = np.arange(len(act))
+                visits[moved, at[moved]] = np.minimum(v[slot_of[moved]], 65535)
     for pair in searchers:
         for srch in pair:
             if srch is not None:

@@ -206,6 +206,15 @@ def test_supervisor_against_candidates(oracle):
                 assert visits[g, i, int(r.moves[g, i])] == visits[g, i].max()
         states, values, pi = rec.to_samples(first_move=2)
         assert states.shape[0] == int((r.lens - 2).sum())
+    # through 3 slots per group: every game still legal and finished
+    rec, sup_black = selfplay.play_match_games(14, sup, ("rave_mcts", {"c_puct": 5.0, "c_iterations": 100}), seed=78, opening_plies=2, slots=3)
+    r = rec.cpu()
+    for g in range(len(rec)):
+        b = oracle.new_board()
+        for i in range(int(r.lens[g])):
+            assert oracle.lib().go_board_check_move(C.byref(b), int(r.moves[g, i]))
+            oracle.lib().go_board_apply(C.byref(b), int(r.moves[g, i]), 1)
+        assert b.cur_player == 0 and b.winner == int(r.winner[g]) and int(r.lens[g]) >= 9
     with pytest.raises(ValueError):
         selfplay.play_match_games(2, sup, ("botzone", {"program": "x"}))
 
