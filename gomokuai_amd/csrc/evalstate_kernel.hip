@@ -12,7 +12,7 @@
 namespace {
 
 using namespace gmk::evs;
-constexpr int kGamesPerBlock = 6;                // 6 x 18.8 KB of state + 14 KB of automaton tables fit one CU's 160 KB of LDS
+constexpr int kGamesPerBlock = 7;                // 7 x 19.1 KB of state and scratch + 14.8 KB of automaton tables fit one CU's 160 KB of LDS
 constexpr int kThreads = 64 * kGamesPerBlock;
 
 __global__ __launch_bounds__(kThreads)

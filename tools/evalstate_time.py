@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gomokuai_amd import lib as G
 torch.cuda.set_device(0); G.init(0)
-n, k = 1536, 40
+n, k = int(sys.argv[1]) if len(sys.argv) > 1 else 1792, 40
 moves, lens, _ = G.synth_boards(n, 1)
 scr = np.full((n, k), -1, np.int16)
 for g in range(n):
@@ -21,4 +21,4 @@ for _ in range(reps):
     L.gmk_evalstate_update(e.h, d.data_ptr(), k, 0); L.gmk_evalstate_update(e.h, back.data_ptr(), k, 0)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
 ups = 2 * (scr >= 0).sum(1).mean()
-print("K2: %d games x %.1f updates (apply, then revert) in %.3f ms -> %.2f us per update per game (6 waves/CU), %.1f M updates/s" % (n, ups, dt * 1e3, dt * 1e6 / ups, n * ups / dt / 1e6))
+print("K2: %d games x %.1f updates (apply, then revert) in %.3f ms -> %.2f us per update per game (7 waves per CU), %.1f M updates/s" % (n, ups, dt * 1e3, dt * 1e6 / ups, n * ups / dt / 1e6))
