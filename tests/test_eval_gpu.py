@@ -115,3 +115,29 @@ def test_properties_at_full_size(oracle):
     sample = np.arange(0, n, 64)
     ref = oracle.replay_batch(moves[sample], lens[sample])
     _compare(ref, (scores[sample], density[sample], totals[sample], status[sample]))
+
+
+def test_dense_boards_match_oracle(oracle):
+    """100 .. 225 stones without a five (prefixes of shuffled tie games): the sizes the synthetic 8..60-ply boards never reach --
+    full queues, saturated counters, the full-board tie."""
+    rng = np.random.RandomState(11)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2             # two colour classes that never line up five
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    n = 384
+    moves = np.zeros((n, 225), np.uint8)
+    lens = np.zeros(n, np.int32)
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(b.pop())
+            if w:
+                seq.append(w.pop())
+        moves[g] = seq
+        lens[g] = 225 if g < 8 else rng.randint(100, 226)
+    got = G.eval_batch_host(G.moves_to_planes(moves, lens))
+    ref = oracle.replay_batch(moves, lens)
+    for name, a, b in zip(("scores", "density", "totals", "status"), ref, got):
+        np.testing.assert_array_equal(a, b, name)
+    assert (got[3][:8] & 1).all() and not (got[3] & 2).any()   # the full boards are over (ties), nothing overflowed
