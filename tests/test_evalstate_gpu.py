@@ -98,3 +98,36 @@ def test_position_outputs_agree_with_k1(oracle):
     assert (s["scores"] == scores).all() and (s["density"] == density).all()
     assert (s["pattern_dist"][:, 225, :] == totals[:, :8]).all() and (s["compound_dist"][:, 225, :] == totals[:, 8:]).all()
     st.close()
+
+
+def test_dense_games_to_the_full_board_and_back(oracle):
+    """Games without a five played to 150 .. 225 stones (shuffled tie games), then taken back completely: the incremental state
+    (saturating flag words included) follows the oracle at the densest positions, up to the full board, and returns to the
+    empty evaluator."""
+    rng = np.random.RandomState(21)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    n = 12
+    scripts = []
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(int(b.pop()))
+            if w:
+                seq.append(int(w.pop()))
+        scripts.append(seq[:225 if g < 2 else int(rng.randint(150, 226))])
+    k = max(len(s) for s in scripts)
+    script = np.full((n, k), -1, dtype=np.int16)
+    for g, s in enumerate(scripts):
+        script[g, :len(s)] = s
+    st = G.EvaluatorStates(n)
+    st.update(script)
+    states = st.read()
+    _compare(states, _oracle_states(oracle, scripts))
+    assert states["meta"][0][0] == 225 and states["meta"][0][2] == 0      # a full board without a winner (the tie itself is Evaluator::checkGameEnd's finding)
+    st.update(np.full((n, k), -2, dtype=np.int16))
+    back = st.read()
+    assert not back["scores"].any() and not back["pattern_dist"].any() and not back["compound_dist"].any() and (back["meta"][:, 0] == 0).all()
+    st.close()
