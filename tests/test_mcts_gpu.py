@@ -111,3 +111,33 @@ def test_pi_from_visits(oracle):
         a = G.visits_to_pi(v, stones)
         b = oracle.visits_to_pi(v, stones)
         assert np.abs(a - b).max() <= 1e-6 and abs(float(a.sum()) - 1.0) < 1e-4
+
+
+def test_nearly_full_boards(oracle):
+    """Roots with 1 .. 12 empty cells (shuffled tie games): rollouts of a few plies, full-board ties, trees that run out of leaves."""
+    rng = np.random.RandomState(8)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2             # two colour classes that never line up five
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    n = 10
+    moves = np.zeros((n, 225), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(b.pop())
+            if w:
+                seq.append(w.pop())
+        moves[g] = seq
+        lens[g] = rng.randint(213, 225)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[g, lens[g] - 1] for g in range(n)], dtype=np.int16)
+    t = G.BatchedMCTS(n, playouts_capacity=300)
+    t.set_roots(planes, last, first_game_id=70)
+    t.run(300)
+    visits, q, rv, nodes, status = t.root_stats()
+    for g in range(n):
+        ov, oq, orv, osize, _ = _oracle_search(oracle, moves[g], int(lens[g]), 300, 70 + g)
+        assert (visits[g] == ov).all() and nodes[g] == osize and q[g].tobytes() == oq.tobytes() and rv[g] == orv, "game %d" % g
+    t.close()

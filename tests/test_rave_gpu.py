@@ -152,3 +152,36 @@ def test_step_keeps_the_subtree_and_noise(gmk, oracle):
         assert (t.root_stats()["status"] == 0).all()
     assert compared >= 10 and kept_visits > 0
     t.close()
+
+
+def _dense_positions(n, lo, hi, seed):
+    """prefixes (lo .. hi stones) of shuffled games between two colour classes that never line up five"""
+    rng = np.random.RandomState(seed)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    out = []
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(int(b.pop()))
+            if w:
+                seq.append(int(w.pop()))
+        out.append(seq[:int(rng.randint(lo, hi + 1))])
+    return out
+
+
+def test_nearly_full_boards(gmk, oracle):
+    """Roots with 1 .. 12 empty cells: rollouts of a few plies, ties at full boards, trees that run out of leaves."""
+    G, O = gmk, oracle
+    pos = _dense_positions(10, 213, 224, 4)
+    t = G.PoolRAVEMCTS(len(pos), node_capacity=1 << 16, c_puct=2.0, seed=SEED, first_game_id=90)
+    t.set_positions(pos)
+    t.run(300)
+    stats = t.root_stats()
+    for g in range(len(pos)):
+        orc = O.PoolRAVEMCTS(2.0, 0.0, seed=SEED, game_id=90 + g)
+        orc.run(pos[g], 300)
+        _compare(stats, g, orc, "game %d" % g)
+    t.close()
