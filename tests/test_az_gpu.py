@@ -186,3 +186,51 @@ def test_step_keeps_the_subtree_and_noise(oracle):
         tree.step(reply)
     assert kept > 0
     tree.close()
+
+
+def test_nearly_full_boards(oracle):
+    """Roots with 1 .. 12 empty cells (shuffled tie games): leaves at full boards (ties) inside the tree, priors on occupied
+    cells dropped by Default::Expand's legality check, trees that run out of leaves."""
+    import torch
+    O = oracle
+    G.init()
+    rng = np.random.RandomState(17)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2             # two colour classes that never line up five
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    n, playouts = 8, 200
+    moves = np.zeros((n, 225), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(b.pop())
+            if w:
+                seq.append(w.pop())
+        moves[g] = seq
+        lens[g] = rng.randint(213, 225)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.stack([moves[np.arange(n), lens - 1], moves[np.arange(n), lens - 2]], 1).astype(np.int16)
+    tree = G.AlphaZeroMCTS(n, node_capacity=1 << 14, c_puct=5.0)
+    tree.set_roots(planes, last)
+
+    def host_network(states):
+        s = states.cpu().numpy()
+        vp = [surrogate(s[g]) for g in range(n)]
+        return (torch.tensor([v for v, _ in vp], dtype=torch.float32, device="cuda"), torch.from_numpy(np.stack([p for _, p in vp])).cuda())
+    tree.search(host_network, playouts)
+    st = tree.root_stats()
+    assert (st["status"] == 0).all()
+    for g in range(n):
+        b = O.new_board()
+        for i in range(int(lens[g])):
+            O.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        om = O.MCTS(playouts, 5.0, 5, 0, 0)
+        om.set_evaluator(surrogate)
+        om.run_playouts(b)
+        v, q, p = om.root_children()
+        np.testing.assert_array_equal(st["visits"][g], v)
+        np.testing.assert_array_equal(st["values"][g].view(np.uint32), q.view(np.uint32))
+        assert st["root_visits"][g] == om.root_visits and st["n_nodes"][g] == om.size
+    tree.close()
