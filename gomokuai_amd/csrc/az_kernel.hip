@@ -487,6 +487,7 @@ extern "C" int gmk_az_expand_host(gmk_az* a, const float* h_values, const float*
 extern "C" int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
                                  float* h_root_value, int32_t* h_n_nodes, int32_t* h_status) {
     if (!a) { gmk::set_error("gmk_az_root_stats: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_root_stats: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(a->t.n_games);
     uint32_t *d_visits = nullptr, *d_root_visits = nullptr;
     float *d_values = nullptr, *d_priors = nullptr, *d_root_value = nullptr;

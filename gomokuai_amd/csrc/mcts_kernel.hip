@@ -506,6 +506,7 @@ struct gmk_mcts {
     float* d_root_prior = nullptr;     // [n_games][225] by child index, used while GameHeader::noise is set
     void* d_step_scratch = nullptr;    // record outputs of gmk_mcts_step_host
     hipStream_t last_stream = nullptr;
+    bool rooted = false;               // gmk_mcts_set_roots has run: headers and arenas hold trees
 };
 
 extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, int c_rollouts, uint64_t seed, gmk_mcts** out) {
@@ -574,10 +575,12 @@ extern "C" int gmk_mcts_set_roots(gmk_mcts* m, const uint16_t* h_planes, const i
                        m->d_parent, static_cast<size_t>(m->node_capacity), m->n_games);
     GMK_HIP_CHECK(hipGetLastError());
     GMK_HIP_CHECK(hipDeviceSynchronize());
+    m->rooted = true;
     return GMK_OK;
 }
 
 extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
+    if (m && !m->rooted) { gmk::set_error("gmk_mcts_run: gmk_mcts_set_roots has not been called"); return GMK_ERR_STATE; }
     if (!m || playouts < 0) { gmk::set_error("gmk_mcts_run: bad arguments"); return GMK_ERR_ARG; }
     SearchParams prm;
     prm.c_puct = m->c_puct;
@@ -606,6 +609,7 @@ extern "C" int gmk_mcts_advance(gmk_mcts* m, uint8_t* d_moves, uint16_t* d_visit
 
 extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner,
                              int32_t* d_unfinished, int reuse_subtree, void* stream) {
+    if (m && !m->rooted) { gmk::set_error("gmk_mcts_step: gmk_mcts_set_roots has not been called"); return GMK_ERR_STATE; }
     if (!m || !d_moves || !d_lens || !d_winner || !d_unfinished) { gmk::set_error("gmk_mcts_step: bad arguments"); return GMK_ERR_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     m->last_stream = s;
@@ -655,6 +659,7 @@ extern "C" int gmk_mcts_step_host(gmk_mcts* m, const int16_t* h_moves, int reuse
 //   P <- (1 - epsilon) * P + epsilon * normalized(gamma(alpha, 1) per child)        (Statistical.hpp:29-34)
 // (root_noise.h).  Host side: 225 floats a game.
 extern "C" int gmk_mcts_add_root_noise(gmk_mcts* m, float alpha, float epsilon, void* stream) {
+    if (m && !m->rooted) { gmk::set_error("gmk_mcts_add_root_noise: gmk_mcts_set_roots has not been called"); return GMK_ERR_STATE; }
     if (!m || !(alpha > 0.0f)) { gmk::set_error("gmk_mcts_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     m->last_stream = s;
@@ -694,6 +699,7 @@ extern "C" int gmk_mcts_launch_info(gmk_mcts* m, int* grid, int* block, int* lds
 
 extern "C" int gmk_mcts_root_stats(gmk_mcts* m, uint32_t* h_visits, float* h_root_value, uint32_t* h_root_visits,
                                    uint32_t* h_nodes, int32_t* h_status) {
+    if (m && !m->rooted) { gmk::set_error("gmk_mcts_root_stats: gmk_mcts_set_roots has not been called"); return GMK_ERR_STATE; }
     if (!m) return GMK_ERR_ARG;
     const size_t n = static_cast<size_t>(m->n_games);
     uint32_t *d_visits = nullptr, *d_rv = nullptr, *d_nodes = nullptr;

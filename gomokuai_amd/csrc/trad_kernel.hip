@@ -812,6 +812,7 @@ extern "C" int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_val
                                    uint32_t* h_root_visits, float* h_root_value, int32_t* h_n_nodes, int32_t* h_status,
                                    uint64_t* h_evaluator_updates) {
     if (!t) { gmk::set_error("gmk_trad_root_stats: bad arguments"); return GMK_ERR_ARG; }
+    if (!t->positioned) { gmk::set_error("gmk_trad_root_stats: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(t->n_games);
     uint32_t *d_visits = nullptr, *d_root_visits = nullptr;
     float *d_values = nullptr, *d_priors = nullptr, *d_root_value = nullptr;

@@ -23,13 +23,22 @@ def test_out_of_order_and_bad_arguments():
         t.run(10)
     with pytest.raises(RuntimeError, match="set_positions"):
         t.step()
+    with pytest.raises(RuntimeError, match="set_positions"):
+        t.root_stats()                                           # the arenas hold nothing to read yet
     t.close()
+    m = G.BatchedMCTS(2, playouts_capacity=10)
+    for call in (lambda: m.run(5), lambda: m.root_stats(), lambda: m.add_root_noise()):
+        with pytest.raises(RuntimeError, match="set_roots"):
+            call()
+    m.close()
     r = G.PoolRAVEMCTS(2, node_capacity=1024)
     with pytest.raises(RuntimeError, match="set_positions"):
         r.run(10)
-    with pytest.raises(RuntimeError, match="run_poolrave"):
-        r.root_stats()                                           # no AMAF statistics before the first PoolRAVE search
+    with pytest.raises(RuntimeError, match="set_positions"):
+        r.root_stats()
     r.set_positions([[112], [112, 113]])
+    with pytest.raises(RuntimeError, match="run_poolrave"):
+        r.root_stats()                                           # positioned, but no AMAF statistics before the first PoolRAVE search
     r.run(2)                                                     # 225 + 224 + 223 nodes do not fit in 1024... the second expansion does not
     assert (r.root_stats()["n_nodes"] <= 1024).all()
     with pytest.raises(RuntimeError, match="run_poolrave"):
@@ -38,6 +47,8 @@ def test_out_of_order_and_bad_arguments():
     a = G.AlphaZeroMCTS(2, node_capacity=1024)
     with pytest.raises(RuntimeError, match="set_roots"):
         a.select()
+    with pytest.raises(RuntimeError, match="set_roots"):
+        a.root_stats()
     with pytest.raises(RuntimeError, match="invalid position"):
         bad = np.zeros((2, 2, 16), np.uint16); bad[0, 0, 3] = 1; bad[0, 1, 3] = 1     # a cell that is black and white
         a.set_roots(bad, np.full((2, 2), -1, np.int16))
