@@ -276,15 +276,57 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
 
 
 def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                       device=None, node_capacity=None, reuse_subtree=True, root_noise=(0.05, 0.25)):
+                       device=None, node_capacity=None, reuse_subtree=True, root_noise=(0.05, 0.25), slots=None):
     """n_games complete games of the network-guided searcher against itself (agents/alphazero.py:5-9 on both sides: the
     reference's AlphaZero self-play), all games in lock step on the current GPU: every move = `playouts` lock-step playouts of
     K7 with `network(states [n,6,15,15]) -> (value [n], probs [n,225])` at the leaves (network.FusedPolicyValueNetwork = K9),
     then every game plays its most visited child (MCTSAgent.eval_state -> MCTS::stepForward); with reuse_subtree the child's
     subtree is kept and root_noise = (alpha, epsilon) is mixed into the root priors before every search (MCTS.cpp:182).
-    Returns GameRecords like play_games."""
+    slots (fresh roots only, reuse_subtree=False): at most that many games in flight, a finished game hands its slot to the next one
+    (see play_supervisor_games).  Returns GameRecords like play_games."""
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    if slots is not None and slots < n_games:
+        if reuse_subtree:
+            raise ValueError("play_network_games: slots need fresh roots (reuse_subtree=False)")
+        games = _HostGames(n_games)
+        if opening_plies > 0:
+            m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+            games.open_with(m, l, opening_plies)
+        visits = np.zeros((n_games, N, N), dtype=np.uint16)
+        slots = int(slots)
+        tree = G.AlphaZeroMCTS(slots, node_capacity=node_capacity if node_capacity is not None else min(playouts * N + 1, (1 << 24) - 1), c_puct=c_puct)
+        active, next_game, overflow = np.arange(slots), slots, False
+        with torch.no_grad():
+            for _ in range((n_games // slots + 2) * N):
+                done = np.nonzero(games.over[active])[0]
+                take = min(len(done), n_games - next_game)
+                active[done[:take]] = np.arange(next_game, next_game + take)
+                next_game += take
+                if games.over[active].all():
+                    break
+                sub_moves, sub_lens = games.moves[active], games.lens[active]
+                last = np.full((slots, 2), -1, dtype=np.int16)
+                rows = np.arange(slots)
+                last[sub_lens > 0, 0] = sub_moves[rows[sub_lens > 0], sub_lens[sub_lens > 0] - 1]
+                last[sub_lens > 1, 1] = sub_moves[rows[sub_lens > 1], sub_lens[sub_lens > 1] - 2]
+                tree.set_roots(G.moves_to_planes(sub_moves, sub_lens), last)
+                tree.search(network, playouts)
+                st = tree.root_stats()
+                overflow |= bool((st["status"] & 1).any())
+                visited = st["visits"].max(1) > 0
+                best = np.where(games.over[active] | ~visited, -1, st["visits"].argmax(1))
+                games.over[active[(best < 0) & ~games.over[active]]] = True
+                played = np.full(n_games, -1, dtype=np.int64)
+                played[active] = best
+                at = games.lens.copy()
+                moved = games.apply(played)
+                slot_of = np.full(n_games, -1, dtype=np.int64)
+                slot_of[active] = np.arange(slots)
+                visits[moved, at[moved]] = np.minimum(st["visits"][slot_of[moved]], 65535)
+        tree.close()
+        return GameRecords(torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev), torch.from_numpy(games.winner).to(dev),
+                           torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
     games = _HostGames(n_games)
     if opening_plies > 0:
         m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)

@@ -244,6 +244,10 @@ def test_network_self_play(oracle):
     d = selfplay.play_network_games(6, fused, 40, opening_plies=2, first_game_id=9, seed=3, reuse_subtree=False, root_noise=None)
     same = (c.moves.cpu() == d.moves.cpu()).all(1)
     assert int(same.sum()) >= 4                              # a tie between two children decided by 1e-7 may send a game elsewhere
+    # 10 games through 3 slots (fresh roots): the same games as all at once (the search of a game does not depend on its slot)
+    e = selfplay.play_network_games(10, fused, 30, opening_plies=2, first_game_id=40, seed=3, reuse_subtree=False, root_noise=None, slots=3)
+    f = selfplay.play_network_games(10, fused, 30, opening_plies=2, first_game_id=40, seed=3, reuse_subtree=False, root_noise=None)
+    assert (e.moves.cpu() == f.moves.cpu()).all() and (e.winner.cpu() == f.winner.cpu()).all() and int(e.lens.min()) >= 9
     fused.close()
 
 
