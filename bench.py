@@ -247,7 +247,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
             "network_ms_per_step": net_ms,
             "config": {"workload": "network-guided MCTS (K7), %d games x %d lock-step playouts per GPU, PolicyValueNetwork float32 with random weights, 4-ply openings" % (n, P)},
             "roofline": {"bound": "mfma", "achieved": conv_flop / (trunk_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": conv_flop / (trunk_ms * 1e-3) / 1e12 / 157.3, "traffic": None, "kernel": "pvnet_trunk_kernel", "kernel_ms": trunk_ms,
+                         "frac": conv_flop / (trunk_ms * 1e-3) / 1e12 / 157.3, "traffic": measured_traffic("pvnet_trunk_kernel", "positions_per_launch", n), "kernel": "pvnet_trunk_kernel", "kernel_ms": trunk_ms,
                          "alg_flop_per_launch": conv_flop, "note": "dense f32-input MFMA peak (MI355X_MICROARCH.md); the convolution FLOPs of the 225 real pixels"},
             "pytorch_module_ms_per_step": torch_ms, "max_abs_diff_vs_pytorch_module": err,
             "note": "the step is the network's forward pass: K9 (one fused kernel for the convolutions, float32 MFMA) + three small dense layers through PyTorch-ROCm; "
