@@ -709,15 +709,35 @@ extern "C" int gmk_trad_create(int n_games, int node_capacity, gmk_trad** out) {
 
 extern "C" int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves, const int32_t* h_lens) {
     if (!t || !h_moves || !h_lens) { gmk::set_error("gmk_trad_set_positions: bad arguments"); return GMK_ERR_ARG; }
-    for (int g = 0; g < t->n_games; ++g)
-        if (h_lens[g] < 0 || h_lens[g] > 225) { gmk::set_error("gmk_trad_set_positions: game %d has %d moves", g, h_lens[g]); return GMK_ERR_ARG; }
+    bool all = true;
+    for (int g = 0; g < t->n_games; ++g) {
+        if (h_lens[g] > 225) { gmk::set_error("gmk_trad_set_positions: game %d has %d moves", g, h_lens[g]); return GMK_ERR_ARG; }
+        all &= h_lens[g] >= 0;
+    }
+    if (!all && !t->positioned) { gmk::set_error("gmk_trad_set_positions: the first call must position every game (a negative length keeps a game as it is)"); return GMK_ERR_ARG; }
+    const size_t n = static_cast<size_t>(t->n_games);
     GMK_HIP_CHECK(hipDeviceSynchronize());
-    GMK_HIP_CHECK(hipMemcpy(t->d_moves, h_moves, static_cast<size_t>(t->n_games) * 225, hipMemcpyHostToDevice));
-    GMK_HIP_CHECK(hipMemcpy(t->d_lens, h_lens, static_cast<size_t>(t->n_games) * 4, hipMemcpyHostToDevice));
-    std::vector<TradHeader> hdr(t->n_games);
-    GMK_HIP_CHECK(hipMemcpy(hdr.data(), t->d_hdr, hdr.size() * sizeof(TradHeader), hipMemcpyDeviceToHost));
-    for (TradHeader& h : hdr) { h.fresh = 1; h.playouts_done = 0; }
-    GMK_HIP_CHECK(hipMemcpy(t->d_hdr, hdr.data(), hdr.size() * sizeof(TradHeader), hipMemcpyHostToDevice));
+    std::vector<TradHeader> hdr(n);
+    GMK_HIP_CHECK(hipMemcpy(hdr.data(), t->d_hdr, n * sizeof(TradHeader), hipMemcpyDeviceToHost));
+    if (all) {
+        GMK_HIP_CHECK(hipMemcpy(t->d_moves, h_moves, n * 225, hipMemcpyHostToDevice));
+        GMK_HIP_CHECK(hipMemcpy(t->d_lens, h_lens, n * 4, hipMemcpyHostToDevice));
+        for (TradHeader& h : hdr) { h.fresh = 1; h.playouts_done = 0; }
+    } else {                                                    // a negative length: that game keeps its position and its tree
+        std::vector<uint8_t> moves(n * 225);
+        std::vector<int32_t> lens(n);
+        GMK_HIP_CHECK(hipMemcpy(moves.data(), t->d_moves, n * 225, hipMemcpyDeviceToHost));
+        GMK_HIP_CHECK(hipMemcpy(lens.data(), t->d_lens, n * 4, hipMemcpyDeviceToHost));
+        for (size_t g = 0; g < n; ++g)
+            if (h_lens[g] >= 0) {
+                std::memcpy(&moves[g * 225], h_moves + g * 225, 225);
+                lens[g] = h_lens[g];
+                hdr[g].fresh = 1; hdr[g].playouts_done = 0;
+            }
+        GMK_HIP_CHECK(hipMemcpy(t->d_moves, moves.data(), n * 225, hipMemcpyHostToDevice));
+        GMK_HIP_CHECK(hipMemcpy(t->d_lens, lens.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    GMK_HIP_CHECK(hipMemcpy(t->d_hdr, hdr.data(), n * sizeof(TradHeader), hipMemcpyHostToDevice));
     t->positioned = true;
     return GMK_OK;
 }

@@ -362,7 +362,8 @@ class TraditionalMCTS:
         _check(load().gmk_trad_reset_evaluators(self.h))
 
     def set_positions(self, move_lists, lens=None):
-        """One move list per game, or (with lens) the arrays themselves: moves uint8[n, 225], lens int32[n]."""
+        """One move list per game, or (with lens) the arrays themselves: moves uint8[n, 225], lens int32[n]; a negative length
+        leaves that game's position and tree as they are (not on the first call)."""
         if lens is not None:
             moves = np.ascontiguousarray(move_lists, dtype=np.uint8)
             lens = np.ascontiguousarray(lens, dtype=np.int32)

@@ -184,14 +184,13 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
     is played.  Without noise the search is deterministic; variety then comes from the openings (synthetic generator,
     `opening_plies` plies of game first_game_id + g).  policy="poolrave" plays the same loop with MCTS(PoolRAVEPolicy)
     (agents/mcts.py:36-40) on both sides: K8 searches, random rollouts seeded by (seed, first_game_id + g).
-    slots (fresh roots only): at most that many games are in flight; a game that ends hands its slot -- tree arena, evaluator,
+    slots: at most that many games are in flight; a game that ends hands its slot -- tree arena, evaluator,
     wavefront -- to the next unstarted game, so the GPU stays full instead of waiting for the longest game of the batch (a search
     costs the same time however many of its games are still alive: one wavefront per game, latency bound).
     Returns the same GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
     if slots is not None and slots < n_games:
-        if reuse_subtree:
-            raise ValueError("play_supervisor_games: slots need fresh roots (reuse_subtree=False)")
-        return _play_supervisor_slots(n_games, int(slots), playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy)
+        return _play_supervisor_slots(n_games, int(slots), playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy,
+                                      reuse_subtree, root_noise)
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -230,7 +229,8 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
                        torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)
 
 
-def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy):
+def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy,
+                           reuse_subtree=False, root_noise=None):
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -239,7 +239,7 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
         m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
         games.open_with(m, l, opening_plies)
     visits = np.zeros((n_games, N, N), dtype=np.uint16)
-    cap = node_capacity if node_capacity is not None else min(playouts * 226 + 1, (1 << 24) - 1)
+    cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * 226 + 1, (1 << 24) - 1)
     if policy == "poolrave":
         tree = G.PoolRAVEMCTS(slots, node_capacity=cap, c_puct=c_puct, seed=seed, first_game_id=first_game_id)
     elif policy == "traditional":
@@ -249,15 +249,23 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
     active = np.arange(slots)                                    # the game in each slot
     next_game = slots
     overflow = False
+    fresh = np.ones(slots, dtype=bool)                           # slots whose game starts from a new root at the next search
     for _ in range((n_games // slots + 2) * N):
         # a finished game hands its slot to the next unstarted one
         done = np.nonzero(games.over[active])[0]
         take = min(len(done), n_games - next_game)
         active[done[:take]] = np.arange(next_game, next_game + take)
+        fresh[done[:take]] = True
         next_game += take
         if games.over[active].all():
             break
-        tree.set_positions(games.moves[active], games.lens[active])
+        if not reuse_subtree:
+            tree.set_positions(games.moves[active], games.lens[active])
+        elif fresh.any():                                        # the others keep the subtree gmk_trad_step left them
+            tree.set_positions(games.moves[active], np.where(fresh, games.lens[active], -1))
+        fresh[:] = False
+        if root_noise is not None:
+            tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
         tree.run(playouts, stream)
         st = tree.root_stats()
         overflow |= bool((st["status"] & 1).any())
@@ -270,6 +278,8 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
         slot_of = np.full(n_games, -1, dtype=np.int64)
         slot_of[active] = np.arange(slots)
         visits[moved, at[moved]] = np.minimum(st["visits"][slot_of[moved]], 65535)
+        if reuse_subtree:
+            tree.step(best.astype(np.int16))                     # finished games ask for -1 on a childless root: nothing moves
     tree.close()
     return GameRecords(torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev), torch.from_numpy(games.winner).to(dev),
                        torch.from_numpy(visits.view(np.int16)).to(dev), first_game_id, overflow)

@@ -197,7 +197,7 @@ typedef struct gmk_trad gmk_trad;
 int gmk_trad_create(int n_games, int node_capacity /* nodes per game, 256 .. 2^24-1 */, gmk_trad** out);
 int gmk_trad_destroy(gmk_trad* t);
 int gmk_trad_reset_evaluators(gmk_trad* t);                       /* Evaluator::reset for every game */
-int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves /* [n][225] */, const int32_t* h_lens /* [n] */);
+int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves /* [n][225] */, const int32_t* h_lens /* [n]; < 0: this game keeps its position and tree */);
 int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stream);
 /* host outputs, any may be NULL: per-cell root child visits / values / priors [n][225], the move stepForward() would
  * play (-1 without children), root visits and value, nodes in the tree, status (bit 0 node capacity reached, bit 1

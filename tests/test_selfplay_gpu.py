@@ -272,5 +272,16 @@ def test_supervisor_self_play_with_slots(oracle):
     assert int(same.sum()) >= 10
     states, _, _ = a.to_samples(first_move=3)
     assert states.shape[0] == int((ra.lens - 3).sum())
-    with pytest.raises(ValueError):
-        selfplay.play_supervisor_games(8, 10, slots=4, reuse_subtree=True)
+    # slots with kept subtrees and root noise (a handed-over slot starts from a new root, the others keep stepping): legal, finished, reproducible
+    kw = dict(opening_plies=2, first_game_id=50, slots=3, reuse_subtree=True, root_noise=(0.05, 0.25), seed=12)
+    for policy, c in (("traditional", 5.0), ("poolrave", 2.0)):
+        c1 = selfplay.play_supervisor_games(9, 90, c_puct=c, policy=policy, **kw)
+        c2 = selfplay.play_supervisor_games(9, 90, c_puct=c, policy=policy, **kw)
+        assert (c1.moves.cpu() == c2.moves.cpu()).all() and not c1.overflow
+        rc = c1.cpu()
+        for g in range(len(c1)):
+            b = oracle.new_board()
+            for i in range(int(rc.lens[g])):
+                assert oracle.lib().go_board_check_move(C.byref(b), int(rc.moves[g, i]))
+                oracle.lib().go_board_apply(C.byref(b), int(rc.moves[g, i]), 1)
+            assert b.cur_player == 0 and b.winner == int(rc.winner[g]) and int(rc.lens[g]) >= 9
