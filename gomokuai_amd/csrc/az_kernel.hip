@@ -418,12 +418,12 @@ extern "C" int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint
     if (rc != GMK_OK) return rc;
     std::vector<AzHeader> hdr(n);
     GMK_HIP_CHECK(hipMemcpy(hdr.data(), a->t.hdr, n * sizeof(AzHeader), hipMemcpyDeviceToHost));
-    for (size_t g = 0; g < n; ++g) {
+    gmk::for_each_game(n, [&](size_t g) {
         float* p = &priors[g * 225];
         bool any = false;
         for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
         if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + static_cast<uint32_t>(g), hdr[g].stones));
-    }
+    });
     if (!a->d_noise_priors) GMK_HIP_CHECK(hipMalloc(&a->d_noise_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(a->d_noise_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(az_set_root_priors_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, a->d_noise_priors);

@@ -672,17 +672,18 @@ extern "C" int gmk_mcts_add_root_noise(gmk_mcts* m, float alpha, float epsilon, 
     GMK_HIP_CHECK(hipMemcpyAsync(hdr.data(), m->d_headers, sizeof(GameHeader) * n, hipMemcpyDeviceToHost, s));
     GMK_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<float> prior(n * 225, 0.0f);
-    for (size_t g = 0; g < n; ++g) {
+    const uint64_t seed = m->seed;
+    gmk::for_each_game(n, [&](size_t g) {
         GameHeader& h = hdr[g];
         h.noise = 0;
-        if ((h.status & 1u) || !h.root_expanded) continue;           // AddNoise is a no-op on a childless root
+        if ((h.status & 1u) || !h.root_expanded) return;             // AddNoise is a no-op on a childless root
         const int n_child = 225 - static_cast<int>(h.stones);
         float* p = &prior[g * 225];
         const float uniform = 1.0f / static_cast<float>(n_child);     // Default::UniformProbs: the priors Expand gave the children
         for (int i = 0; i < n_child; ++i) p[i] = uniform;
-        gmk::mix_root_noise(p, n_child, alpha, epsilon, gmk::root_noise_engine_seed(m->seed, h.game_id, h.stones));
+        gmk::mix_root_noise(p, n_child, alpha, epsilon, gmk::root_noise_engine_seed(seed, h.game_id, h.stones));
         h.noise = 1;
-    }
+    });
     GMK_HIP_CHECK(hipMemcpyAsync(m->d_root_prior, prior.data(), prior.size() * sizeof(float), hipMemcpyHostToDevice, s));
     GMK_HIP_CHECK(hipMemcpyAsync(m->d_headers, hdr.data(), sizeof(GameHeader) * n, hipMemcpyHostToDevice, s));
     GMK_HIP_CHECK(hipStreamSynchronize(s));

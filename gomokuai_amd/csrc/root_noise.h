@@ -5,9 +5,12 @@
 // runs; only the engine's seed differs (the reference: random_device; here: Philox of (seed; game id, stones on the root
 // board, 'nois')), so searches stay reproducible.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <random>
+#include <thread>
+#include <vector>
 
 #include "philox.h"
 
@@ -29,6 +32,18 @@ inline void mix_root_noise(float* p, int n, float alpha, float epsilon, uint32_t
     }
     const float norm = sq > 0.0f ? std::sqrt(sq) : 1.0f;           // VectorXf::normalized(): a zero vector stays zero
     for (int i = 0; i < n; ++i) p[i] += epsilon * (sq > 0.0f ? noise[i] / norm : noise[i]);
+}
+
+// fn(g) for g in [0, n) on the host's cores: a game's draws depend on nothing but its own seed, and seeding a Mersenne twister
+// plus ~220 gamma draws per game is ~20 us, which at thousands of games per search would rival the search itself
+template <class Fn>
+inline void for_each_game(size_t n, Fn fn) {
+    const size_t workers = std::min<size_t>({n / 64 + 1, std::max(1u, std::thread::hardware_concurrency()), 16});
+    if (workers <= 1) { for (size_t g = 0; g < n; ++g) fn(g); return; }
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; ++w)
+        pool.emplace_back([=]() { for (size_t g = n * w / workers; g < n * (w + 1) / workers; ++g) fn(g); });
+    for (std::thread& t : pool) t.join();
 }
 
 }  // namespace gmk

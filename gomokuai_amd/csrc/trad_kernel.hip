@@ -813,12 +813,12 @@ extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, 
     int rc = gmk_trad_root_stats(t, nullptr, nullptr, priors.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     if (rc != GMK_OK) return rc;
     GMK_HIP_CHECK(hipMemcpy(lens.data(), t->d_lens, n * 4, hipMemcpyDeviceToHost));
-    for (size_t g = 0; g < n; ++g) {
+    gmk::for_each_game(n, [&](size_t g) {
         float* p = &priors[g * 225];
         bool any = false;
         for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
         if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + static_cast<uint32_t>(g), static_cast<uint32_t>(lens[g])));
-    }
+    });
     if (!t->d_priors) GMK_HIP_CHECK(hipMalloc(&t->d_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(t->d_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
     const TradArena a = t->arena();
