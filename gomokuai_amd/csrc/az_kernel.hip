@@ -311,6 +311,8 @@ struct gmk_az {
     AzArena other{};                                             // second arena, allocated by the first gmk_az_step
     int16_t* d_forced = nullptr;
     float* d_noise_priors = nullptr;
+    std::vector<uint32_t> game_ids;                              // the game a slot is playing, relative to the callers' first_game_id (default: the slot number)
+    bool second_arena = false;
     // device scratch of the host-driven form (gmk_az_select_host / gmk_az_expand_host)
     float *h_states = nullptr, *h_values = nullptr, *h_probs = nullptr;
     int16_t* h_paths = nullptr;
@@ -338,7 +340,15 @@ extern "C" int gmk_az_create(int n_games, int node_capacity, double c_puct, gmk_
                     hipMalloc(&a->t.stat, nodes * 8) == hipSuccess && hipMalloc(&a->t.kids, nodes * 8) == hipSuccess &&
                     hipMalloc(&a->t.prior, nodes * 4) == hipSuccess && hipMalloc(&a->t.parent, nodes * 4) == hipSuccess;
     if (!ok) { gmk_az_destroy(a); gmk::set_error("gmk_az_create: device allocation failed"); return GMK_ERR_HIP; }
+    a->game_ids.resize(static_cast<size_t>(n_games));
+    for (int g = 0; g < n_games; ++g) a->game_ids[static_cast<size_t>(g)] = static_cast<uint32_t>(g);
     *out = a;
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_set_game_ids(gmk_az* a, const uint32_t* h_ids) {
+    if (!a || !h_ids) { gmk::set_error("gmk_az_set_game_ids: bad arguments"); return GMK_ERR_ARG; }
+    a->game_ids.assign(h_ids, h_ids + a->t.n_games);
     return GMK_OK;
 }
 
@@ -393,11 +403,18 @@ extern "C" int gmk_az_step(gmk_az* a, const int16_t* h_moves) {
     if (!a) { gmk::set_error("gmk_az_step: bad arguments"); return GMK_ERR_ARG; }
     if (!a->rooted) { gmk::set_error("gmk_az_step: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(a->t.n_games), nodes = n * static_cast<size_t>(a->t.cap);
-    if (!a->other.stat) {
+    if (!a->second_arena) {
         const bool ok = hipMalloc(&a->other.stat, nodes * 8) == hipSuccess && hipMalloc(&a->other.kids, nodes * 8) == hipSuccess &&
                         hipMalloc(&a->other.prior, nodes * 4) == hipSuccess && hipMalloc(&a->other.parent, nodes * 4) == hipSuccess &&
                         hipMalloc(&a->d_forced, n * 2) == hipSuccess;
-        if (!ok) { gmk::set_error("gmk_az_step: hipMalloc of the second arena (%zu nodes) failed", nodes); return GMK_ERR_HIP; }
+        if (!ok) {                                                  // all or nothing: a later call must not find half an arena
+            (void)hipFree(a->other.stat); (void)hipFree(a->other.kids); (void)hipFree(a->other.prior); (void)hipFree(a->other.parent); (void)hipFree(a->d_forced);
+            a->other = AzArena{}; a->d_forced = nullptr;
+            (void)hipGetLastError();
+            gmk::set_error("gmk_az_step: hipMalloc of the second arena (%zu nodes) failed", nodes);
+            return GMK_ERR_HIP;
+        }
+        a->second_arena = true;
     }
     GMK_HIP_CHECK(hipDeviceSynchronize());
     if (h_moves) GMK_HIP_CHECK(hipMemcpy(a->d_forced, h_moves, n * 2, hipMemcpyHostToDevice));
@@ -422,7 +439,7 @@ extern "C" int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint
         float* p = &priors[g * 225];
         bool any = false;
         for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
-        if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + static_cast<uint32_t>(g), hdr[g].stones));
+        if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + a->game_ids[g], hdr[g].stones));
     });
     if (!a->d_noise_priors) GMK_HIP_CHECK(hipMalloc(&a->d_noise_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(a->d_noise_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));

@@ -409,6 +409,8 @@ private:
         int32_t nodes = 1, status = 0;
         visits_.assign(kN, 0);
         throw_gmk(gmk_az_root_stats(az_handle_, visits_.data(), values.data(), priors.data(), &root_visits, &q, &nodes, &status));
+        if (status & 2)                                             // node arena full: playouts were dropped, the statistics are not those of the requested search
+            throw std::overflow_error("CorePyExt (MI355X): the search tree outgrew its node arena (" + std::to_string(az_capacity_) + " nodes); playouts were dropped");
         root_->state_value = q;
         root_->node_visits = root_visits;
         root_->children.clear();

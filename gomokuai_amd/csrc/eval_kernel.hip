@@ -11,27 +11,33 @@
 //     grid-stride loop: the automaton (dense DFA 556x4 words + emission records, ~14 KB) is staged at LDS address 0
 //     ONCE per workgroup, so a DFA step's address is just (next-row offset | symbol * 4); after that single barrier
 //     the waves never wait for each other (phases of one board are ordered by wavefront-scope fences only);
+//   * a wavefront takes SIXTEEN consecutive boards at a time.  Phase D, once per group: the 7x7 density stencil of all sixteen
+//     boards (both colours) on the matrix cores -- Out[cell][board, colour] = W[cell][cell'] * Stone[cell'][board, colour] with
+//     the constant banded weight matrix as the A operand of v_mfma_i32_32x32x32_i8 (62 MFMAs per group, small integers: exact);
+//     the accumulators go straight to HBM as 16-byte stores, and what the other phases need from the density (count >= 1 for
+//     the area bonus, count >= 2 for the compound gate, per empty cell and colour) stays in eight registers as bit strings;
 //   * phase 0: the two bit-planes become 88 "line words" (rows, columns, both diagonals) that already hold the 2-bit
-//     DFA symbols of their cells (one LDS XOR per stone and line), plus the rows as 4-bit digits for phase 3;
+//     DFA symbols of their cells (one LDS XOR per stone and line);
 //   * phase 1: the 72 lines that can hold a pattern (>= 5 cells) are spread over the 64 lanes (the 8 shortest ride
 //     behind the shortest primaries: 19 steps per lane); a lane's lines are one stream of 2-bit symbols,
 //     a step is one LDS lookup; emitting transitions are queued by ballot prefix;
 //   * phase 2: one lane per queued transition: one 16-byte record read gives the (<= 2) matches, each with a
 //     compact list of <= 4 score deposits (ds_add_u32) and 4-bit per-(cell, colour, direction, type) counters;
-//   * phase 3: one lane per cell: the 7x7 density stencil as v_dot8_u32_u4 dot products of digit windows with the
-//     block's weight rows, area bonus, compound decision from the counters;
+//   * phase 3: one lane per cell: area bonus and compound candidates from the gate bits of phase D and the counters;
 //   * phase 4: eight lanes per compound component: its counter-move cells from the 13-symbol window around it;
 //   * phase 5: the 3.6 KB score block leaves LDS as coalesced 16-byte stores.
 // HBM traffic per board: 64 B in, 7 248 B out (7 312 B algorithmic); everything else stays on chip.
 #include <algorithm>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "capi_common.h"
 
 namespace {
 
-constexpr int kBoardsPerBlock = 16;
+constexpr int kBoardsPerBlock = 16;               // wavefronts per workgroup, one board in flight each
+constexpr int kGroupBoards = 16;                  // boards a wavefront takes at a time (the columns of phase D's matrix product)
 constexpr int kThreads = 64 * kBoardsPerBlock;
 constexpr int kCells = 225;
 constexpr int kQueueCap = 448;
@@ -41,17 +47,14 @@ constexpr int kMaxBlocksPerCu = 1;
 constexpr int kScoreWords = 4 * kCells;          // 900, 16-byte aligned block
 constexpr int kCntWords = 3 * kCells + 1;        // [LiveThree, DeadThree, LiveTwo][cell]: eight 4-bit counters per word, field = colour * 4 + direction:
                                                  // how many '_' pieces of matches of that type lie on the cell (<= 15: at most 8 transitions x 2 matches reach a cell)
-constexpr int kNibWords = 21 * 6 + 2;            // stones as 4-bit digits for v_dot8_u32_u4: [row -3 .. 17][black, white][3 words]; a row is
-                                                 // 3 zero digits, 15 cells, 3 zero digits (+ 3 unused), so the 7 digits around column x start at digit x
-constexpr int kZeroWords = kNibWords + kScoreWords + kCntWords;      // cleared for every board (a multiple of 4); the digit rows come first:
-                                                                      // phase 3 reaches all 28 of its words from one base register with immediate offsets
+constexpr int kZeroWords = kScoreWords + kCntWords;                   // cleared for every board (a multiple of 4)
 constexpr int kLineWords = 96;                   // line words, 2 bits per cell = its DFA symbol (0 black, 1 white, 3 blank), cell p of the line at bits 2p:
                                                  // rows [0,15), columns [20,35), diagonals x-y+14 at [36,65), anti-diagonals x+y at [65,94)
 constexpr int kColBase = 20, kDiagBase = 36, kAntiBase = 65;
 constexpr int kMiscWords = 16;                   // [0] stones black | white << 16, [1] winner bits, [2] error, [3] compound queue count, [4..14] totals
 constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
 static_assert(kZeroWords % 4 == 0 && kBoardWords % 4 == 0, "16-byte alignment of the per-board blocks");
-constexpr int kStaticTableWords = 128 + kLineWords;   // lane jobs, initial line words
+constexpr int kStaticTableWords = 128 + kLineWords + 512;   // lane jobs, initial line words, the bits-to-bytes table of phase D
 
 // Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
@@ -130,13 +133,245 @@ __device__ __forceinline__ void add_counter_cells(uint32_t w0, int back, int q, 
     }
 }
 
+// ---- phase D: the density stencil of sixteen boards on the matrix cores ----
+// Evaluator::Updater::updateBlock (Pattern.cpp:236-272) adds, for every stone, the 7x7 BlockWeights (Pattern.cpp:598-609) around
+// it to its colour's weight plane and their non-zero mask to its count plane: as a function of the position,
+//   weight[c][q] = sum over cells q' of W[q' - q] * stone_c[q'],  count[c][q] likewise with W != 0,
+// a product of a constant banded 225 x 225 matrix with the stone planes.  Sixteen boards x two colours are the 32 columns
+// of v_mfma_i32_32x32x32_i8; an M tile is 32 consecutive cells (7 tiles cover cells 0..223, cell 224 is done by hand), a K tile
+// two board rows of 16 (k = 16 y + x: the stones of a row become the bytes of its tile as they lie).  A tile of cells only
+// reaches rows y0-3 .. y1+3, so 31 (M, K) tile pairs per plane kind hold non-zeros: 62 MFMAs per group.
+constexpr int kDensTiles = 7;
+__host__ __device__ constexpr int dens_kt_lo(int m) { return (((32 * m) / 15 - 3) < 0 ? 0 : (32 * m) / 15 - 3) / 2; }
+__host__ __device__ constexpr int dens_kt_hi(int m) { return (((32 * m + 31) / 15 + 3) > 14 ? 14 : (32 * m + 31) / 15 + 3) / 2; }
+__host__ __device__ constexpr int dens_steps() { int n = 0; for (int m = 0; m < kDensTiles; ++m) n += 2 * (dens_kt_hi(m) - dens_kt_lo(m) + 1); return n; }
+constexpr int kDensSteps = dens_steps();            // 62: 31 for the count planes, then 31 for the weight planes
+constexpr int kDensAhead = 4;                       // A operands in flight in the gate pass
+__host__ __device__ constexpr int dens_tile_base(int m) { int n = 0; for (int i = 0; i < m; ++i) n += dens_kt_hi(i) - dens_kt_lo(i) + 1; return n; }
+constexpr int kDensKindSteps = dens_tile_base(kDensTiles);        // 31
+struct constexpr_step { int m, kt; };
+__host__ __device__ constexpr constexpr_step dens_step(int s) {   // step of one plane kind -> (M tile, K tile)
+    for (int m = 0; m < kDensTiles; ++m)
+        for (int kt = dens_kt_lo(m); kt <= dens_kt_hi(m); ++kt, --s)
+            if (s == 0) return {m, kt};
+    return {0, 0};
+}
+// BlockWeights by |dy| and dx + 3 (the matrix is symmetric in both axes)
+__host__ __device__ constexpr int block_weight(int dy, int dx) {
+    constexpr int w[4][7] = {{1, 3, 4, 0, 4, 3, 1}, {0, 3, 5, 4, 5, 3, 0}, {0, 4, 3, 3, 3, 4, 0}, {2, 0, 0, 1, 0, 0, 2}};
+    return w[dy < 0 ? -dy : dy][dx + 3];
+}
+
+template <class F, int... S>
+__device__ __forceinline__ void for_each_step(F& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+struct __attribute__((packed, aligned(4))) Int4Unaligned { int32_t x, y, z, w; };      // a 16-byte store to a 4-byte aligned address
+
+// ---- phase D, part 1 (once per group): the gates ----
+// Lane l = (column n = l & 31, k half h = l >> 5); column n = board (n >> 1) of the group, plane (n & 1) (0 black, 1 white).
+// Count planes only, cells on the accumulator ROWS (A = weights, B = stones): lane (n, h) then holds, per M tile, sixteen cells of
+// ITS column, and "count >= 1", "count >= 2" pack into bit strings with two instructions per cell.  Nothing is stored from here
+// (except cell 224, which no tile covers): the planes leave in part 2, spread over the group's board iterations.
+// a_tab: the weight operands in lane order, one uint4 per lane and step.
+// Returns, for THIS lane's column, bit strings over the cells, already restricted to empty cells, as four registers each:
+// register p of lane (n, h) holds cells 64 p + 32 h .. + 31, so that pass p of phase 3 (cell = 64 p + lane) finds its bit
+// with ONE ds_bpermute from lane (lane & 32) | n.  gate1: count >= 1 (<=> weight > 0), gate2: count >= 2.
+__device__ __forceinline__ void density_gates(const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
+                                              const v4i* __restrict__ a_tab, int32_t* __restrict__ out_density,
+                                              v4i* s_bt /* 8 KB of this wavefront's LDS */, uint32_t (&gate1)[4], uint32_t (&gate2)[4]) {
+    const int n = lane & 31, h = lane >> 5, plane = n & 1;
+    const int board = first_board + (n >> 1);
+    const bool live = board < n_boards;
+    uint32_t own[8], both[8];                       // rows 2k (low half) and 2k+1 (high half) of this column's plane / of both planes
+    {
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+        if (live) {
+            const uint4* p = reinterpret_cast<const uint4*>(planes + static_cast<size_t>(board) * 32);
+            a0 = p[plane * 2]; a1 = p[plane * 2 + 1]; b0 = p[2 - plane * 2]; b1 = p[3 - plane * 2];
+        }
+        own[0] = a0.x; own[1] = a0.y; own[2] = a0.z; own[3] = a0.w; own[4] = a1.x; own[5] = a1.y; own[6] = a1.z; own[7] = a1.w;
+        both[0] = a0.x | b0.x; both[1] = a0.y | b0.y; both[2] = a0.z | b0.z; both[3] = a0.w | b0.w;
+        both[4] = a1.x | b1.x; both[5] = a1.y | b1.y; both[6] = a1.z | b1.z; both[7] = a1.w | b1.w;
+    }
+    // stone operands: K tile kt, slot (h, j) = cell (row 2 kt + h, column j): the row's bits as bytes.  They wait in LDS (the
+    // board region is idle during this part) instead of 32 registers: one ds_read_b128 per MFMA, hidden behind it.
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        const uint32_t r = (own[kt] >> (16 * h)) & 0x7FFFu;
+        v4i b;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) b[v] = static_cast<int>((((r >> (4 * v)) & 15u) * 0x204081u) & 0x01010101u);
+        s_bt[kt * 64 + lane] = b;
+    }
+    // occupied cells of the board as one string over the cells (bit q of the 225)
+    uint32_t occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        const uint32_t pair = (both[kt] & 0x7FFFu) | ((both[kt] >> 16) << 15);          // rows 2 kt, 2 kt + 1: 30 cells
+        const int off = 30 * kt, w = off >> 5, sft = off & 31;
+        occ[w] |= pair << sft;
+        if (sft > 2) occ[w + 1] |= pair >> (32 - sft);
+    }
+    // cell 224 = (14, 14): the taps dy, dx in -3 .. 0 that lie on the board
+    uint32_t c224 = 0, w224 = 0;
+#pragma unroll
+    for (int dy = -3; dy <= 0; ++dy) {
+        const int y = 14 + dy;
+        const uint32_t r = (y & 1) ? own[y >> 1] >> 16 : own[y >> 1] & 0xFFFFu;
+#pragma unroll
+        for (int dx = -3; dx <= 0; ++dx) {
+            if (block_weight(dy, dx) == 0) continue;
+            const uint32_t bit = (r >> (14 + dx)) & 1u;
+            c224 += bit;
+            w224 += bit * static_cast<uint32_t>(block_weight(dy, dx));
+        }
+    }
+    if (live && out_density && h == 0) {            // [white, black][count, weight][cell]; occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
+        int32_t* out = out_density + static_cast<size_t>(board) * 4 * kCells + (1 - plane) * 2 * kCells;
+        const uint32_t neg = 0u - (occ[7] & 1u);
+        out[224] = static_cast<int32_t>(c224 ^ neg);
+        out[kCells + 224] = static_cast<int32_t>(w224 ^ neg);
+    }
+    // The 31 steps as ONE software pipeline: the weight operand of step s + kDensAhead is requested when step s issues, the
+    // stone operand comes from LDS.  The scheduling barriers keep the compiler from gathering the loads of a whole tile at its
+    // top (registers this kernel does not have at four wavefronts per SIMD).
+    uint32_t gates[8];                              // per M tile: count >= 1 at bit pos, count >= 2 at bit pos + 4 (pos below)
+    uint32_t a_off = lane * 16;                     // walks the table in step order; opaque, so that ONE offset register serves all loads
+    wave_phase_fence();
+    v4i a_ring[kDensAhead];
+#pragma unroll
+    for (int s = 0; s < kDensAhead; ++s) {
+        a_ring[s] = *reinterpret_cast<const v4i*>(reinterpret_cast<const char*>(a_tab) + a_off);
+        a_off += 1024;
+        asm volatile("" : "+v"(a_off));
+    }
+    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto do_step = [&](auto step_constant) {        // one call per step, expanded at compile time (see the fold below)
+        constexpr int s = decltype(step_constant)::value;
+        constexpr constexpr_step st = dens_step(s);
+        const v4i b = s_bt[st.kt * 64 + lane];
+        if (st.kt == dens_kt_lo(st.m)) acc = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_ring[s % kDensAhead], b, acc, 0, 0, 0);
+        if (s + kDensAhead < kDensKindSteps) {
+            a_ring[s % kDensAhead] = *reinterpret_cast<const v4i*>(reinterpret_cast<const char*>(a_tab) + a_off);
+            a_off += 1024;
+            asm volatile("" : "+v"(a_off));
+        }
+        if (st.kt == dens_kt_hi(st.m)) {            // accumulator i = cell 32 m + 8 (i / 4) + 4 h + (i % 4)
+            uint32_t t = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pos = 8 * (i / 4) + (i % 4);
+                const uint32_t c = min(static_cast<uint32_t>(acc[i]), 2u);              // 0, 1, 2
+                t |= (((c + 1u) >> 1) | ((c >> 1) << 4)) << pos;
+            }
+            asm volatile("" : "+v"(t));             // (pins the sixteen-to-one reduction here: sunk to the end of the pass it would keep every tile's accumulators alive)
+            gates[st.m] = t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for_each_step(do_step, std::make_integer_sequence<int, kDensKindSteps>{});
+    gates[7] = 0;
+    uint32_t g1[8], g2[8];
+#pragma unroll
+    for (int m = 0; m < kDensTiles; ++m) {
+        g1[m] = (gates[m] & 0x0F0F0F0Fu) << (4 * h);
+        g2[m] = ((gates[m] >> 4) & 0x0F0F0F0Fu) << (4 * h);
+    }
+    g1[7] = h == 0 ? min(c224, 1u) : 0u;
+    g2[7] = h == 0 ? min(c224, 2u) >> 1 : 0u;
+    // both k halves of a column hold half of its cells' bits: exchange, restrict to empty cells, lay out for phase 3
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        g1[k] = (g1[k] | static_cast<uint32_t>(__shfl_xor(static_cast<int>(g1[k]), 32))) & ~occ[k];
+        g2[k] = (g2[k] | static_cast<uint32_t>(__shfl_xor(static_cast<int>(g2[k]), 32))) & ~occ[k];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        gate1[p] = h ? g1[2 * p + 1] : g1[2 * p];
+        gate2[p] = h ? g2[2 * p + 1] : g2[2 * p];
+    }
+}
+
+// ---- phase D, part 2 (fourteen times per group, one per board iteration): one plane kind of one M tile leaves for HBM ----
+// Here the BOARDS are on the accumulator rows (A = stones, B = weights): lane (n, h) holds cell 32 M + n of sixteen board-colour
+// columns, so a store instruction writes 2 x 128 contiguous bytes (with the cells on the rows a lane would own 16 bytes of 64
+// different cache lines: measured 2.4 TB/s for the density planes alone).  Spreading the fourteen passes over the group's board
+// iterations spreads the 3.6 KB per board over the kernel's run time instead of one burst at its start.
+// The stones are read again (64 B per board from L2) and become operand bytes through a 256-entry table in LDS (byte -> 8 bytes).
+template <int KIND, int M>
+__device__ __forceinline__ void density_tile_pass(const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
+                                                  const v4i* __restrict__ a_tab, int32_t* __restrict__ out_density,
+                                                  const uint2* __restrict__ s_lut) {
+    constexpr int lo = dens_kt_lo(M), hi = dens_kt_hi(M), nk = hi - lo + 1;
+    const int n = lane & 31, h = lane >> 5, plane = n & 1;
+    const int board = first_board + (n >> 1);
+    const bool live = board < n_boards;
+    uint32_t own[nk], both[nk];                     // rows 2 (lo + k), 2 (lo + k) + 1
+    {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(planes + static_cast<size_t>(live ? board : first_board) * 32);
+#pragma unroll
+        for (int k = 0; k < nk; ++k) {
+            own[k] = p[plane * 8 + lo + k];
+            both[k] = own[k] | p[(1 - plane) * 8 + lo + k];
+            if (!live) own[k] = both[k] = 0u;
+        }
+    }
+    // occupied cells 32 M .. 32 M + 31 of this lane's board
+    uint32_t occ = 0;
+    {
+        constexpr int y0 = (32 * M) / 15, y1 = (32 * M + 31) / 15;
+#pragma unroll
+        for (int y = y0; y <= y1; ++y) {
+            const uint32_t r = ((y & 1) ? both[y / 2 - lo] >> 16 : both[y / 2 - lo]) & 0x7FFFu;
+            const int at = 15 * y - 32 * M;
+            occ |= at >= 0 ? r << at : r >> -at;
+        }
+    }
+    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < nk; ++k) {
+        const uint32_t r = (own[k] >> (16 * h)) & 0x7FFFu;
+        const uint2 b0 = s_lut[r & 255u], b1 = s_lut[r >> 8];
+        const v4i stones = {static_cast<int>(b0.x), static_cast<int>(b0.y), static_cast<int>(b1.x), static_cast<int>(b1.y)};
+        const v4i weights = a_tab[(KIND * kDensKindSteps + dens_tile_base(M) + k) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(stones, weights, acc, 0, 0, 0);
+    }
+    // accumulator i = board-colour column 8 (i / 4) + 4 h + (i % 4) at cell 32 M + n; columns 2 b, 2 b + 1 are board b
+    const int n_live = n_boards - first_board;      // >= 16 except in the last group
+    int32_t* out = out_density + static_cast<size_t>(first_board) * 4 * kCells + KIND * kCells + 32 * M + n + h * (2 * 4 * kCells);
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const int b = 4 * (i / 4) + (i % 4) / 2;    // + 2 h
+        const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(8 * b + 16 * h, static_cast<int>(occ)));
+        const int neg = __builtin_amdgcn_sbfe(static_cast<int>(w), n, 1);       // occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
+        if (b + 2 * h < n_live) {
+            out[b * 4 * kCells + 1 * 2 * kCells] = acc[i] ^ neg;                 // column 2 b: black, the second colour block
+            out[b * 4 * kCells + 0 * 2 * kCells] = acc[i + 1] ^ neg;             // column 2 b + 1: white, the first
+        }
+    }
+}
+
+__device__ __forceinline__ void density_pass(int pass, const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
+                                             const v4i* __restrict__ a_tab, int32_t* __restrict__ out_density, const uint2* __restrict__ s_lut) {
+    switch (pass) {                                 // wave-uniform
+#define GMK_PASS(K, M) case K * 7 + M: density_tile_pass<K, M>(planes, n_boards, first_board, lane, a_tab, out_density, s_lut); break;
+        GMK_PASS(0, 0) GMK_PASS(0, 1) GMK_PASS(0, 2) GMK_PASS(0, 3) GMK_PASS(0, 4) GMK_PASS(0, 5) GMK_PASS(0, 6)
+        GMK_PASS(1, 0) GMK_PASS(1, 1) GMK_PASS(1, 2) GMK_PASS(1, 3) GMK_PASS(1, 4) GMK_PASS(1, 5) GMK_PASS(1, 6)
+#undef GMK_PASS
+        default: break;
+    }
+}
+
 __global__ __launch_bounds__(kThreads)
-void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int iterations,
+void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int n_groups,
                            int32_t* __restrict__ out_scores, int32_t* __restrict__ out_density,
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
-                           int trans_words, int record_words,
-                           int phase_mask /* profiling aid: bit p runs phase p; 0x3F in production */) {
+                           int trans_words, int record_words, const v4i* __restrict__ dens_a,
+                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D; 0x7F in production */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [trans (LDS address 0)][records (16-byte aligned)][lane jobs 128][initial line words 96][boards: kBoardsPerBlock * kBoardWords]
     const uint4* s_rec = reinterpret_cast<const uint4*>(lds + trans_words);
@@ -147,35 +382,57 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     for (int i = threadIdx.x; i < record_words; i += kThreads) lds[trans_words + i] = g_records[i];
     if (threadIdx.x < 128) s_jobs[threadIdx.x] = c_lane_jobs[threadIdx.x];
     if (threadIdx.x < kLineWords) s_jobs[128 + threadIdx.x] = c_line_init[threadIdx.x];
+    uint2* s_lut = reinterpret_cast<uint2*>(s_jobs + 128 + kLineWords);      // byte -> its eight bits as bytes (the stone operands of phase D)
+    if (threadIdx.x < 256) s_lut[threadIdx.x] = make_uint2(((threadIdx.x & 15u) * 0x204081u) & 0x01010101u, ((threadIdx.x >> 4) * 0x204081u) & 0x01010101u);
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* s_nib = lds + trans_words + record_words + kStaticTableWords + wave * kBoardWords;
-    uint32_t* s_scores = s_nib + kNibWords;                  // int32 scores, accumulated with ds_add
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+    uint32_t* s_scores = lds + trans_words + record_words + kStaticTableWords + wave * kBoardWords;      // int32 scores, accumulated with ds_add
     uint32_t* s_cnt = s_scores + kScoreWords;
-    uint32_t* s_lines = s_nib + kZeroWords;
+    uint32_t* s_lines = s_scores + kZeroWords;
     uint32_t* s_queue = s_lines + kLineWords;
     uint32_t* s_misc = s_queue + kQueueCap;
 
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
-    const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
     const int scan_steps = c_scan_steps;
     const char* lds_bytes = reinterpret_cast<const char*>(lds);           // the transition table starts at LDS address 0
-    const uint32_t lane_tag = static_cast<uint32_t>(lane) << 10;
 
-    // the next board's 64 B are fetched while the current board is evaluated (one dependent HBM round trip per board otherwise)
+    // groups of sixteen boards: consecutive groups go to different workgroups first (small batches still use every CU)
+    for (int group = blockIdx.x + gridDim.x * wave; group < n_groups; group += gridDim.x * kBoardsPerBlock) {
+    const int first_board = group * kGroupBoards;
+    uint32_t gate1[4] = {0, 0, 0, 0}, gate2[4] = {0, 0, 0, 0};
+    if (phase_mask & 64) density_gates(planes, n_boards, first_board, lane0, dens_a, out_density, reinterpret_cast<v4i*>(s_scores), gate1, gate2);
+    const bool planes_out = out_density != nullptr && (phase_mask & 64);
+
+    // Everything the board phases derive from the lane number is derived from THIS copy, which the compiler cannot see through:
+    // those ~45 registers of per-lane constants are then computed after phase D (once per sixteen boards) instead of
+    // living through it, where they would spill.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
+    const uint32_t lane_tag = static_cast<uint32_t>(lane) << 10;
+    // a board's 64 B are fetched while the board before it is evaluated (they were read by phase D: an L2 hit)
     auto fetch_row = [&](int b) -> uint32_t {
         if (lane >= 16 || b >= n_boards) return 0u;
         return static_cast<uint32_t>(planes[static_cast<size_t>(b) * 32 + lane]) | (static_cast<uint32_t>(planes[static_cast<size_t>(b) * 32 + 16 + lane]) << 16);
     };
-    uint32_t next_row = fetch_row(blockIdx.x * kBoardsPerBlock + wave);
+    uint32_t next_row = fetch_row(first_board);
 
-    for (int it = 0; it < iterations; ++it) {
-        const int board = (it * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave;
+#pragma unroll 1
+    for (int bi = 0; bi < kGroupBoards; ++bi) {
+        const int board = first_board + bi;
         const bool live = board < n_boards;
+        if (!live) break;
 
-        // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words and digit rows ----
+        // ---- phase D, part 2: one of the fourteen density passes of the group per board ----
+        if (planes_out) {
+            int lane_p = lane0, first_p = first_board;         // opaque copies: what a pass derives from them is computed in the pass, not for all
+            asm volatile("" : "+v"(lane_p), "+s"(first_p));     // fourteen passes ahead of the loop (hundreds of registers)
+            density_pass(bi, planes, n_boards, first_p, lane_p, dens_a, out_density, s_lut);
+        }
+
+        // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words ----
         {
-            uint4* z = reinterpret_cast<uint4*>(s_nib) + lane;
+            uint4* z = reinterpret_cast<uint4*>(s_scores) + lane;
 #pragma unroll
             for (int i = 0; i < kZeroWords / 4; i += 64)
                 if (i + 64 <= kZeroWords / 4 || lane < kZeroWords / 4 - i) z[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -184,19 +441,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         if (lane < kLineWords - 64) s_lines[64 + lane] = s_line_init[64 + lane];
         if (lane < kMiscWords) s_misc[lane] = 0;
         const uint32_t my_row = next_row;
-        next_row = fetch_row(((it + 1) * gridDim.x + blockIdx.x) * kBoardsPerBlock + wave);
+        next_row = bi + 1 < kGroupBoards ? fetch_row(board + 1) : 0u;
         wave_phase_fence();
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {                      // the rows as 4-bit digits (phase 3's dot products)
-            const int i = lane + 64 * pass, y = i / 6, part = i - 6 * y;      // part = colour * 3 + word
-            const uint32_t roww = __shfl(my_row, min(y, 14));
-            const uint32_t half = part >= 3 ? roww >> 16 : roww & 0x7FFFu;
-            uint32_t v = ((half << 3) >> (8 * (part >= 3 ? part - 3 : part))) & 0xFFu;
-            v = (v | (v << 12)) & 0x000F000Fu;
-            v = (v | (v << 6)) & 0x03030303u;
-            v = (v | (v << 3)) & 0x11111111u;
-            if (i < 90) s_nib[18 + i] = v;
-        }
         if (lane < 15) atomicAdd(&s_misc[0], static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16));
         {
             // a stone turns its cell's blank (3) into black (0) or white (1) in the four lines through it: one XOR each.
@@ -271,81 +517,55 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         }
         wave_phase_fence();
 
-        // ---- phase 3: one lane per cell: density stencil, area bonus, compound candidates ----
+        // ---- phase 3: one lane per cell: area bonus, compound candidates ----
+        // The density planes themselves left in phase D; here only its gates matter: bit (cell) of gate1 / gate2 of the
+        // board's black column (lane 2 bi of phase D) and white column (lane 2 bi + 1), one ds_bpermute each.
         int n_cand = 0;                                         // wave-uniform
-        if (phase_mask & 8)
-        for (int q0 = 0; q0 < kCells; q0 += 64) {
-            const int q = min(q0 + lane, kCells - 1);           // the last pass has 33 cells; spare lanes redo cell 224 harmlessly
-            const bool spare = q0 + lane >= kCells;
-            const int x = q % 15, y = q / 15;
-            // rows y-3 .. y+3 as 4-bit digits: the 7 digits around column x start at digit x of the padded row, i.e. at bit
-            // 4 * (x & 7) of word x >> 3; v_alignbit takes them out of two words.  Rows y-k and y+k have the same weights
-            // (Pattern.cpp:601-607), so their digits are added first (<= 2, no carry); v_dot8_u32_u4 multiplies the
-            // digits with the row's weights (the eighth digit gets weight 0) and accumulates.
-            uint32_t nib_at = y * 6 + (x >> 3);
-            asm volatile("" : "+v"(nib_at));                    // one base register, the 28 reads use immediate offsets
-            const uint32_t* nib = s_nib + nib_at;
-            const uint32_t sh = (x & 7) * 4;
-            uint32_t cnt_c[2], wgt_c[2];                        // [0] white, [1] black (Evaluator::Group, Pattern.h:154-156)
-            uint32_t centre = 0;
+        if (phase_mask & 8) {
+            const int src_black = ((lane & 32) | (2 * bi)) * 4, src_white = src_black + 4;
+            const uint32_t sh = lane & 31;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                uint32_t w[7];
-#pragma unroll
-                for (int k = 0; k < 7; ++k) w[k] = __builtin_amdgcn_alignbit(nib[k * 6 + c * 3 + 1], nib[k * 6 + c * 3], sh);
-                const uint32_t p3 = w[0] + w[6], p2 = w[1] + w[5], p1 = w[2] + w[4], p0 = w[3];
-                uint32_t wg = __builtin_amdgcn_udot8(p3, 0x2001002u, 0u, false);
-                wg = __builtin_amdgcn_udot8(p2, 0x0433340u, wg, false);
-                wg = __builtin_amdgcn_udot8(p1, 0x0354530u, wg, false);
-                wg = __builtin_amdgcn_udot8(p0, 0x1340431u, wg, false);
-                uint32_t cn = __builtin_amdgcn_udot8(p3, 0x1001001u, 0u, false);
-                cn = __builtin_amdgcn_udot8(p2 + p1, 0x0111110u, cn, false);
-                cn = __builtin_amdgcn_udot8(p0, 0x1110111u, cn, false);
-                wgt_c[1 - c] = wg;
-                cnt_c[1 - c] = cn;
-                centre |= p0;
-            }
-            const bool occupied = (centre & 0x1000u) != 0;
-            if (!occupied && !spare) {
-                if (wgt_c[0] > 0) atomicAdd(&s_scores[0 * kCells + q], 160u);           // Pattern.cpp:268
-                if (wgt_c[1] > 0) atomicAdd(&s_scores[3 * kCells + q], 160u);
-            }
-            if (live && out_density && !spare) {
-                int32_t* d = out_density + static_cast<size_t>(board) * 4 * kCells + q;
-                const uint32_t neg = occupied ? ~0u : 0u;       // occupied cells hold -v - 1 (Pattern.cpp:253-265)
-                d[0 * kCells] = static_cast<int32_t>(cnt_c[0] ^ neg);
-                d[1 * kCells] = static_cast<int32_t>(wgt_c[0] ^ neg);
-                d[2 * kCells] = static_cast<int32_t>(cnt_c[1] ^ neg);
-                d[3 * kCells] = static_cast<int32_t>(wgt_c[1] ^ neg);
-            }
-            // compound candidates (Compound::Test, Pattern.cpp:424-433, and the density gate, Pattern.cpp:182): cells whose
-            // LiveThree / DeadThree / LiveTwo '_' counters, each clipped to 2 (the reference's 2-bit shift flags), OR-ed over the
-            // types, sum to two or more over the directions; decided in phase 3b
-            uint32_t cand = 0;
-            if (!occupied && !spare) {
-                const uint32_t any = s_cnt[q] | s_cnt[kCells + q] | s_cnt[2 * kCells + q];
+            for (int pass = 0; pass < 4; ++pass) {
+                const int q = 64 * pass + lane;                 // the last pass has 33 cells: the gates of the cells beyond are zero
+                const uint32_t g1b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate1[pass]))) >> sh) & 1u;
+                const uint32_t g1w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate1[pass]))) >> sh) & 1u;
+                const uint32_t g2b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate2[pass]))) >> sh) & 1u;
+                const uint32_t g2w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate2[pass]))) >> sh) & 1u;
+                // +160 in the own view where the colour's weight is positive (Pattern.cpp:268); adding zero elsewhere is harmless
+                atomicAdd(&s_scores[0 * kCells + q], g1w * 160u);
+                atomicAdd(&s_scores[3 * kCells + q], g1b * 160u);
+                // compound candidates (Compound::Test, Pattern.cpp:424-433, and the density gate, Pattern.cpp:182): empty cells whose
+                // LiveThree / DeadThree / LiveTwo '_' counters, each clipped to 2 (the reference's 2-bit shift flags), OR-ed over the
+                // types, sum to two or more over the directions; decided in phase 3b
+                const int qc = min(q, kCells - 1);
+                const uint32_t any = s_cnt[qc] | s_cnt[kCells + qc] | s_cnt[2 * kCells + qc];
                 const uint32_t upper = (any >> 1) | (any >> 2) | (any >> 3);
                 const uint32_t ge2 = upper & 0x11111111u, ge1 = (any | upper) & 0x11111111u;         // one bit per field with count >= 2 / >= 1
-                if (__popc(ge1 & 0xFFFFu) + __popc(ge2 & 0xFFFFu) >= 2 && cnt_c[0] >= 2) cand |= 1u;
-                if (__popc(ge1 >> 16) + __popc(ge2 >> 16) >= 2 && cnt_c[1] >= 2) cand |= 2u;
-            }
-            const unsigned long long pushers = __ballot(cand != 0u);
-            if (pushers) {
-                if (cand) {
-                    const int slot = n_cand + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pushers >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pushers), 0u)));
-                    if (slot < kQueueCap / 2) s_queue[slot] = static_cast<uint32_t>(q) | (cand << 8);
+                uint32_t cand = 0;
+                if (__popc(ge1 & 0xFFFFu) + __popc(ge2 & 0xFFFFu) >= 2 && g2w) cand |= 1u;
+                if (__popc(ge1 >> 16) + __popc(ge2 >> 16) >= 2 && g2b) cand |= 2u;
+                const unsigned long long pushers = __ballot(cand != 0u);
+                if (pushers) {
+                    if (cand) {
+                        const int slot = n_cand + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pushers >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pushers), 0u)));
+                        if (slot < kQueueCap / 2) s_queue[slot] = static_cast<uint32_t>(q) | (cand << 8);
+                    }
+                    n_cand += __popcll(pushers);
                 }
-                n_cand += __popcll(pushers);
             }
         }
         wave_phase_fence();
 
-        // ---- phase 3b: one lane per candidate cell: compound state machine (Pattern.cpp:440-486), critical-point deposits,
+        // (phases 3b, 4 and 5 derive their per-lane constants from a copy made here, per board: they are used once per board at most,
+        // and kept across the density pass above they would spill)
+        int lane_b = lane;
+        asm volatile("" : "+v"(lane_b));
+        // ---- phase 3b: one lane_b per candidate cell: compound state machine (Pattern.cpp:440-486), critical-point deposits,
         //      counter-move rescans queued in the upper half of the queue ----
         if (n_cand > kQueueCap / 2) { s_misc[2] = 1; n_cand = kQueueCap / 2; }
         if (phase_mask & 8)
-        for (int m = lane; m < n_cand; m += 64) {
+        for (int m = lane_b; m < n_cand; m += 64) {
             const uint32_t ce = s_queue[m];
             const int q = ce & 255;
             const uint32_t cw_l3 = s_cnt[q], cw_d3 = s_cnt[kCells + q], cw_l2 = s_cnt[2 * kCells + q];
@@ -388,13 +608,13 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
 
         // ---- phase 4: the counter-move cells of every compound component: the FIRST match of its type that runs through
         //      the cell with a blank there (Compound::updateAntis, Pattern.cpp:520-543), scanning the 13-symbol window
-        //      centred on the cell.  Such a match ends at window index 6..12; eight lanes share a component, lane kk looks
+        //      centred on the cell.  Such a match ends at window index 6..12; eight lanes share a component, lane_b kk looks
         //      at the transition at index 6 + kk only (the automaton forgets its start state after 7 symbols, so <= 8
-        //      lookups from the root bring it to the right state), and the lowest lane with a hit applies it ----
+        //      lookups from the root bring it to the right state), and the lowest lane_b with a hit applies it ----
         if (phase_mask & 16) {
             const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap / 2);
             for (int m0 = 0; m0 < n_comp; m0 += 8) {
-                const int m = m0 + (lane >> 3), kk = lane & 7, k = 6 + kk;
+                const int m = m0 + (lane_b >> 3), kk = lane_b & 7, k = 6 + kk;
                 const uint32_t ent = m < n_comp ? s_queue[kQueueCap / 2 + m] : 0u;
                 const int q = ent & 255, c = (ent >> 8) & 1, dir = (ent >> 9) & 3, tslot = (ent >> 11) & 3;
                 const int want = tslot == 0 ? 5 : tslot == 1 ? 4 : 3;
@@ -424,7 +644,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     }
                 }
                 const unsigned long long hits = __ballot(hit_back >= 0);
-                const uint32_t mine = static_cast<uint32_t>(hits >> (lane & ~7)) & 0xFFu;
+                const uint32_t mine = static_cast<uint32_t>(hits >> (lane_b & ~7)) & 0xFFu;
                 if (hit_back >= 0 && (mine & ((1u << kk) - 1u)) == 0u) add_counter_cells(hit_w0, hit_back, q, stride, s_scores + (c ? 2 : 1) * kCells);
             }
         }
@@ -435,10 +655,10 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             if (out_scores) {
                 int4* dst = reinterpret_cast<int4*>(out_scores + static_cast<size_t>(board) * kScoreWords);
                 const int4* src = reinterpret_cast<const int4*>(s_scores);
-                for (int i = lane; i < kScoreWords / 4; i += 64) dst[i] = src[i];
+                for (int i = lane_b; i < kScoreWords / 4; i += 64) dst[i] = src[i];
             }
-            if (out_totals && lane < 11) out_totals[static_cast<size_t>(board) * 11 + lane] = s_misc[4 + lane];
-            if (out_status && lane == 0) {
+            if (out_totals && lane_b < 11) out_totals[static_cast<size_t>(board) * 11 + lane_b] = s_misc[4 + lane_b];
+            if (out_status && lane_b == 0) {
                 const uint32_t wbits = s_misc[1], stones = s_misc[0];
                 const int stones_b = stones & 0xFFFFu, stones_w = stones >> 16;
                 // the side that completed five is the only one that can own a Five (the game stops there)
@@ -449,6 +669,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             }
         }
         wave_phase_fence();
+    }
     }
 }
 
@@ -485,19 +706,47 @@ int upload_lane_jobs() {
     return GMK_OK;
 }
 
-struct Launch { int grid, iterations; size_t lds; };
+// The weight operands of phase D in lane order: step s (plane kind count / weight, M tile m, K tile kt),
+// lane l = (cell 32 m + (l & 31), k half h = l >> 5), byte j = the tap from cell (row 2 kt + h, column j) to that cell.
+int upload_density_operands(int8_t** d_out) {
+    std::vector<int8_t> a(static_cast<size_t>(kDensSteps) * 64 * 16, 0);
+    int step = 0;
+    for (int kind = 0; kind < 2; ++kind)
+        for (int m = 0; m < kDensTiles; ++m)
+            for (int kt = dens_kt_lo(m); kt <= dens_kt_hi(m); ++kt, ++step)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 16; ++j) {
+                        const int cell = 32 * m + (l & 31), yo = cell / 15, xo = cell % 15, y = 2 * kt + (l >> 5), x = j;
+                        const int dy = y - yo, dx = x - xo;
+                        if (y > 14 || x > 14 || std::abs(dy) > 3 || std::abs(dx) > 3) continue;
+                        const int w = block_weight(dy, dx);
+                        a[(static_cast<size_t>(step) * 64 + l) * 16 + j] = static_cast<int8_t>(kind == 0 ? (w != 0) : w);
+                    }
+    if (step != kDensSteps) { gmk::set_error("density operand table: %d steps, expected %d", step, kDensSteps); return GMK_ERR_STATE; }
+    // every tap of every cell must lie in one of the K tiles its M tile visits
+    for (int cell = 0; cell < 224; ++cell)
+        for (int dy = -3; dy <= 3; ++dy) {
+            const int y = cell / 15 + dy, m = cell / 32;
+            if (y < 0 || y > 14) continue;
+            if (y / 2 < dens_kt_lo(m) || y / 2 > dens_kt_hi(m)) { gmk::set_error("density operand table: row %d of cell %d is not covered", y, cell); return GMK_ERR_STATE; }
+        }
+    GMK_HIP_CHECK(hipMalloc(d_out, a.size()));
+    GMK_HIP_CHECK(hipMemcpy(*d_out, a.data(), a.size(), hipMemcpyHostToDevice));
+    return GMK_OK;
+}
+
+struct Launch { int grid, n_groups; size_t lds; };
 
 Launch plan_launch(int n, const gmk::DeviceState& st) {
-    const int tiles = (n + kBoardsPerBlock - 1) / kBoardsPerBlock;
-    const int max_grid = std::max(1, st.cu_count * kMaxBlocksPerCu);
     Launch l;
-    l.iterations = std::max(1, (tiles + max_grid - 1) / max_grid);
-    l.grid = std::max(1, (tiles + l.iterations - 1) / l.iterations);
+    l.n_groups = (n + kGroupBoards - 1) / kGroupBoards;
+    l.grid = std::max(1, std::min(l.n_groups, st.cu_count * kMaxBlocksPerCu));
     l.lds = static_cast<size_t>(kBoardsPerBlock * kBoardWords + st.n_states * 4 + st.n_records * 4 + kStaticTableWords) * 4;
     return l;
 }
 
 bool g_jobs_uploaded = false;
+int8_t* g_dens_a = nullptr;
 
 }  // namespace
 
@@ -508,17 +757,19 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
     if (n < 0 || (n > 0 && !d_planes)) { gmk::set_error("gmk_eval_batch: bad arguments"); return GMK_ERR_ARG; }
     if (n == 0) return GMK_OK;
     if (!g_jobs_uploaded) {
-        const int rc = upload_lane_jobs();
+        int rc = upload_lane_jobs();
+        if (rc != GMK_OK) return rc;
+        rc = upload_density_operands(&g_dens_a);
         if (rc != GMK_OK) return rc;
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_positions_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_jobs_uploaded = true;
     }
     const Launch l = plan_launch(n, st);
     if (l.lds > 160u * 1024u) { gmk::set_error("gmk_eval_batch: tables do not fit in LDS (%zu bytes)", l.lds); return GMK_ERR_CAPACITY; }
-    static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x3F;
+    static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x7F;
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
-                       d_planes, n, l.iterations, d_scores, d_density, d_totals, d_status,
-                       st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, phase_mask);
+                       d_planes, n, l.n_groups, d_scores, d_density, d_totals, d_status,
+                       st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, reinterpret_cast<const v4i*>(g_dens_a), phase_mask);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }

@@ -66,10 +66,11 @@ struct SearchParams {
     int playouts;
     int rollout_stride_log2;
     int profile;                    // GMK_MCTS_PROFILE=1: per-phase shader-clock sums into GameHeader::pad (diagnostic runs only)
+    const float* value_table;       // float(double(sum) / double(c_rollouts)) at index sum + c_rollouts (Random.h:30-33): owned by the HANDLE, since
+                                    // handles with different c_rollouts run side by side (supervisor against candidate)
 };
 
 __constant__ float c_prior[226];          // 1.0f / float(n) evaluated on the host (MonteCarlo.hpp:50-55)
-__constant__ float c_value[129];          // float(double(sum) / double(c_rollouts)), index sum + c_rollouts (Random.h:30-33)
 
 // Quarter-wave (one DPP row of 16 lanes) primitives for the select / expand phases: DPP moves cost an ALU cycle each where
 // a ds_bpermute shuffle is a ~100-cycle LDS round trip, and this kernel runs one wave per SIMD with nothing to hide it.
@@ -258,7 +259,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                 float value;
                 unsigned long long bytes = 0;
                 if (s_need[gs]) {
-                    const float state_value = c_value[s_sum[gs] + R];
+                    const float state_value = prm.value_table[s_sum[gs] + R];
                     value = -state_value;                            // MCTS.cpp:169
                     const uint32_t rw = s_leaf[gs][l16];
                     const uint32_t open = (l16 < 15) ? (~(rw | (rw >> 16)) & 0x7FFFu) : 0u;
@@ -504,6 +505,7 @@ struct gmk_mcts {
     uint32_t* d_link2 = nullptr;
     uint32_t* d_parent2 = nullptr;
     float* d_root_prior = nullptr;     // [n_games][225] by child index, used while GameHeader::noise is set
+    float* d_value = nullptr;          // [2 * c_rollouts + 1] rollout sum -> state value
     void* d_step_scratch = nullptr;    // record outputs of gmk_mcts_step_host
     hipStream_t last_stream = nullptr;
     bool rooted = false;               // gmk_mcts_set_roots has run: headers and arenas hold trees
@@ -534,20 +536,28 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
         gmk_mcts_destroy(m);
         return GMK_ERR_HIP;
     }
-    float prior[226];
-    prior[0] = 0.0f;
-    for (int i = 1; i <= 225; ++i) prior[i] = 1.0f / static_cast<float>(i);
+    static bool prior_uploaded = false;            // the same for every handle: written once, never while a search may be reading it
+    if (!prior_uploaded) {
+        float prior[226];
+        prior[0] = 0.0f;
+        for (int i = 1; i <= 225; ++i) prior[i] = 1.0f / static_cast<float>(i);
+        GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_prior), prior, sizeof prior));
+        prior_uploaded = true;
+    }
     float value[129] = {};
     for (int s = -c_rollouts; s <= c_rollouts; ++s) value[s + c_rollouts] = static_cast<float>(static_cast<double>(s) / static_cast<double>(c_rollouts));
-    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_prior), prior, sizeof prior));
-    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_value), value, sizeof value));
+    if (hipMalloc(&m->d_value, sizeof value) != hipSuccess || hipMemcpy(m->d_value, value, sizeof value, hipMemcpyHostToDevice) != hipSuccess) {
+        gmk::set_error("gmk_mcts_create: value table upload failed");
+        gmk_mcts_destroy(m);
+        return GMK_ERR_HIP;
+    }
     *out = m;
     return GMK_OK;
 }
 
 extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     if (!m) return GMK_OK;
-    (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent);
+    (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent); (void)hipFree(m->d_value);
     (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2); (void)hipFree(m->d_root_prior); (void)hipFree(m->d_step_scratch);
     delete m;
     return GMK_OK;
@@ -579,6 +589,17 @@ extern "C" int gmk_mcts_set_roots(gmk_mcts* m, const uint16_t* h_planes, const i
     return GMK_OK;
 }
 
+extern "C" int gmk_mcts_set_game_ids(gmk_mcts* m, const uint32_t* h_ids) {
+    if (!m || !h_ids) { gmk::set_error("gmk_mcts_set_game_ids: bad arguments"); return GMK_ERR_ARG; }
+    if (!m->rooted) { gmk::set_error("gmk_mcts_set_game_ids: gmk_mcts_set_roots has not been called"); return GMK_ERR_STATE; }
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<GameHeader> hdr(static_cast<size_t>(m->n_games));
+    GMK_HIP_CHECK(hipMemcpy(hdr.data(), m->d_headers, hdr.size() * sizeof(GameHeader), hipMemcpyDeviceToHost));
+    for (int g = 0; g < m->n_games; ++g) hdr[static_cast<size_t>(g)].game_id = h_ids[g];
+    GMK_HIP_CHECK(hipMemcpy(m->d_headers, hdr.data(), hdr.size() * sizeof(GameHeader), hipMemcpyHostToDevice));
+    return GMK_OK;
+}
+
 extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     if (m && !m->rooted) { gmk::set_error("gmk_mcts_run: gmk_mcts_set_roots has not been called"); return GMK_ERR_STATE; }
     if (!m || playouts < 0) { gmk::set_error("gmk_mcts_run: bad arguments"); return GMK_ERR_ARG; }
@@ -592,6 +613,7 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     while ((1 << stride_log2) < m->games_per_block * m->c_rollouts) ++stride_log2;
     prm.rollout_stride_log2 = stride_log2;
     prm.profile = std::getenv("GMK_MCTS_PROFILE") ? 1 : 0;
+    prm.value_table = m->d_value;
     m->last_stream = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), (static_cast<size_t>(kLineWords) << stride_log2) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
                        m->d_root_prior, prm);
@@ -617,6 +639,9 @@ extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t
         const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
         if (hipMalloc(&m->d_stats2, nodes * sizeof(uint2)) != hipSuccess || hipMalloc(&m->d_link2, nodes * 4) != hipSuccess ||
             hipMalloc(&m->d_parent2, nodes * 4) != hipSuccess) {
+            (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2);      // all or nothing: the guard above tests d_stats2
+            m->d_stats2 = nullptr; m->d_link2 = nullptr; m->d_parent2 = nullptr;
+            (void)hipGetLastError();
             gmk::set_error("gmk_mcts_step: hipMalloc of the second arena (%zu nodes) failed", nodes);
             return GMK_ERR_HIP;
         }

@@ -40,6 +40,7 @@ struct RaveParams {
     const int32_t* lens;
     int n_games, cap, playouts;
     uint32_t seed_lo, seed_hi, first_game_id;
+    const uint32_t* game_ids;                    // [n_games] the game a slot is playing, relative to first_game_id (gmk_trad_set_game_ids)
     double c_puct;
     int profile;                                 // GMK_RAVE_PROFILE: shader clocks per stage into TradHeader::prof (diagnostic runs only)
 };
@@ -203,7 +204,7 @@ void rave_playouts_kernel(RaveParams prm) {
                     rollout = true;
                     // the rollout's random cells, one Philox block per lane: off the serial chain of the game itself
                     if (lane * 8 < 225 - ply)
-                        s_cells[wave][lane] = rollout_cells(prm.first_game_id + static_cast<uint32_t>(game), playout0 + static_cast<uint32_t>(it),
+                        s_cells[wave][lane] = rollout_cells(prm.first_game_id + prm.game_ids[game], playout0 + static_cast<uint32_t>(it),
                                                             static_cast<uint32_t>(init) << 8, static_cast<uint32_t>(lane), prm.seed_lo, prm.seed_hi);
                 }
             }
@@ -347,7 +348,7 @@ extern "C" int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, u
     prm.a = t->arena();
     prm.hdr = t->d_hdr; prm.moves = t->d_moves; prm.lens = t->d_lens;
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts;
-    prm.seed_lo = static_cast<uint32_t>(seed); prm.seed_hi = static_cast<uint32_t>(seed >> 32); prm.first_game_id = first_game_id;
+    prm.seed_lo = static_cast<uint32_t>(seed); prm.seed_hi = static_cast<uint32_t>(seed >> 32); prm.first_game_id = first_game_id; prm.game_ids = t->d_game_ids;
     prm.c_puct = c_puct;
     static const bool profile = std::getenv("GMK_RAVE_PROFILE") != nullptr;
     prm.profile = profile ? 1 : 0;

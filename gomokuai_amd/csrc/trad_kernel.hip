@@ -674,7 +674,7 @@ extern "C" int gmk_trad_destroy(gmk_trad* t) {
     if (!t) return GMK_OK;
     (void)hipFree(t->d_states); (void)hipFree(t->d_stat); (void)hipFree(t->d_info); (void)hipFree(t->d_link);
     (void)hipFree(t->d_front); (void)hipFree(t->d_ord); (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_front2);
-    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_amaf); (void)hipFree(t->d_amaf2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens);
+    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_amaf); (void)hipFree(t->d_amaf2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens); (void)hipFree(t->d_game_ids);
     delete t;
     return GMK_OK;
 }
@@ -700,10 +700,24 @@ extern "C" int gmk_trad_create(int n_games, int node_capacity, gmk_trad** out) {
               hipMalloc(&t->d_link, nodes * 4) == hipSuccess && hipMalloc(&t->d_front, nodes * 8) == hipSuccess && hipMalloc(&t->d_ord, nodes) == hipSuccess &&
               hipMalloc(&t->d_hdr, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess &&
               hipMalloc(&t->d_moves, static_cast<size_t>(n_games) * 225) == hipSuccess &&
-              hipMalloc(&t->d_lens, static_cast<size_t>(n_games) * 4) == hipSuccess;
+              hipMalloc(&t->d_lens, static_cast<size_t>(n_games) * 4) == hipSuccess &&
+              hipMalloc(&t->d_game_ids, static_cast<size_t>(n_games) * 4) == hipSuccess;
     if (ok) ok = hipMemset(t->d_hdr, 0, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess;
+    if (ok) {
+        t->game_ids.resize(static_cast<size_t>(n_games));
+        for (int g = 0; g < n_games; ++g) t->game_ids[static_cast<size_t>(g)] = static_cast<uint32_t>(g);
+        ok = hipMemcpy(t->d_game_ids, t->game_ids.data(), static_cast<size_t>(n_games) * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok || gmk_trad_reset_evaluators(t) != GMK_OK) { gmk_trad_destroy(t); gmk::set_error("gmk_trad_create: device allocation failed"); return GMK_ERR_HIP; }
     *out = t;
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_set_game_ids(gmk_trad* t, const uint32_t* h_ids) {
+    if (!t || !h_ids) { gmk::set_error("gmk_trad_set_game_ids: bad arguments"); return GMK_ERR_ARG; }
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    t->game_ids.assign(h_ids, h_ids + t->n_games);
+    GMK_HIP_CHECK(hipMemcpy(t->d_game_ids, h_ids, static_cast<size_t>(t->n_games) * 4, hipMemcpyHostToDevice));
     return GMK_OK;
 }
 
@@ -784,11 +798,18 @@ extern "C" int gmk_trad_step(gmk_trad* t, const int16_t* h_moves) {
     if (!t) { gmk::set_error("gmk_trad_step: bad arguments"); return GMK_ERR_ARG; }
     if (!t->positioned) { gmk::set_error("gmk_trad_step: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(t->n_games), nodes = n * static_cast<size_t>(t->cap);
-    if (!t->d_stat2) {
+    if (!t->second_arena) {
         const bool ok = hipMalloc(&t->d_stat2, nodes * 8) == hipSuccess && hipMalloc(&t->d_info2, nodes * 8) == hipSuccess &&
                         hipMalloc(&t->d_link2, nodes * 4) == hipSuccess && hipMalloc(&t->d_front2, nodes * 8) == hipSuccess &&
                         hipMalloc(&t->d_ord2, nodes) == hipSuccess && hipMalloc(&t->d_forced, n * 2) == hipSuccess;
-        if (!ok) { gmk::set_error("gmk_trad_step: hipMalloc of the second arena (%zu nodes) failed", nodes); return GMK_ERR_HIP; }
+        if (!ok) {                                                  // all or nothing: a later call must not find half an arena
+            (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_link2); (void)hipFree(t->d_front2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_forced);
+            t->d_stat2 = t->d_info2 = t->d_front2 = nullptr; t->d_link2 = nullptr; t->d_ord2 = nullptr; t->d_forced = nullptr;
+            (void)hipGetLastError();
+            gmk::set_error("gmk_trad_step: hipMalloc of the second arena (%zu nodes) failed", nodes);
+            return GMK_ERR_HIP;
+        }
+        t->second_arena = true;
     }
     GMK_HIP_CHECK(hipDeviceSynchronize());
     if (h_moves) GMK_HIP_CHECK(hipMemcpy(t->d_forced, h_moves, n * 2, hipMemcpyHostToDevice));
@@ -817,7 +838,7 @@ extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, 
         float* p = &priors[g * 225];
         bool any = false;
         for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
-        if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + static_cast<uint32_t>(g), static_cast<uint32_t>(lens[g])));
+        if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + t->game_ids[g], static_cast<uint32_t>(lens[g])));
     });
     if (!t->d_priors) GMK_HIP_CHECK(hipMalloc(&t->d_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(t->d_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));

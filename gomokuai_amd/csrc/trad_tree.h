@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 namespace gmk {
 namespace tree {
@@ -78,7 +79,9 @@ struct gmk_trad {
     gmk::tree::TradHeader* d_hdr = nullptr;
     uint8_t* d_moves = nullptr;
     int32_t* d_lens = nullptr;
-    bool attr_set = false, positioned = false;
+    std::vector<uint32_t> game_ids;                                         // the game a slot is playing, relative to the callers' first_game_id (default: the slot number)
+    uint32_t* d_game_ids = nullptr;
+    bool attr_set = false, positioned = false, second_arena = false;
     int policy = 0;                                                          // 0 not searched yet, 1 TraditionalPolicy (gmk_trad_run), 2 PoolRAVEPolicy (gmk_trad_run_poolrave): one per handle
 
     gmk::tree::TradArena arena() const { return {d_stat, d_info, d_link, d_front, d_ord, d_amaf}; }

@@ -28,11 +28,11 @@ EXPORTS = [
     "gmk_tables_info", "gmk_tables_pattern", "gmk_tables_copy", "gmk_tables_copy_dat", "gmk_tables_scan",
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
-    "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_run", "gmk_mcts_root_stats",
+    "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_set_game_ids", "gmk_mcts_run", "gmk_mcts_root_stats",
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
-    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_add_root_noise", "gmk_az_root_stats",
-    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
+    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_root_stats",
+    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
 ]
 
 
@@ -76,6 +76,9 @@ def load():
     L.gmk_mcts_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.POINTER(vp)]
     L.gmk_mcts_destroy.argtypes = [vp]
     L.gmk_mcts_set_roots.argtypes = [vp, vp, vp, C.c_uint32]
+    L.gmk_mcts_set_game_ids.argtypes = [vp, vp]
+    L.gmk_trad_set_game_ids.argtypes = [vp, vp]
+    L.gmk_az_set_game_ids.argtypes = [vp, vp]
     L.gmk_mcts_run.argtypes = [vp, C.c_int, vp]
     L.gmk_mcts_root_stats.argtypes = [vp, vp, vp, vp, vp, vp]
     L.gmk_mcts_alg_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -252,6 +255,14 @@ class BatchedMCTS:
         assert planes.shape == (self.n, 2, 16) and last.shape == (self.n,)
         _check(load().gmk_mcts_set_roots(self.h, planes.ctypes.data, last.ctypes.data, first_game_id))
 
+    STATUS_TERMINAL, STATUS_ARENA_FULL, STATUS_ILLEGAL_STEP = 1, 2, 4      # bits of root_stats()[4]
+
+    def set_game_ids(self, ids):
+        """Global id of every game (uint32[n]) instead of first_game_id + g: the id keys the game's random streams."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert ids.shape == (self.n,)
+        _check(load().gmk_mcts_set_game_ids(self.h, ids.ctypes.data))
+
     def run(self, playouts, stream=None):
         _check(load().gmk_mcts_run(self.h, playouts, stream))
 
@@ -358,8 +369,17 @@ class TraditionalMCTS:
 
     __del__ = close
 
+    STATUS_ARENA_FULL, STATUS_EVALUATOR_ERROR, STATUS_BOARD_ONLY_REVERT, STATUS_ILLEGAL_STEP = 1, 2, 4, 8      # bits of root_stats()["status"]
+
     def reset_evaluators(self):
         _check(load().gmk_trad_reset_evaluators(self.h))
+
+    def set_game_ids(self, ids):
+        """The game each slot is playing, relative to the first_game_id of add_root_noise / PoolRAVEMCTS (uint32[n]; default: the
+        slot number): random streams belong to the game, not to the slot it runs in."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert ids.shape == (self.n,)
+        _check(load().gmk_trad_set_game_ids(self.h, ids.ctypes.data))
 
     def set_positions(self, move_lists, lens=None):
         """One move list per game, or (with lens) the arrays themselves: moves uint8[n, 225], lens int32[n]; a negative length
@@ -452,6 +472,14 @@ class AlphaZeroMCTS:
             self.h = None
 
     __del__ = close
+
+    STATUS_ARENA_FULL, STATUS_ILLEGAL_STEP = 2, 4      # bits of root_stats()["status"]
+
+    def set_game_ids(self, ids):
+        """The game each slot is playing, relative to add_root_noise's first_game_id (uint32[n]; default: the slot number)."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert ids.shape == (self.n,)
+        _check(load().gmk_az_set_game_ids(self.h, ids.ctypes.data))
 
     def set_roots(self, planes, last_moves):
         """planes uint16[n,2,16]; last_moves int16[n,2] = (last move, the one before), -1 where there is none."""

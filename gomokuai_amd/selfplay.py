@@ -115,7 +115,7 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
             break
     status = tree.root_stats()[4]
     tree.close()
-    return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, bool((status & 2).any()))
+    return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, bool((status & G.BatchedMCTS.STATUS_ARENA_FULL).any()))
 
 
 class _HostGames:
@@ -216,7 +216,7 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
             tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
         tree.run(playouts, stream)
         st = tree.root_stats()
-        overflow |= bool((st["status"] & 1).any())
+        overflow |= bool((st["status"] & G.TraditionalMCTS.STATUS_ARENA_FULL).any())
         played = np.where(games.over, -1, st["best"]).astype(np.int16)
         games.over |= played < 0                                 # no child: nothing the policy wants to play (cannot happen on a live board)
         at = games.lens.copy()
@@ -259,6 +259,7 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
         next_game += take
         if games.over[active].all():
             break
+        tree.set_game_ids(active)                                # root noise and rollout streams are the GAME's (first_game_id + its number), whatever slot it runs in
         if not reuse_subtree:
             tree.set_positions(games.moves[active], games.lens[active])
         elif fresh.any():                                        # the others keep the subtree gmk_trad_step left them
@@ -268,7 +269,7 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
             tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
         tree.run(playouts, stream)
         st = tree.root_stats()
-        overflow |= bool((st["status"] & 1).any())
+        overflow |= bool((st["status"] & G.TraditionalMCTS.STATUS_ARENA_FULL).any())
         best = np.where(games.over[active], -1, st["best"])
         games.over[active[(best < 0) & ~games.over[active]]] = True
         played = np.full(n_games, -1, dtype=np.int64)
@@ -315,6 +316,7 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
                 next_game += take
                 if games.over[active].all():
                     break
+                tree.set_game_ids(active)
                 sub_moves, sub_lens = games.moves[active], games.lens[active]
                 last = np.full((slots, 2), -1, dtype=np.int16)
                 rows = np.arange(slots)
@@ -323,7 +325,7 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
                 tree.set_roots(G.moves_to_planes(sub_moves, sub_lens), last)
                 tree.search(network, playouts)
                 st = tree.root_stats()
-                overflow |= bool((st["status"] & 1).any())
+                overflow |= bool((st["status"] & G.AlphaZeroMCTS.STATUS_ARENA_FULL).any())
                 visited = st["visits"].max(1) > 0
                 best = np.where(games.over[active] | ~visited, -1, st["visits"].argmax(1))
                 games.over[active[(best < 0) & ~games.over[active]]] = True
@@ -356,7 +358,7 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
                 tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
             tree.search(network, playouts)
             st = tree.root_stats()
-            overflow |= bool((st["status"] & 1).any())
+            overflow |= bool((st["status"] & G.AlphaZeroMCTS.STATUS_ARENA_FULL).any())
             visited = st["visits"].max(1) > 0                    # no child was visited: nothing to play (cannot happen on a live board)
             played = np.where(games.over | ~visited, -1, st["visits"].argmax(1)).astype(np.int16)      # max_element: the first maximum in child (= cell) order
             games.over |= played < 0
@@ -377,30 +379,34 @@ class _Searcher:
         kind, kw = spec
         self.kind, self.n, self.playouts = kind, n, int(kw.get("c_iterations", playouts))
         c_puct = float(kw.get("c_puct", 5.0))
+        self.first_game_id = first_game_id
         if kind == "traditional_mcts":                       # AGENT_MAP names of the reference (agents/__init__.py, config.py:9-19)
             self.tree = G.TraditionalMCTS(n, node_capacity=min(self.playouts * 226 + 256, (1 << 24) - 1), c_puct=c_puct)
         elif kind == "rave_mcts":
             self.tree = G.PoolRAVEMCTS(n, node_capacity=min(self.playouts * 226 + 256, (1 << 24) - 1), c_puct=c_puct, seed=seed, first_game_id=first_game_id)
         elif kind == "random_mcts":
             self.tree = G.BatchedMCTS(n, playouts_capacity=self.playouts, c_puct=c_puct, c_rollouts=int(kw.get("c_rollouts", 5)), seed=seed)
-            self.first_game_id = first_game_id
         else:
             raise ValueError("play_match_games: unknown agent '%s' (traditional_mcts, rave_mcts, random_mcts)" % kind)
 
-    def search(self, moves, lens, stream):
-        """Root visit counts [n, 225] and the move MCTS::stepForward() would make per game (-1: none), from fresh roots."""
+    def search(self, moves, lens, games, stream):
+        """Root visit counts [n, 225] and the move MCTS::stepForward() would make per game (-1: none), from fresh roots.
+        games int[n]: the number of the game in each slot; its random streams are keyed by first_game_id + that number."""
         if self.kind == "random_mcts":
             planes = G.moves_to_planes(moves, lens)
             last = np.where(lens > 0, moves[np.arange(self.n), np.maximum(lens, 1) - 1].astype(np.int16), np.int16(-1))
             self.tree.set_roots(planes, last, self.first_game_id)
+            self.tree.set_game_ids((self.first_game_id + np.asarray(games)).astype(np.uint32))
             self.tree.run(self.playouts, stream)
-            visits = self.tree.root_stats()[0]
+            stats = self.tree.root_stats()
+            visits = stats[0]
             best = np.where(visits.max(1) > 0, visits.argmax(1), -1).astype(np.int32)        # max_element: the first maximum in child (= cell) order
-            return visits, best, False
+            return visits, best, bool((stats[4] & G.BatchedMCTS.STATUS_ARENA_FULL).any())
+        self.tree.set_game_ids(np.asarray(games, dtype=np.uint32))
         self.tree.set_positions(moves, lens)
         self.tree.run(self.playouts, stream)
         st = self.tree.root_stats()
-        return st["visits"], st["best"], bool((st["status"] & 1).any())
+        return st["visits"], st["best"], bool((st["status"] & G.TraditionalMCTS.STATUS_ARENA_FULL).any())
 
     def close(self):
         self.tree.close()
@@ -413,8 +419,8 @@ def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAUL
     candidate = (name, kwargs) as in DATA_CONFIG["schedule"]: ("traditional_mcts" | "rave_mcts" | "random_mcts", {"c_puct": ..,
     "c_iterations": .., "c_rollouts": ..}).  All games run side by side on the current GPU: the games in which the supervisor
     has black and the games in which it has white form two groups, each with one batched searcher per agent (K6 / K8 / K3), so
-    that every ply is two searches (one per group) covering all unfinished games; roots are fresh at every move and the
-    candidates' random streams are numbered within their group.  slots: games in flight per group (default: all of them); a
+    that every ply is two searches (one per group) covering all unfinished games; roots are fresh at every move and every
+    game's random streams are keyed by its own global id first_game_id + g, whatever group and slot it runs in.  slots: games in flight per group (default: all of them); a
     finished game hands its slot to the next unstarted game of its group, which keeps the searches full (see play_supervisor_games).
     Returns (GameRecords, supervisor_is_black bool[n]); the records' visit counts at move i are those of the player who made it."""
     G.init(torch.cuda.current_device() if device is None else device.index)
@@ -433,8 +439,7 @@ def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAUL
         k = len(idx) if slots is None else min(int(slots), len(idx))
         active.append(idx[:k].copy())
         waiting.append(list(idx[k:]))
-        first = first_game_id + (int(idx[0]) if len(idx) else 0)
-        searchers.append([_Searcher(spec, k, playouts, seed, first) if k else None for spec in (supervisor, candidate)])
+        searchers.append([_Searcher(spec, k, playouts, seed, first_game_id) if k else None for spec in (supervisor, candidate)])
     overflow = False
     for _ in range((2 + (0 if slots is None else n_games // max(1, int(slots)))) * max_moves):
         if games.over.all():
@@ -454,7 +459,7 @@ def play_match_games(n_games, supervisor, candidate, playouts=400, seed=G.DEFAUL
                 sel = turn & ~games.over[act]
                 if not sel.any():
                     continue
-                v, best, full = searchers[gi][who].search(games.moves[act], games.lens[act], stream)
+                v, best, full = searchers[gi][who].search(games.moves[act], games.lens[act], act, stream)
                 overflow |= full
                 played = np.full(n_games, -1, dtype=np.int64)
                 played[act[sel]] = best[sel]
@@ -507,53 +512,78 @@ def dump_batches(samples, path, batch_size=512):
     return n_batches
 
 
+def pack_records(rec):
+    """The wire form of a rank's records, ONE uint8 tensor on the records' device: lens int32[n], winner int8[n],
+    then only what was played: moves uint8[sum(lens)] and, if visits were recorded, uint16[sum(lens)][225] (the root visit counts
+    of the searched plies; plies that were not searched -- openings -- carry their zero rows).  ~27 KB per game instead of the
+    fixed-stride 101 KB."""
+    lens = rec.lens.to(torch.int32).contiguous()
+    n = int(lens.shape[0])
+    if n == 0:
+        return torch.zeros(0, dtype=torch.uint8, device=lens.device)
+    played = torch.arange(N, device=lens.device)[None, :] < lens[:, None]            # [n, 225]
+    parts = [lens.view(torch.uint8).reshape(-1), rec.winner.to(torch.int8).contiguous().view(torch.uint8).reshape(-1),
+             rec.moves.contiguous().view(torch.uint8).reshape(n, N)[played]]
+    if rec.visits is not None:
+        parts.append(rec.visits.contiguous().view(torch.int16).reshape(n, N, N)[played].contiguous().view(torch.uint8).reshape(-1))
+    return torch.cat(parts)
+
+
+def unpack_records(buf, n, has_visits, first_game_id=0, overflow=False):
+    """pack_records undone: fixed-stride GameRecords on buf's device (what to_samples() / K4 + K5 read)."""
+    dev = buf.device
+    lens = buf[:4 * n].view(torch.int32).clone()
+    winner = buf[4 * n:5 * n].view(torch.int8).clone()
+    total = int(lens.sum()) if n else 0
+    played = torch.arange(N, device=dev)[None, :] < lens[:, None]
+    moves = torch.zeros((n, N), dtype=torch.uint8, device=dev)
+    moves[played] = buf[5 * n:5 * n + total]
+    visits = None
+    if has_visits:
+        visits = torch.zeros((n, N, N), dtype=torch.int16, device=dev)
+        flat = buf[5 * n + total:5 * n + total + total * N * 2]
+        if (5 * n + total) % 2:                                  # int16 views need an even byte offset
+            flat = flat.clone()
+        visits[played] = flat.view(torch.int16).reshape(total, N)
+    return GameRecords(moves, lens, winner, visits, first_game_id, overflow)
+
+
 def gather_records(rec, dst=0, group=None):
-    """The exchange step: every rank contributes its fixed-stride records, rank `dst` receives the concatenation in
-    rank order (= global game id order).  Works on any torch.distributed backend; with world size 1 it is the identity."""
+    """The one exchange step of the path (network/data_helper.py:97-113: the worker processes' `Manager().list()`): every rank
+    contributes its records in the compact wire form of pack_records, rank `dst` receives them with one grouped batch of
+    point-to-point transfers -- every other rank posts ONE send, dst posts world - 1 receives (RCCL has no native gather; over xGMI
+    the 7 peers send concurrently on their own links) -- and unpacks the concatenation in rank order (= global game id order).
+    The same code runs on every torch.distributed backend (RCCL on the GPU box, gloo in the CPU tests); with world size 1 it is the
+    identity.  Returns the gathered GameRecords on dst, None elsewhere."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return rec
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    # shards may differ by one game: exchange the counts, pad to the longest, trim after the gather
-    mine = torch.tensor([len(rec)], dtype=torch.int64, device=rec.lens.device)
-    counts = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(counts, mine, group=group)
-    counts = [int(c) for c in counts]
-    longest = max(counts)
-    out = {}
-    for name in ("moves", "lens", "winner", "visits"):
-        t = getattr(rec, name)
-        if t is None:
-            out[name] = None
-            continue
-        t = t.contiguous()
-        dtype, tail = t.dtype, tuple(t.shape[1:])
-        t = t.reshape(t.shape[0], -1).view(torch.uint8)             # bytes on the wire: every backend carries uint8
-        if t.shape[0] < longest:
-            t = torch.cat([t, torch.zeros((longest - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)], dim=0)
-        bucket = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        if dist.get_backend(group) == "nccl":
-            # RCCL has no native gather: all ranks post one send, dst posts world-1 receives (grouped point-to-point
-            # over xGMI, 7 peers send concurrently), self-copy on dst
-            if rank == dst:
-                ops = [dist.P2POp(dist.irecv, bucket[r], r, group) for r in range(world) if r != dst]
-                bucket[dst].copy_(t)
-            else:
-                ops = [dist.P2POp(dist.isend, t, dst, group)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        else:
-            dist.gather(t, bucket, dst=dst, group=group)
-        if rank == dst:
-            whole = torch.cat([bucket[r][:counts[r]] for r in range(world)], dim=0)
-            out[name] = whole.view(dtype).reshape((whole.shape[0],) + tail)
-        else:
-            out[name] = None
-    first = torch.tensor([rec.first_game_id], dtype=torch.int64, device=rec.lens.device)
-    dist.all_reduce(first, op=dist.ReduceOp.MIN, group=group)       # id of the first game of the gathered block
+    dev = rec.lens.device
+    mine = pack_records(rec)
+    # sizes first: [games, bytes, first game id, arena overflow seen, visits recorded]
+    meta = torch.tensor([len(rec), int(mine.numel()), int(rec.first_game_id), int(bool(rec.overflow)), int(rec.visits is not None)], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    metas = [[int(v) for v in m] for m in metas]
+    if rank == dst:
+        bufs = [mine if r == dst else torch.empty(metas[r][1], dtype=torch.uint8, device=dev) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst and metas[r][1] > 0]
+    else:
+        ops = [dist.P2POp(dist.isend, mine, dst, group)] if mine.numel() > 0 else []
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != dst:
         return None
-    return GameRecords(out["moves"], out["lens"], out["winner"], out["visits"], int(first))
+    has_visits = all(m[4] for m in metas if m[0] > 0) and any(m[0] > 0 for m in metas)
+    overflow = any(m[3] for m in metas)                          # a rank whose arenas overflowed must not be reported as clean
+    parts = [unpack_records(bufs[r], metas[r][0], bool(metas[r][4]), metas[r][2]) for r in range(world) if metas[r][0] > 0]
+    first = min((m[2] for m in metas if m[0] > 0), default=rec.first_game_id)
+    if not parts:
+        return GameRecords(rec.moves[:0], rec.lens[:0], rec.winner[:0], None if rec.visits is None else rec.visits[:0], first, overflow)
+    return GameRecords(torch.cat([p.moves for p in parts]), torch.cat([p.lens for p in parts]), torch.cat([p.winner for p in parts]),
+                       torch.cat([p.visits for p in parts]) if has_visits else None, first, overflow)
 
 
 def shard(n_total, rank, world):

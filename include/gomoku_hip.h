@@ -136,6 +136,10 @@ int gmk_mcts_destroy(gmk_mcts *m);
 /* Fresh roots (MCTS::reset + syncWithBoard on a tree without the position, MCTS.cpp:119-125,149-156):
  * h_planes uint16[n][2][16]; h_last_move int16[n] (-1 for an empty board).  first_game_id = global id of game 0. */
 int gmk_mcts_set_roots(gmk_mcts *m, const uint16_t *h_planes, const int16_t *h_last_move, uint32_t first_game_id);
+/* The global id of every game (uint32[n], host), overriding first_game_id + g of the last gmk_mcts_set_roots: for callers whose
+ * handle plays a changing or non-contiguous set of games (slots handed from finished games to new ones, the groups of a match).
+ * The id is word 0 of every random-number counter of the game (rollouts, root noise). */
+int gmk_mcts_set_game_ids(gmk_mcts *m, const uint32_t *h_ids);
 /* MCTS::runPlayouts with the iteration constraint (MCTS.cpp:179-198): `playouts` playouts for every game, one launch. */
 int gmk_mcts_run(gmk_mcts *m, int playouts, void *stream);
 /* One self-play move for every unfinished game, to be called after gmk_mcts_run (replaces the loop body of
@@ -197,6 +201,10 @@ typedef struct gmk_trad gmk_trad;
 int gmk_trad_create(int n_games, int node_capacity /* nodes per game, 256 .. 2^24-1 */, gmk_trad** out);
 int gmk_trad_destroy(gmk_trad* t);
 int gmk_trad_reset_evaluators(gmk_trad* t);                       /* Evaluator::reset for every game */
+/* The game each slot of the handle is playing, relative to the first_game_id the noise / PoolRAVE entry points take (uint32[n], host;
+ * default: the slot number).  A caller that hands the slot of a finished game to a new one sets the new game's number here, so that
+ * the game's random streams (root noise, PoolRAVE rollouts) belong to the GAME, not to the slot it happens to run in. */
+int gmk_trad_set_game_ids(gmk_trad* t, const uint32_t* h_ids);
 int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves /* [n][225] */, const int32_t* h_lens /* [n]; < 0: this game keeps its position and tree */);
 int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stream);
 /* host outputs, any may be NULL: per-cell root child visits / values / priors [n][225], the move stepForward() would
@@ -246,7 +254,9 @@ int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_probs, void* 
 /* MCTS::stepForward() / stepForward(move) (core/lib/src/MCTS.cpp:129-147) for every game, subtree kept (as gmk_trad_step): h_moves
  * int16[n] = the cell to step to, -1 = the most visited child, NULL = -1 for all; status bit 2 = not a legal move. */
 int gmk_az_step(gmk_az* a, const int16_t* h_moves);
-/* Default::AddNoise on every root with children (core/lib/include/algorithms/MonteCarlo.hpp:97-108) */
+/* Default::AddNoise on every root with children (core/lib/include/algorithms/MonteCarlo.hpp:97-108); the stream of slot g is keyed
+ * by first_game_id + ids[g], ids as set by gmk_az_set_game_ids (uint32[n], host; default: the slot number) */
+int gmk_az_set_game_ids(gmk_az* a, const uint32_t* h_ids);
 int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id);
 /* The same two steps for an evaluator that runs on the host and wants positions, not planes (the Python callable of
  * Policy(eval_state=...)): select, then the moves from the root to every pending leaf (h_paths int16[n][226], h_lens int32[n],

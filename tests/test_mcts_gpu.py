@@ -52,6 +52,26 @@ def test_visits_match_oracle(oracle, n_games, plies, playouts):
     t.close()
 
 
+def test_two_handles_with_different_rollout_counts(oracle):
+    """The rollout-sum -> value table belongs to the handle: a supervisor with c_rollouts = 5 and a candidate with 10 live side
+    by side (play_match_games, two CorePyExt MCTS(RandomPolicy(c, r)) agents) and both must search like the oracle, in either
+    order of creation and use."""
+    moves, lens, planes, last = _openings(6, 4, first=31)
+    a = G.BatchedMCTS(6, playouts_capacity=150, c_rollouts=5)
+    b = G.BatchedMCTS(6, playouts_capacity=150, c_rollouts=10)          # created second: a one-table-per-process build would now serve a with b's table
+    c = G.BatchedMCTS(6, playouts_capacity=150, c_rollouts=3)
+    for t, r in ((a, 5), (b, 10), (c, 3), (a, 5)):
+        t.set_roots(planes, last, first_game_id=40)
+        t.run(150)
+        visits, q, _, nodes, status = t.root_stats()
+        for g in range(6):
+            ov, oq, _, osize, _ = _oracle_search(oracle, moves[g], int(lens[g]), 150, 40 + g, c_rollouts=r)
+            assert (visits[g] == ov).all() and nodes[g] == osize and q[g].tobytes() == oq.tobytes(), "c_rollouts %d, game %d" % (r, g)
+        assert not status.any()
+    for t in (a, b, c):
+        t.close()
+
+
 def test_results_independent_of_batching(oracle):
     """Game g's result depends on its global id only: 30 games in one handle == the same games run as 7 + 23."""
     moves, lens, planes, last = _openings(30, 4, first=5)

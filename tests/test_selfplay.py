@@ -68,16 +68,17 @@ def _free_port():
     return port
 
 
-def _gather_worker(rank, world, port, out_dir):
+def _gather_worker(rank, world, port, out_dir, total, dst):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, n = selfplay.shard(7, rank, world)
+    lo, n = selfplay.shard(total, rank, world)
     rec = _fake_records(n, lo, 100 + rank)
-    got = selfplay.gather_records(rec, dst=0)
+    rec.overflow = rank == world - 1                       # one rank saw an arena overflow: rank dst must hear of it
+    got = selfplay.gather_records(rec, dst=dst)
     torch.save({"moves": rec.moves, "lens": rec.lens, "winner": rec.winner, "visits": rec.visits}, os.path.join(out_dir, "part%d.pt" % rank))
-    if rank == 0:
-        assert got is not None and len(got) == 7 and got.first_game_id == 0
+    if rank == dst:
+        assert got is not None and len(got) == total and got.first_game_id == 0 and got.overflow
         torch.save({"moves": got.moves, "lens": got.lens, "winner": got.winner, "visits": got.visits}, os.path.join(out_dir, "all.pt"))
     else:
         assert got is None
@@ -85,13 +86,30 @@ def _gather_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_gather_world_size_2_gloo(tmp_path):
-    world = 2
-    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,total,dst", [(2, 7, 0), (3, 7, 1), (3, 2, 0)])      # even-ish shards; uneven shards to a non-zero root; a rank without a game
+def test_gather_gloo(tmp_path, world, total, dst):
+    """The exchange step with world size 2 and 3 on gloo: ONE code path for every backend (grouped point-to-point transfers of
+    the compact wire form), so this is what RCCL runs on the GPU box."""
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path), total, dst), nprocs=world, join=True)
     parts = [torch.load(os.path.join(tmp_path, "part%d.pt" % r)) for r in range(world)]
     allrec = torch.load(os.path.join(tmp_path, "all.pt"))
     for key in ("moves", "lens", "winner", "visits"):
         assert torch.equal(allrec[key], torch.cat([p[key] for p in parts], dim=0)), key
+
+
+def test_wire_form_is_compact_and_round_trips():
+    """pack_records carries only what was played (moves u8[L], visits u16[L][225], winner, length per game)."""
+    rec = _fake_records(3, 9, 5)
+    buf = selfplay.pack_records(rec)
+    total = int(rec.lens.sum())
+    assert buf.dtype == torch.uint8 and buf.numel() == 3 * 5 + total + total * 225 * 2
+    assert buf.numel() < 0.6 * (rec.moves.numel() + rec.visits.numel() * 2)
+    back = selfplay.unpack_records(buf, 3, True, first_game_id=9)
+    for key in ("moves", "lens", "winner", "visits"):
+        assert torch.equal(getattr(back, key), getattr(rec, key)), key
+    no_visits = selfplay.GameRecords(rec.moves, rec.lens, rec.winner, None, 9)
+    back = selfplay.unpack_records(selfplay.pack_records(no_visits), 3, False)
+    assert back.visits is None and torch.equal(back.moves, rec.moves)
 
 
 def test_gather_single_process_is_identity():
