@@ -292,7 +292,7 @@ def cpu_baseline_mcts(playouts):
             "sample": "%d searches of %d playouts from the same 4-ply openings, oracle MCTS restatement, %.1f s" % (done // playouts, playouts, dt)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -312,14 +312,71 @@ def main():
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
     ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
     ap.add_argument("--rave-playouts", type=int, default=400)
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test without a GPU: ranks rendezvous over gloo, the step is a no-op and the line says so (tests/test_bench_launcher.py)")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes of this script, one per GPU of the
+    node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), and wait.
+    This process has not touched the GPU (no torch import yet): the ranks are children, nothing is exec'ed over a GPU process."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def stub_rank(args, world, rank):
+    """--stub: what the launcher and the rank bookkeeping do, without a GPU: rendezvous (gloo), barrier, max over ranks, one line."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    elapsed = time.perf_counter() - t0 + 1e-9
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "board-evals/s", "value": args.boards * world * args.steps / elapsed, "unit": "board-evals/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "stub",
+                          "config": {"workload": "launcher self-test (--stub): no kernel ran"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: the line's n_gpus must be the number of ranks that ran" % (args.gpus, world))
+    if args.stub:
+        return stub_rank(args, world, rank)
 
     import numpy as np
     import torch
     from gomokuai_amd import lib as G
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     if distributed:

@@ -29,7 +29,6 @@
 // HBM traffic per board: 64 B in, 7 248 B out (7 312 B algorithmic); everything else stays on chip.
 #include <algorithm>
 #include <cstdlib>
-#include <utility>
 #include <vector>
 
 #include "capi_common.h"
@@ -54,7 +53,7 @@ constexpr int kColBase = 20, kDiagBase = 36, kAntiBase = 65;
 constexpr int kMiscWords = 16;                   // [0] stones black | white << 16, [1] winner bits, [2] error, [3] compound queue count, [4..14] totals
 constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
 static_assert(kZeroWords % 4 == 0 && kBoardWords % 4 == 0, "16-byte alignment of the per-board blocks");
-constexpr int kStaticTableWords = 128 + kLineWords + 512;   // lane jobs, initial line words, the bits-to-bytes table of phase D
+constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560;   // lane jobs, initial line words, the bits-to-bytes table and the weight table of phase D
 
 // Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
@@ -140,30 +139,21 @@ __device__ __forceinline__ void add_counter_cells(uint32_t w0, int back, int q, 
 // a product of a constant banded 225 x 225 matrix with the stone planes.  Sixteen boards x two colours are the 32 columns
 // of v_mfma_i32_32x32x32_i8; an M tile is 32 consecutive cells (7 tiles cover cells 0..223, cell 224 is done by hand), a K tile
 // two board rows of 16 (k = 16 y + x: the stones of a row become the bytes of its tile as they lie).  A tile of cells only
-// reaches rows y0-3 .. y1+3, so 31 (M, K) tile pairs per plane kind hold non-zeros: 62 MFMAs per group.
+// reaches rows y0-3 .. y1+3, so 31 (M, K) tile pairs per plane kind hold non-zeros.
 constexpr int kDensTiles = 7;
 __host__ __device__ constexpr int dens_kt_lo(int m) { return (((32 * m) / 15 - 3) < 0 ? 0 : (32 * m) / 15 - 3) / 2; }
 __host__ __device__ constexpr int dens_kt_hi(int m) { return (((32 * m + 31) / 15 + 3) > 14 ? 14 : (32 * m + 31) / 15 + 3) / 2; }
-__host__ __device__ constexpr int dens_steps() { int n = 0; for (int m = 0; m < kDensTiles; ++m) n += 2 * (dens_kt_hi(m) - dens_kt_lo(m) + 1); return n; }
-constexpr int kDensSteps = dens_steps();            // 62: 31 for the count planes, then 31 for the weight planes
-constexpr int kDensAhead = 4;                       // A operands in flight in the gate pass
-__host__ __device__ constexpr int dens_tile_base(int m) { int n = 0; for (int i = 0; i < m; ++i) n += dens_kt_hi(i) - dens_kt_lo(i) + 1; return n; }
-constexpr int kDensKindSteps = dens_tile_base(kDensTiles);        // 31
-struct constexpr_step { int m, kt; };
-__host__ __device__ constexpr constexpr_step dens_step(int s) {   // step of one plane kind -> (M tile, K tile)
-    for (int m = 0; m < kDensTiles; ++m)
-        for (int kt = dens_kt_lo(m); kt <= dens_kt_hi(m); ++kt, --s)
-            if (s == 0) return {m, kt};
-    return {0, 0};
-}
+// The weight operand of lane (cell c = (yo, xo), k half h) at K tile kt holds the taps from row y = 2 kt + h, columns 0..15, to c:
+// byte j = w(y - yo, j - xo).  It depends on (dy, xo) only, so ALL weight operands are rows of one small table in LDS,
+// [plane kind][dy + 6][xo] x 16 bytes (6 240 B), read with one ds_read_b128 per MFMA; going up one K tile is +2 in dy = +480 bytes,
+// an immediate offset.  (A table in global memory, 62 KB read by every wavefront for every group, cost 380 MB of L2 traffic per
+// launch and a global-load latency per MFMA.)
+constexpr int kWtabDy = 13, kWtabEntryWords = 4, kWtabKindWords = kWtabDy * 15 * kWtabEntryWords, kWtabWords = 2 * kWtabKindWords;
 // BlockWeights by |dy| and dx + 3 (the matrix is symmetric in both axes)
 __host__ __device__ constexpr int block_weight(int dy, int dx) {
     constexpr int w[4][7] = {{1, 3, 4, 0, 4, 3, 1}, {0, 3, 5, 4, 5, 3, 0}, {0, 4, 3, 3, 3, 4, 0}, {2, 0, 0, 1, 0, 0, 2}};
     return w[dy < 0 ? -dy : dy][dx + 3];
 }
-
-template <class F, int... S>
-__device__ __forceinline__ void for_each_step(F& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -174,12 +164,12 @@ struct __attribute__((packed, aligned(4))) Int4Unaligned { int32_t x, y, z, w; }
 // Count planes only, cells on the accumulator ROWS (A = weights, B = stones): lane (n, h) then holds, per M tile, sixteen cells of
 // ITS column, and "count >= 1", "count >= 2" pack into bit strings with two instructions per cell.  Nothing is stored from here
 // (except cell 224, which no tile covers): the planes leave in part 2, spread over the group's board iterations.
-// a_tab: the weight operands in lane order, one uint4 per lane and step.
+// s_wtab: the weight table in LDS (above).
 // Returns, for THIS lane's column, bit strings over the cells, already restricted to empty cells, as four registers each:
 // register p of lane (n, h) holds cells 64 p + 32 h .. + 31, so that pass p of phase 3 (cell = 64 p + lane) finds its bit
 // with ONE ds_bpermute from lane (lane & 32) | n.  gate1: count >= 1 (<=> weight > 0), gate2: count >= 2.
 __device__ __forceinline__ void density_gates(const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
-                                              const v4i* __restrict__ a_tab, int32_t* __restrict__ out_density,
+                                              const v4i* __restrict__ s_wtab, int32_t* __restrict__ out_density,
                                               v4i* s_bt /* 8 KB of this wavefront's LDS */, uint32_t (&gate1)[4], uint32_t (&gate2)[4]) {
     const int n = lane & 31, h = lane >> 5, plane = n & 1;
     const int board = first_board + (n >> 1);
@@ -234,45 +224,27 @@ __device__ __forceinline__ void density_gates(const uint16_t* __restrict__ plane
         out[224] = static_cast<int32_t>(c224 ^ neg);
         out[kCells + 224] = static_cast<int32_t>(w224 ^ neg);
     }
-    // The 31 steps as ONE software pipeline: the weight operand of step s + kDensAhead is requested when step s issues, the
-    // stone operand comes from LDS.  The scheduling barriers keep the compiler from gathering the loads of a whole tile at its
-    // top (registers this kernel does not have at four wavefronts per SIMD).
+    // 31 MFMAs, both operands from LDS; one accumulator tile at a time
     uint32_t gates[8];                              // per M tile: count >= 1 at bit pos, count >= 2 at bit pos + 4 (pos below)
-    uint32_t a_off = lane * 16;                     // walks the table in step order; opaque, so that ONE offset register serves all loads
     wave_phase_fence();
-    v4i a_ring[kDensAhead];
 #pragma unroll
-    for (int s = 0; s < kDensAhead; ++s) {
-        a_ring[s] = *reinterpret_cast<const v4i*>(reinterpret_cast<const char*>(a_tab) + a_off);
-        a_off += 1024;
-        asm volatile("" : "+v"(a_off));
+    for (int m = 0; m < kDensTiles; ++m) {
+        const int cell = 32 * m + n, yo = (cell * 0x8889) >> 19, xo = cell - 15 * yo;    // (cell / 15 for cell < 2^15)
+        const v4i* w = s_wtab + (2 * dens_kt_lo(m) + h - yo + 6) * 15 + xo;
+        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int kt = dens_kt_lo(m); kt <= dens_kt_hi(m); ++kt)
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[30 * (kt - dens_kt_lo(m))], s_bt[kt * 64 + lane], acc, 0, 0, 0);
+        uint32_t t = 0;                             // accumulator i = cell 32 m + 8 (i / 4) + 4 h + (i % 4)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int pos = 8 * (i / 4) + (i % 4);
+            const uint32_t c = min(static_cast<uint32_t>(acc[i]), 2u);                  // 0, 1, 2
+            t |= (((c + 1u) >> 1) | ((c >> 1) << 4)) << pos;
+        }
+        asm volatile("" : "+v"(t));                 // (pins the sixteen-to-one reduction here: sunk to the end of the pass it would keep every tile's accumulators alive)
+        gates[m] = t;
     }
-    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto do_step = [&](auto step_constant) {        // one call per step, expanded at compile time (see the fold below)
-        constexpr int s = decltype(step_constant)::value;
-        constexpr constexpr_step st = dens_step(s);
-        const v4i b = s_bt[st.kt * 64 + lane];
-        if (st.kt == dens_kt_lo(st.m)) acc = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_ring[s % kDensAhead], b, acc, 0, 0, 0);
-        if (s + kDensAhead < kDensKindSteps) {
-            a_ring[s % kDensAhead] = *reinterpret_cast<const v4i*>(reinterpret_cast<const char*>(a_tab) + a_off);
-            a_off += 1024;
-            asm volatile("" : "+v"(a_off));
-        }
-        if (st.kt == dens_kt_hi(st.m)) {            // accumulator i = cell 32 m + 8 (i / 4) + 4 h + (i % 4)
-            uint32_t t = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int pos = 8 * (i / 4) + (i % 4);
-                const uint32_t c = min(static_cast<uint32_t>(acc[i]), 2u);              // 0, 1, 2
-                t |= (((c + 1u) >> 1) | ((c >> 1) << 4)) << pos;
-            }
-            asm volatile("" : "+v"(t));             // (pins the sixteen-to-one reduction here: sunk to the end of the pass it would keep every tile's accumulators alive)
-            gates[st.m] = t;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    for_each_step(do_step, std::make_integer_sequence<int, kDensKindSteps>{});
     gates[7] = 0;
     uint32_t g1[8], g2[8];
 #pragma unroll
@@ -302,67 +274,68 @@ __device__ __forceinline__ void density_gates(const uint16_t* __restrict__ plane
 // iterations spreads the 3.6 KB per board over the kernel's run time instead of one burst at its start.
 // The stones are read again (64 B per board from L2) and become operand bytes through a 256-entry table in LDS (byte -> 8 bytes).
 template <int KIND, int M>
-__device__ __forceinline__ void density_tile_pass(const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
-                                                  const v4i* __restrict__ a_tab, int32_t* __restrict__ out_density,
-                                                  const uint2* __restrict__ s_lut) {
+__device__ __forceinline__ void density_tile_pass(const uint32_t (&own_rows)[8], const uint32_t (&other_rows)[8], int n_boards, int first_board, int lane,
+                                                  const v4i* __restrict__ s_wtab, int32_t* __restrict__ out_density,
+                                                  const uint2* __restrict__ s_lut, int plane_stride) {
     constexpr int lo = dens_kt_lo(M), hi = dens_kt_hi(M), nk = hi - lo + 1;
-    const int n = lane & 31, h = lane >> 5, plane = n & 1;
-    const int board = first_board + (n >> 1);
-    const bool live = board < n_boards;
-    uint32_t own[nk], both[nk];                     // rows 2 (lo + k), 2 (lo + k) + 1
-    {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(planes + static_cast<size_t>(live ? board : first_board) * 32);
-#pragma unroll
-        for (int k = 0; k < nk; ++k) {
-            own[k] = p[plane * 8 + lo + k];
-            both[k] = own[k] | p[(1 - plane) * 8 + lo + k];
-            if (!live) own[k] = both[k] = 0u;
-        }
-    }
-    // occupied cells 32 M .. 32 M + 31 of this lane's board
+    constexpr int y0 = (32 * M) / 15, y1 = (32 * M + 31) / 15;
+    const int n = lane & 31, h = lane >> 5;
+    // occupied cells 32 M .. 32 M + 31 of this lane's board (rows y0 .. y1 of both planes)
     uint32_t occ = 0;
-    {
-        constexpr int y0 = (32 * M) / 15, y1 = (32 * M + 31) / 15;
 #pragma unroll
-        for (int y = y0; y <= y1; ++y) {
-            const uint32_t r = ((y & 1) ? both[y / 2 - lo] >> 16 : both[y / 2 - lo]) & 0x7FFFu;
-            const int at = 15 * y - 32 * M;
-            occ |= at >= 0 ? r << at : r >> -at;
-        }
+    for (int y = y0; y <= y1; ++y) {
+        const uint32_t both = own_rows[y / 2] | other_rows[y / 2];
+        const uint32_t r = ((y & 1) ? both >> 16 : both) & 0x7FFFu;
+        const int at = 15 * y - 32 * M;
+        occ |= at >= 0 ? r << at : r >> -at;
     }
+    const int cell = 32 * M + n, yo = (cell * 0x8889) >> 19, xo = cell - 15 * yo;
+    const v4i* w = s_wtab + KIND * (kWtabKindWords / kWtabEntryWords) + (2 * lo + h - yo + 6) * 15 + xo;
     v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < nk; ++k) {
-        const uint32_t r = (own[k] >> (16 * h)) & 0x7FFFu;
+        const uint32_t r = (own_rows[lo + k] >> (16 * h)) & 0x7FFFu;
         const uint2 b0 = s_lut[r & 255u], b1 = s_lut[r >> 8];
         const v4i stones = {static_cast<int>(b0.x), static_cast<int>(b0.y), static_cast<int>(b1.x), static_cast<int>(b1.y)};
-        const v4i weights = a_tab[(KIND * kDensKindSteps + dens_tile_base(M) + k) * 64 + lane];
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(stones, weights, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(stones, w[30 * k], acc, 0, 0, 0);
     }
     // accumulator i = board-colour column 8 (i / 4) + 4 h + (i % 4) at cell 32 M + n; columns 2 b, 2 b + 1 are board b
     const int n_live = n_boards - first_board;      // >= 16 except in the last group
-    int32_t* out = out_density + static_cast<size_t>(first_board) * 4 * kCells + KIND * kCells + 32 * M + n + h * (2 * 4 * kCells);
+    int32_t* out = out_density + static_cast<size_t>(first_board) * 4 * plane_stride + KIND * plane_stride + 32 * M + n + h * (2 * 4 * plane_stride);
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
         const int b = 4 * (i / 4) + (i % 4) / 2;    // + 2 h
-        const uint32_t w = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(8 * b + 16 * h, static_cast<int>(occ)));
-        const int neg = __builtin_amdgcn_sbfe(static_cast<int>(w), n, 1);       // occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
-        if (b + 2 * h < n_live) {
-            out[b * 4 * kCells + 1 * 2 * kCells] = acc[i] ^ neg;                 // column 2 b: black, the second colour block
-            out[b * 4 * kCells + 0 * 2 * kCells] = acc[i + 1] ^ neg;             // column 2 b + 1: white, the first
+        const uint32_t wd = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(8 * b + 16 * h, static_cast<int>(occ)));
+        const int neg = __builtin_amdgcn_sbfe(static_cast<int>(wd), n, 1);      // occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
+        if (b + 2 * h < n_live && plane_stride > 0) {
+            out[b * 4 * plane_stride + 1 * 2 * plane_stride] = acc[i] ^ neg;                 // column 2 b: black, the second colour block
+            out[b * 4 * plane_stride + 0 * 2 * plane_stride] = acc[i + 1] ^ neg;             // column 2 b + 1: white, the first
         }
     }
 }
 
-__device__ __forceinline__ void density_pass(int pass, const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
-                                             const v4i* __restrict__ a_tab, int32_t* __restrict__ out_density, const uint2* __restrict__ s_lut) {
-    switch (pass) {                                 // wave-uniform
-#define GMK_PASS(K, M) case K * 7 + M: density_tile_pass<K, M>(planes, n_boards, first_board, lane, a_tab, out_density, s_lut); break;
-        GMK_PASS(0, 0) GMK_PASS(0, 1) GMK_PASS(0, 2) GMK_PASS(0, 3) GMK_PASS(0, 4) GMK_PASS(0, 5) GMK_PASS(0, 6)
-        GMK_PASS(1, 0) GMK_PASS(1, 1) GMK_PASS(1, 2) GMK_PASS(1, 3) GMK_PASS(1, 4) GMK_PASS(1, 5) GMK_PASS(1, 6)
-#undef GMK_PASS
-        default: break;
+// All fourteen passes of a group, back to back: the group's density planes are one contiguous block of 16 x 3 600 bytes, and written
+// within a few microseconds by one wavefront they reach DRAM as whole cache lines, row after row.  (One pass per board iteration --
+// each line written in two pieces a board's work apart, each board's block in fourteen -- ran into the DRAM controller's write
+// credits: TCC_EA0_WRREQ 9.7 M per launch instead of 3.9 M for the scores alone, a fifth of them 32-byte pieces.)
+// The sixteen wavefronts of a workgroup take turns (the caller runs this in board iteration `wavefront number`), so that at any time
+// one wavefront per CU is storing planes while fifteen evaluate boards.
+__device__ __forceinline__ void density_planes_out(const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
+                                                   const v4i* __restrict__ s_wtab, int32_t* __restrict__ out_density,
+                                                   const uint2* __restrict__ s_lut, int plane_stride) {
+    const int n = lane & 31, plane = n & 1, board = first_board + (n >> 1);
+    uint32_t own[8], other[8];
+    {
+        // (columns without a board read the group's first board: what they compute is never stored)
+        const uint4* p = reinterpret_cast<const uint4*>(planes + static_cast<size_t>(board < n_boards ? board : first_board) * 32);
+        const uint4 a0 = p[plane * 2], a1 = p[plane * 2 + 1], b0 = p[2 - plane * 2], b1 = p[3 - plane * 2];
+        own[0] = a0.x; own[1] = a0.y; own[2] = a0.z; own[3] = a0.w; own[4] = a1.x; own[5] = a1.y; own[6] = a1.z; own[7] = a1.w;
+        other[0] = b0.x; other[1] = b0.y; other[2] = b0.z; other[3] = b0.w; other[4] = b1.x; other[5] = b1.y; other[6] = b1.z; other[7] = b1.w;
     }
+#define GMK_PASS(K, M) density_tile_pass<K, M>(own, other, n_boards, first_board, lane, s_wtab, out_density, s_lut, plane_stride); __builtin_amdgcn_sched_barrier(0);
+    GMK_PASS(0, 0) GMK_PASS(1, 0) GMK_PASS(0, 1) GMK_PASS(1, 1) GMK_PASS(0, 2) GMK_PASS(1, 2) GMK_PASS(0, 3) GMK_PASS(1, 3)
+    GMK_PASS(0, 4) GMK_PASS(1, 4) GMK_PASS(0, 5) GMK_PASS(1, 5) GMK_PASS(0, 6) GMK_PASS(1, 6)
+#undef GMK_PASS
 }
 
 __global__ __launch_bounds__(kThreads)
@@ -370,8 +343,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                            int32_t* __restrict__ out_scores, int32_t* __restrict__ out_density,
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
-                           int trans_words, int record_words, const v4i* __restrict__ dens_a,
-                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D; 0x7F in production */) {
+                           int trans_words, int record_words, const uint32_t* __restrict__ g_wtab,
+                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D (bit 8: its planes 1 KB apart, bit 9: passes without stores, bit 10: no passes); 0x7F in production */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [trans (LDS address 0)][records (16-byte aligned)][lane jobs 128][initial line words 96][boards: kBoardsPerBlock * kBoardWords]
     const uint4* s_rec = reinterpret_cast<const uint4*>(lds + trans_words);
@@ -384,6 +357,9 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     if (threadIdx.x < kLineWords) s_jobs[128 + threadIdx.x] = c_line_init[threadIdx.x];
     uint2* s_lut = reinterpret_cast<uint2*>(s_jobs + 128 + kLineWords);      // byte -> its eight bits as bytes (the stone operands of phase D)
     if (threadIdx.x < 256) s_lut[threadIdx.x] = make_uint2(((threadIdx.x & 15u) * 0x204081u) & 0x01010101u, ((threadIdx.x >> 4) * 0x204081u) & 0x01010101u);
+    uint32_t* s_wtab_words = s_jobs + 128 + kLineWords + 512;
+    for (int i = threadIdx.x; i < kWtabWords; i += kThreads) s_wtab_words[i] = g_wtab[i];
+    const v4i* s_wtab = reinterpret_cast<const v4i*>(s_wtab_words);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     uint32_t* s_scores = lds + trans_words + record_words + kStaticTableWords + wave * kBoardWords;      // int32 scores, accumulated with ds_add
@@ -400,8 +376,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     for (int group = blockIdx.x + gridDim.x * wave; group < n_groups; group += gridDim.x * kBoardsPerBlock) {
     const int first_board = group * kGroupBoards;
     uint32_t gate1[4] = {0, 0, 0, 0}, gate2[4] = {0, 0, 0, 0};
-    if (phase_mask & 64) density_gates(planes, n_boards, first_board, lane0, dens_a, out_density, reinterpret_cast<v4i*>(s_scores), gate1, gate2);
-    const bool planes_out = out_density != nullptr && (phase_mask & 64);
+    if (phase_mask & 64) density_gates(planes, n_boards, first_board, lane0, s_wtab, out_density, reinterpret_cast<v4i*>(s_scores), gate1, gate2);
+    const bool planes_out = out_density != nullptr && (phase_mask & 64) && !(phase_mask & 1024);
 
     // Everything the board phases derive from the lane number is derived from THIS copy, which the compiler cannot see through:
     // those ~45 registers of per-lane constants are then computed after phase D (once per sixteen boards) instead of
@@ -410,248 +386,267 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     asm volatile("" : "+v"(lane));
     const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
     const uint32_t lane_tag = static_cast<uint32_t>(lane) << 10;
-    // a board's 64 B are fetched while the board before it is evaluated (they were read by phase D: an L2 hit)
-    auto fetch_row = [&](int b) -> uint32_t {
-        if (lane >= 16 || b >= n_boards) return 0u;
-        return static_cast<uint32_t>(planes[static_cast<size_t>(b) * 32 + lane]) | (static_cast<uint32_t>(planes[static_cast<size_t>(b) * 32 + 16 + lane]) << 16);
+    // a board's 64 B are fetched while the board before it is evaluated (they were read by phase D: an L2 hit).  No branch around
+    // the loads (every lane reads some valid row, the result is masked where it is used): with one, the compiler waits for the
+    // data at the end of the branch, i.e. at once, and the wait covers every store issued before.
+    const uint16_t* row_ptr = planes + (lane & 15);
+    uint32_t next_black = 0, next_white = 0;         // the two halves stay apart until they are used: combining them would be a use
+    uint32_t cur_black = 0, cur_white = 0;           // the rows of the board being evaluated: landed (see below)
+    auto fetch_row = [&](int b) {
+        const uint16_t* p = row_ptr + static_cast<size_t>(min(b, n_boards - 1)) * 32;
+        next_black = p[0];
+        next_white = p[16];
     };
-    uint32_t next_row = fetch_row(first_board);
+    auto take_row = [&](int b) -> uint32_t { return lane < 16 && b < n_boards ? cur_black | (cur_white << 16) : 0u; };
+    fetch_row(first_board);
+    asm volatile("" : "+v"(next_black), "+v"(next_white));        // (once per group: wait for them here)
 
 #pragma unroll 1
     for (int bi = 0; bi < kGroupBoards; ++bi) {
         const int board = first_board + bi;
         const bool live = board < n_boards;
-        if (!live) break;
+        // the next board's planes are requested here, ahead of phases 0 .. 4, and waited for just before this iteration's stores:
+        // loads and stores share one in-order counter (vmcnt), so wherever else the wait stood it would also wait for stores
+        // issued moments before (the compiler cannot count across the loop, it waits for everything).  There, the youngest
+        // outstanding operation is this load, a board's work old.
+        cur_black = next_black; cur_white = next_white;
+        if (bi + 1 < kGroupBoards) fetch_row(board + 1);
 
-        // ---- phase D, part 2: one of the fourteen density passes of the group per board ----
-        if (planes_out) {
-            int lane_p = lane0, first_p = first_board;         // opaque copies: what a pass derives from them is computed in the pass, not for all
-            asm volatile("" : "+v"(lane_p), "+s"(first_p));     // fourteen passes ahead of the loop (hundreds of registers)
-            density_pass(bi, planes, n_boards, first_p, lane_p, dens_a, out_density, s_lut);
-        }
-
-        // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words ----
-        {
-            uint4* z = reinterpret_cast<uint4*>(s_scores) + lane;
-#pragma unroll
-            for (int i = 0; i < kZeroWords / 4; i += 64)
-                if (i + 64 <= kZeroWords / 4 || lane < kZeroWords / 4 - i) z[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        s_lines[lane] = s_line_init[lane];
-        if (lane < kLineWords - 64) s_lines[64 + lane] = s_line_init[64 + lane];
-        if (lane < kMiscWords) s_misc[lane] = 0;
-        const uint32_t my_row = next_row;
-        next_row = bi + 1 < kGroupBoards ? fetch_row(board + 1) : 0u;
-        wave_phase_fence();
-        if (lane < 15) atomicAdd(&s_misc[0], static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16));
-        {
-            // a stone turns its cell's blank (3) into black (0) or white (1) in the four lines through it: one XOR each.
-            // Four lanes share a row (cells 0-3, 4-7, 8-11, 12-14), so the loop runs as long as the fullest quarter row.
-            const int y = lane >> 2, part = lane & 3;
-            const uint32_t row = __shfl(my_row, min(y, 14));
-            uint32_t row_sym = 0;
-            for (uint32_t m = lane < 60 ? (row | (row >> 16)) & (0xFu << (4 * part)) & 0x7FFFu : 0u; m; m &= m - 1u) {
-                const int x = __ffs(m) - 1;
-                const uint32_t code = ((row >> x) & 1u) ? 3u : 2u;
-                row_sym |= code << (2 * x);
-                atomicXor(&s_lines[kColBase + x], code << (2 * y));
-                atomicXor(&s_lines[kDiagBase + x - y + 14], code << (2 * min(x, y)));
-                atomicXor(&s_lines[kAntiBase + x + y], code << (2 * min(14 - x, y)));
+        if (live) {
+            // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words ----
+            {
+                uint4* z = reinterpret_cast<uint4*>(s_scores) + lane;
+    #pragma unroll
+                for (int i = 0; i < kZeroWords / 4; i += 64)
+                    if (i + 64 <= kZeroWords / 4 || lane < kZeroWords / 4 - i) z[i] = make_uint4(0u, 0u, 0u, 0u);
             }
-            if (row_sym) atomicXor(&s_lines[y], row_sym);
-        }
-        wave_phase_fence();
-
-        // ---- phase 1: walk the DFA along this lane's lines; transitions that emit go to the queue ----
-        // The lane's one or two lines become ONE stream of 2-bit DFA symbols:
-        //   '?' cells '?' '?'  ['?' cells '?' '?']  '?' '?' ...
-        // (after "??" the automaton sits in its '?' self-loop state, which the next line's leading '?' keeps: no reset
-        // between the two lines).  The stream is kept shifted left by 2, so a step is: symbol * 4 = low word & 12, LDS
-        // address = (previous word's next-row offset) | symbol * 4, one lookup.  Emitting transitions are queued raw
-        // (record, lane, step); the slot is a ballot prefix (this wave is the only producer), decoding happens in phase 2.
-        int n_queued = 0;                                       // wave-uniform
-        if (phase_mask & 2) {
-            const int len_a = job_a & 15, len_b = job_b & 15;
-            uint64_t syms = line_symbols(s_lines[(job_a >> 16) & 127u], len_a);
-            syms |= line_symbols(s_lines[(job_b >> 16) & 127u], len_b) << (2 * len_a + 6);
-            syms |= 0xAAAAAAAAAAAAAAAAull << (2 * (len_a + len_b) + 12);
-            uint32_t cur = static_cast<uint32_t>(syms) << 2;    // symbols 0..14 at bits 2..31
-            const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2..
-            uint32_t tw = 0;                                    // the previous step's table word (row 0 = root)
-            for (int step = 0; step < scan_steps; ++step) {
-                if (step == 15) cur = rest;
-                const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
-                cur >>= 2;
-                tw = *reinterpret_cast<const uint32_t*>(lds_bytes + addr);
-                const uint32_t rec = gmk::dev_trans_record(tw);
-                const unsigned long long emitters = __ballot(rec != 0u);
-                if (emitters) {
-                    if (rec) {
-                        const int slot = n_queued + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
-                                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u)));
-                        if (slot < kQueueCap) s_queue[slot] = rec | lane_tag | (static_cast<uint32_t>(step) << 16);
-                    }
-                    n_queued += __popcll(emitters);
+            s_lines[lane] = s_line_init[lane];
+            if (lane < kLineWords - 64) s_lines[64 + lane] = s_line_init[64 + lane];
+            if (lane < kMiscWords) s_misc[lane] = 0;
+            const uint32_t my_row = take_row(board);
+            wave_phase_fence();
+            if (lane < 15) atomicAdd(&s_misc[0], static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16));
+            {
+                // a stone turns its cell's blank (3) into black (0) or white (1) in the four lines through it: one XOR each.
+                // Four lanes share a row (cells 0-3, 4-7, 8-11, 12-14), so the loop runs as long as the fullest quarter row.
+                const int y = lane >> 2, part = lane & 3;
+                const uint32_t row = __shfl(my_row, min(y, 14));
+                uint32_t row_sym = 0;
+                for (uint32_t m = lane < 60 ? (row | (row >> 16)) & (0xFu << (4 * part)) & 0x7FFFu : 0u; m; m &= m - 1u) {
+                    const int x = __ffs(m) - 1;
+                    const uint32_t code = ((row >> x) & 1u) ? 3u : 2u;
+                    row_sym |= code << (2 * x);
+                    atomicXor(&s_lines[kColBase + x], code << (2 * y));
+                    atomicXor(&s_lines[kDiagBase + x - y + 14], code << (2 * min(x, y)));
+                    atomicXor(&s_lines[kAntiBase + x + y], code << (2 * min(14 - x, y)));
                 }
+                if (row_sym) atomicXor(&s_lines[y], row_sym);
             }
-            if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
-        }
-        wave_phase_fence();
+            wave_phase_fence();
 
-        // ---- phase 2: one lane per emitting transition: the score deposits of its 1-2 matches ----
-        if (phase_mask & 4) {
-            for (int m = lane; m < n_queued; m += 64) {
-                const uint32_t qe = s_queue[m];
-                // which line of which lane, and where on it (symbol 0 of a line is its leading pad)
-                const int src_lane = (qe >> 10) & 63, src_step = static_cast<int>(qe >> 16);
-                const uint4 rec = s_rec[qe & 1023u];
-                const uint32_t ja = s_jobs[src_lane * 2], jb = s_jobs[src_lane * 2 + 1];
-                const int first_len = static_cast<int>(ja & 15u) + 3;
-                const uint32_t job = src_step < first_len ? ja : jb;
-                const int pos = (src_step < first_len ? src_step : src_step - first_len) - 1;
-                const int dir = (job >> 12) & 3, stride = dir_stride(dir);
-                const int cell_at = static_cast<int>(((job >> 8) & 15u) * 15u + ((job >> 4) & 15u)) + pos * stride;
-                deposit_match(rec.x, rec.y, cell_at, dir, stride, s_scores, s_cnt, s_misc);
-                if (rec.z) deposit_match(rec.z, rec.w, cell_at, dir, stride, s_scores, s_cnt, s_misc);
-            }
-        }
-        wave_phase_fence();
-
-        // ---- phase 3: one lane per cell: area bonus, compound candidates ----
-        // The density planes themselves left in phase D; here only its gates matter: bit (cell) of gate1 / gate2 of the
-        // board's black column (lane 2 bi of phase D) and white column (lane 2 bi + 1), one ds_bpermute each.
-        int n_cand = 0;                                         // wave-uniform
-        if (phase_mask & 8) {
-            const int src_black = ((lane & 32) | (2 * bi)) * 4, src_white = src_black + 4;
-            const uint32_t sh = lane & 31;
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int q = 64 * pass + lane;                 // the last pass has 33 cells: the gates of the cells beyond are zero
-                const uint32_t g1b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate1[pass]))) >> sh) & 1u;
-                const uint32_t g1w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate1[pass]))) >> sh) & 1u;
-                const uint32_t g2b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate2[pass]))) >> sh) & 1u;
-                const uint32_t g2w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate2[pass]))) >> sh) & 1u;
-                // +160 in the own view where the colour's weight is positive (Pattern.cpp:268); adding zero elsewhere is harmless
-                atomicAdd(&s_scores[0 * kCells + q], g1w * 160u);
-                atomicAdd(&s_scores[3 * kCells + q], g1b * 160u);
-                // compound candidates (Compound::Test, Pattern.cpp:424-433, and the density gate, Pattern.cpp:182): empty cells whose
-                // LiveThree / DeadThree / LiveTwo '_' counters, each clipped to 2 (the reference's 2-bit shift flags), OR-ed over the
-                // types, sum to two or more over the directions; decided in phase 3b
-                const int qc = min(q, kCells - 1);
-                const uint32_t any = s_cnt[qc] | s_cnt[kCells + qc] | s_cnt[2 * kCells + qc];
-                const uint32_t upper = (any >> 1) | (any >> 2) | (any >> 3);
-                const uint32_t ge2 = upper & 0x11111111u, ge1 = (any | upper) & 0x11111111u;         // one bit per field with count >= 2 / >= 1
-                uint32_t cand = 0;
-                if (__popc(ge1 & 0xFFFFu) + __popc(ge2 & 0xFFFFu) >= 2 && g2w) cand |= 1u;
-                if (__popc(ge1 >> 16) + __popc(ge2 >> 16) >= 2 && g2b) cand |= 2u;
-                const unsigned long long pushers = __ballot(cand != 0u);
-                if (pushers) {
-                    if (cand) {
-                        const int slot = n_cand + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pushers >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pushers), 0u)));
-                        if (slot < kQueueCap / 2) s_queue[slot] = static_cast<uint32_t>(q) | (cand << 8);
-                    }
-                    n_cand += __popcll(pushers);
-                }
-            }
-        }
-        wave_phase_fence();
-
-        // (phases 3b, 4 and 5 derive their per-lane constants from a copy made here, per board: they are used once per board at most,
-        // and kept across the density pass above they would spill)
-        int lane_b = lane;
-        asm volatile("" : "+v"(lane_b));
-        // ---- phase 3b: one lane_b per candidate cell: compound state machine (Pattern.cpp:440-486), critical-point deposits,
-        //      counter-move rescans queued in the upper half of the queue ----
-        if (n_cand > kQueueCap / 2) { s_misc[2] = 1; n_cand = kQueueCap / 2; }
-        if (phase_mask & 8)
-        for (int m = lane_b; m < n_cand; m += 64) {
-            const uint32_t ce = s_queue[m];
-            const int q = ce & 255;
-            const uint32_t cw_l3 = s_cnt[q], cw_d3 = s_cnt[kCells + q], cw_l2 = s_cnt[2 * kCells + q];
-            for (int c = 0; c < 2; ++c) {
-                if (!((ce >> (8 + c)) & 1u)) continue;
-                // state machine S0,L2,LD3,To33,To43,To44 = 0..5; a counter counts like the reference's 2-bit shift flags: 0, 1, 2 or more (Pattern.cpp:395-400)
-                int state = 0, l3 = 0, triple = 0, n_comp = 0;
-                uint32_t comps = 0;                         // 4 bits per component: dir | tslot << 2
-                for (int d = 0; d < 4; ++d) {
-                    const int f = 4 * (c * 4 + d);
-                    const int k3 = min((cw_l3 >> f) & 15u, 2u), kd = min((cw_d3 >> f) & 15u, 2u), k2 = min((cw_l2 >> f) & 15u, 2u);
-                    const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
-                    if (t < 0) continue;
-                    const int k = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
-                    if (t == 0) ++l3;
-                    for (int r = 0; r < k; ++r) {
-                        comps |= static_cast<uint32_t>(d | (t << 2)) << (4 * n_comp);
-                        ++n_comp;
-                        if (state == 0) state += cond;
-                        else if (state <= 2) state += cond + 1;
-                        else { triple = 1; state += (state == 5) ? 0 : cond - 1; }
+            // ---- phase 1: walk the DFA along this lane's lines; transitions that emit go to the queue ----
+            // The lane's one or two lines become ONE stream of 2-bit DFA symbols:
+            //   '?' cells '?' '?'  ['?' cells '?' '?']  '?' '?' ...
+            // (after "??" the automaton sits in its '?' self-loop state, which the next line's leading '?' keeps: no reset
+            // between the two lines).  The stream is kept shifted left by 2, so a step is: symbol * 4 = low word & 12, LDS
+            // address = (previous word's next-row offset) | symbol * 4, one lookup.  Emitting transitions are queued raw
+            // (record, lane, step); the slot is a ballot prefix (this wave is the only producer), decoding happens in phase 2.
+            int n_queued = 0;                                       // wave-uniform
+            if (phase_mask & 2) {
+                const int len_a = job_a & 15, len_b = job_b & 15;
+                uint64_t syms = line_symbols(s_lines[(job_a >> 16) & 127u], len_a);
+                syms |= line_symbols(s_lines[(job_b >> 16) & 127u], len_b) << (2 * len_a + 6);
+                syms |= 0xAAAAAAAAAAAAAAAAull << (2 * (len_a + len_b) + 12);
+                uint32_t cur = static_cast<uint32_t>(syms) << 2;    // symbols 0..14 at bits 2..31
+                const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2..
+                uint32_t tw = 0;                                    // the previous step's table word (row 0 = root)
+                for (int step = 0; step < scan_steps; ++step) {
+                    if (step == 15) cur = rest;
+                    const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
+                    cur >>= 2;
+                    tw = *reinterpret_cast<const uint32_t*>(lds_bytes + addr);
+                    const uint32_t rec = gmk::dev_trans_record(tw);
+                    const unsigned long long emitters = __ballot(rec != 0u);
+                    if (emitters) {
+                        if (rec) {
+                            const int slot = n_queued + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u)));
+                            if (slot < kQueueCap) s_queue[slot] = rec | lane_tag | (static_cast<uint32_t>(step) << 16);
+                        }
+                        n_queued += __popcll(emitters);
                     }
                 }
-                const int ctype = state - 3;
-                if (ctype < 0 || ctype > 2) { s_misc[2] = 1; continue; }               // reference reads out of bounds here
-                atomicAdd(&s_misc[12 + ctype], c ? 0x10000u : 1u);
-                const int g_own = c ? 3 : 0, g_opp = c ? 2 : 1;
-                atomicAdd(&s_scores[g_own * kCells + q], 600u * n_comp);               // updateCritical, both perspectives
-                atomicAdd(&s_scores[g_opp * kCells + q], 600u * n_comp);
-                if (triple || l3) continue;
-                for (int i = 0; i < n_comp; ++i) {                                     // queue the counter-move rescans
-                    const uint32_t cd = (comps >> (4 * i)) & 15u;
-                    const uint32_t slot = atomicAdd(&s_misc[3], 1u);
-                    if (slot < kQueueCap / 2) s_queue[kQueueCap / 2 + slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(c) << 8) | (cd << 9);
-                    else s_misc[2] = 1;
-                }
+                if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
             }
-        }
-        wave_phase_fence();
+            wave_phase_fence();
 
-        // ---- phase 4: the counter-move cells of every compound component: the FIRST match of its type that runs through
-        //      the cell with a blank there (Compound::updateAntis, Pattern.cpp:520-543), scanning the 13-symbol window
-        //      centred on the cell.  Such a match ends at window index 6..12; eight lanes share a component, lane_b kk looks
-        //      at the transition at index 6 + kk only (the automaton forgets its start state after 7 symbols, so <= 8
-        //      lookups from the root bring it to the right state), and the lowest lane_b with a hit applies it ----
-        if (phase_mask & 16) {
-            const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap / 2);
-            for (int m0 = 0; m0 < n_comp; m0 += 8) {
-                const int m = m0 + (lane_b >> 3), kk = lane_b & 7, k = 6 + kk;
-                const uint32_t ent = m < n_comp ? s_queue[kQueueCap / 2 + m] : 0u;
-                const int q = ent & 255, c = (ent >> 8) & 1, dir = (ent >> 9) & 3, tslot = (ent >> 11) & 3;
-                const int want = tslot == 0 ? 5 : tslot == 1 ? 4 : 3;
-                const int x = q % 15, y = q / 15, stride = dir_stride(dir);
-                uint32_t hit_w0 = 0;
-                int hit_back = -1;
-                if (m < n_comp && kk < 7) {
-                    // the line through q in this direction: its word, q's position on it, its length
-                    const int diag = x - y + 14, anti = x + y;
-                    const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
-                    const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
-                    const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
-                    // six '?' | cells | six '?', then the 13 symbols starting six before q
-                    const uint64_t syms = (0xAAAull | (static_cast<uint64_t>(s_lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
-                    const int start = k > 7 ? k - 7 : 0;
-                    uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;      // kept shifted left by 2 as in phase 1
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(lds_bytes + ((tw & 0x3FFFu) | (cur & 12u)));
-                        cur >>= 2;
-                    }
-                    if ((gmk::dev_trans_kinds(tw) >> tslot) & 1u) {                     // the record holds the wanted type
-                        const uint4 rec = s_rec[gmk::dev_trans_record(tw)];
-                        hit_back = counter_match(rec.x, k, want);
-                        hit_w0 = rec.x;
-                        if (hit_back < 0) { hit_back = counter_match(rec.z, k, want); hit_w0 = rec.z; }
+            // ---- phase 2: one lane per emitting transition: the score deposits of its 1-2 matches ----
+            if (phase_mask & 4) {
+                for (int m = lane; m < n_queued; m += 64) {
+                    const uint32_t qe = s_queue[m];
+                    // which line of which lane, and where on it (symbol 0 of a line is its leading pad)
+                    const int src_lane = (qe >> 10) & 63, src_step = static_cast<int>(qe >> 16);
+                    const uint4 rec = s_rec[qe & 1023u];
+                    const uint32_t ja = s_jobs[src_lane * 2], jb = s_jobs[src_lane * 2 + 1];
+                    const int first_len = static_cast<int>(ja & 15u) + 3;
+                    const uint32_t job = src_step < first_len ? ja : jb;
+                    const int pos = (src_step < first_len ? src_step : src_step - first_len) - 1;
+                    const int dir = (job >> 12) & 3, stride = dir_stride(dir);
+                    const int cell_at = static_cast<int>(((job >> 8) & 15u) * 15u + ((job >> 4) & 15u)) + pos * stride;
+                    deposit_match(rec.x, rec.y, cell_at, dir, stride, s_scores, s_cnt, s_misc);
+                    if (rec.z) deposit_match(rec.z, rec.w, cell_at, dir, stride, s_scores, s_cnt, s_misc);
+                }
+            }
+            wave_phase_fence();
+
+            // ---- phase 3: one lane per cell: area bonus, compound candidates ----
+            // The density planes themselves left in phase D; here only its gates matter: bit (cell) of gate1 / gate2 of the
+            // board's black column (lane 2 bi of phase D) and white column (lane 2 bi + 1), one ds_bpermute each.
+            int n_cand = 0;                                         // wave-uniform
+            if (phase_mask & 8) {
+                const int src_black = ((lane & 32) | (2 * bi)) * 4, src_white = src_black + 4;
+                const uint32_t sh = lane & 31;
+    #pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int q = 64 * pass + lane;                 // the last pass has 33 cells: the gates of the cells beyond are zero
+                    const uint32_t g1b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate1[pass]))) >> sh) & 1u;
+                    const uint32_t g1w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate1[pass]))) >> sh) & 1u;
+                    const uint32_t g2b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate2[pass]))) >> sh) & 1u;
+                    const uint32_t g2w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate2[pass]))) >> sh) & 1u;
+                    // +160 in the own view where the colour's weight is positive (Pattern.cpp:268); adding zero elsewhere is harmless
+                    atomicAdd(&s_scores[0 * kCells + q], g1w * 160u);
+                    atomicAdd(&s_scores[3 * kCells + q], g1b * 160u);
+                    // compound candidates (Compound::Test, Pattern.cpp:424-433, and the density gate, Pattern.cpp:182): empty cells whose
+                    // LiveThree / DeadThree / LiveTwo '_' counters, each clipped to 2 (the reference's 2-bit shift flags), OR-ed over the
+                    // types, sum to two or more over the directions; decided in phase 3b
+                    const int qc = min(q, kCells - 1);
+                    const uint32_t any = s_cnt[qc] | s_cnt[kCells + qc] | s_cnt[2 * kCells + qc];
+                    const uint32_t upper = (any >> 1) | (any >> 2) | (any >> 3);
+                    const uint32_t ge2 = upper & 0x11111111u, ge1 = (any | upper) & 0x11111111u;         // one bit per field with count >= 2 / >= 1
+                    uint32_t cand = 0;
+                    if (__popc(ge1 & 0xFFFFu) + __popc(ge2 & 0xFFFFu) >= 2 && g2w) cand |= 1u;
+                    if (__popc(ge1 >> 16) + __popc(ge2 >> 16) >= 2 && g2b) cand |= 2u;
+                    const unsigned long long pushers = __ballot(cand != 0u);
+                    if (pushers) {
+                        if (cand) {
+                            const int slot = n_cand + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pushers >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pushers), 0u)));
+                            if (slot < kQueueCap / 2) s_queue[slot] = static_cast<uint32_t>(q) | (cand << 8);
+                        }
+                        n_cand += __popcll(pushers);
                     }
                 }
-                const unsigned long long hits = __ballot(hit_back >= 0);
-                const uint32_t mine = static_cast<uint32_t>(hits >> (lane_b & ~7)) & 0xFFu;
-                if (hit_back >= 0 && (mine & ((1u << kk) - 1u)) == 0u) add_counter_cells(hit_w0, hit_back, q, stride, s_scores + (c ? 2 : 1) * kCells);
             }
+            wave_phase_fence();
+
+            // ---- phase 3b: one lane per candidate cell: compound state machine (Pattern.cpp:440-486), critical-point deposits,
+            //      counter-move rescans queued in the upper half of the queue ----
+            if (n_cand > kQueueCap / 2) { s_misc[2] = 1; n_cand = kQueueCap / 2; }
+            if (phase_mask & 8)
+            for (int m = lane; m < n_cand; m += 64) {
+                const uint32_t ce = s_queue[m];
+                const int q = ce & 255;
+                const uint32_t cw_l3 = s_cnt[q], cw_d3 = s_cnt[kCells + q], cw_l2 = s_cnt[2 * kCells + q];
+                for (int c = 0; c < 2; ++c) {
+                    if (!((ce >> (8 + c)) & 1u)) continue;
+                    // state machine S0,L2,LD3,To33,To43,To44 = 0..5; a counter counts like the reference's 2-bit shift flags: 0, 1, 2 or more (Pattern.cpp:395-400)
+                    int state = 0, l3 = 0, triple = 0, n_comp = 0;
+                    uint32_t comps = 0;                         // 4 bits per component: dir | tslot << 2
+                    for (int d = 0; d < 4; ++d) {
+                        const int f = 4 * (c * 4 + d);
+                        const int k3 = min((cw_l3 >> f) & 15u, 2u), kd = min((cw_d3 >> f) & 15u, 2u), k2 = min((cw_l2 >> f) & 15u, 2u);
+                        const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
+                        if (t < 0) continue;
+                        const int k = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
+                        if (t == 0) ++l3;
+                        for (int r = 0; r < k; ++r) {
+                            comps |= static_cast<uint32_t>(d | (t << 2)) << (4 * n_comp);
+                            ++n_comp;
+                            if (state == 0) state += cond;
+                            else if (state <= 2) state += cond + 1;
+                            else { triple = 1; state += (state == 5) ? 0 : cond - 1; }
+                        }
+                    }
+                    const int ctype = state - 3;
+                    if (ctype < 0 || ctype > 2) { s_misc[2] = 1; continue; }               // reference reads out of bounds here
+                    atomicAdd(&s_misc[12 + ctype], c ? 0x10000u : 1u);
+                    const int g_own = c ? 3 : 0, g_opp = c ? 2 : 1;
+                    atomicAdd(&s_scores[g_own * kCells + q], 600u * n_comp);               // updateCritical, both perspectives
+                    atomicAdd(&s_scores[g_opp * kCells + q], 600u * n_comp);
+                    if (triple || l3) continue;
+                    for (int i = 0; i < n_comp; ++i) {                                     // queue the counter-move rescans
+                        const uint32_t cd = (comps >> (4 * i)) & 15u;
+                        const uint32_t slot = atomicAdd(&s_misc[3], 1u);
+                        if (slot < kQueueCap / 2) s_queue[kQueueCap / 2 + slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(c) << 8) | (cd << 9);
+                        else s_misc[2] = 1;
+                    }
+                }
+            }
+            wave_phase_fence();
+
+            // ---- phase 4: the counter-move cells of every compound component: the FIRST match of its type that runs through
+            //      the cell with a blank there (Compound::updateAntis, Pattern.cpp:520-543), scanning the 13-symbol window
+            //      centred on the cell.  Such a match ends at window index 6..12; eight lanes share a component, lane kk looks
+            //      at the transition at index 6 + kk only (the automaton forgets its start state after 7 symbols, so <= 8
+            //      lookups from the root bring it to the right state), and the lowest lane with a hit applies it ----
+            if (phase_mask & 16) {
+                const int n_comp = min(static_cast<int>(s_misc[3]), kQueueCap / 2);
+                for (int m0 = 0; m0 < n_comp; m0 += 8) {
+                    const int m = m0 + (lane >> 3), kk = lane & 7, k = 6 + kk;
+                    const uint32_t ent = m < n_comp ? s_queue[kQueueCap / 2 + m] : 0u;
+                    const int q = ent & 255, c = (ent >> 8) & 1, dir = (ent >> 9) & 3, tslot = (ent >> 11) & 3;
+                    const int want = tslot == 0 ? 5 : tslot == 1 ? 4 : 3;
+                    const int x = q % 15, y = q / 15, stride = dir_stride(dir);
+                    uint32_t hit_w0 = 0;
+                    int hit_back = -1;
+                    if (m < n_comp && kk < 7) {
+                        // the line through q in this direction: its word, q's position on it, its length
+                        const int diag = x - y + 14, anti = x + y;
+                        const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
+                        const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
+                        const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
+                        // six '?' | cells | six '?', then the 13 symbols starting six before q
+                        const uint64_t syms = (0xAAAull | (static_cast<uint64_t>(s_lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
+                        const int start = k > 7 ? k - 7 : 0;
+                        uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;      // kept shifted left by 2 as in phase 1
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(lds_bytes + ((tw & 0x3FFFu) | (cur & 12u)));
+                            cur >>= 2;
+                        }
+                        if ((gmk::dev_trans_kinds(tw) >> tslot) & 1u) {                     // the record holds the wanted type
+                            const uint4 rec = s_rec[gmk::dev_trans_record(tw)];
+                            hit_back = counter_match(rec.x, k, want);
+                            hit_w0 = rec.x;
+                            if (hit_back < 0) { hit_back = counter_match(rec.z, k, want); hit_w0 = rec.z; }
+                        }
+                    }
+                    const unsigned long long hits = __ballot(hit_back >= 0);
+                    const uint32_t mine = static_cast<uint32_t>(hits >> (lane & ~7)) & 0xFFu;
+                    if (hit_back >= 0 && (mine & ((1u << kk) - 1u)) == 0u) add_counter_cells(hit_w0, hit_back, q, stride, s_scores + (c ? 2 : 1) * kCells);
+                }
+            }
+            wave_phase_fence();
+
         }
-        wave_phase_fence();
+
+        asm volatile("" : "+v"(next_black), "+v"(next_white));    // the wait for the next board's planes (a use the compiler must honour)
+
+        // ---- phase D, part 2: the group's density planes leave, in the board iteration that is this wavefront's turn ----
+        if (planes_out && bi == wave) {
+            int lane_p = lane0, first_p = first_board;         // opaque copies: what the passes derive from them is computed here, not kept
+            asm volatile("" : "+v"(lane_p), "+s"(first_p));     // in registers from the top of the group
+            density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
+        }
+        if (!live) {
+            if (!planes_out || bi >= wave) break;
+            continue;
+        }
 
         // ---- phase 5: results leave LDS ----
         if (live && (phase_mask & 32)) {
+            int lane_b = lane;                                  // (a copy the compiler cannot see through: the store addresses are computed here,
+            asm volatile("" : "+v"(lane_b));                    // not kept in registers across the density pass)
             if (out_scores) {
                 int4* dst = reinterpret_cast<int4*>(out_scores + static_cast<size_t>(board) * kScoreWords);
                 const int4* src = reinterpret_cast<const int4*>(s_scores);
@@ -706,32 +701,34 @@ int upload_lane_jobs() {
     return GMK_OK;
 }
 
-// The weight operands of phase D in lane order: step s (plane kind count / weight, M tile m, K tile kt),
-// lane l = (cell 32 m + (l & 31), k half h = l >> 5), byte j = the tap from cell (row 2 kt + h, column j) to that cell.
-int upload_density_operands(int8_t** d_out) {
-    std::vector<int8_t> a(static_cast<size_t>(kDensSteps) * 64 * 16, 0);
-    int step = 0;
+// The weight table of phase D (kWtab*): [plane kind: count, weight][dy + 6][xo] x 16 bytes, byte j = the tap from column j of a row
+// dy below the cell's to a cell in column xo: BlockWeights (Pattern.cpp:598-609) at (dy, j - xo), its non-zero mask for the count planes.
+int upload_density_weights(uint32_t** d_out) {
+    std::vector<int8_t> t(static_cast<size_t>(kWtabWords) * 4, 0);
     for (int kind = 0; kind < 2; ++kind)
-        for (int m = 0; m < kDensTiles; ++m)
-            for (int kt = dens_kt_lo(m); kt <= dens_kt_hi(m); ++kt, ++step)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 16; ++j) {
-                        const int cell = 32 * m + (l & 31), yo = cell / 15, xo = cell % 15, y = 2 * kt + (l >> 5), x = j;
-                        const int dy = y - yo, dx = x - xo;
-                        if (y > 14 || x > 14 || std::abs(dy) > 3 || std::abs(dx) > 3) continue;
-                        const int w = block_weight(dy, dx);
-                        a[(static_cast<size_t>(step) * 64 + l) * 16 + j] = static_cast<int8_t>(kind == 0 ? (w != 0) : w);
-                    }
-    if (step != kDensSteps) { gmk::set_error("density operand table: %d steps, expected %d", step, kDensSteps); return GMK_ERR_STATE; }
-    // every tap of every cell must lie in one of the K tiles its M tile visits
+        for (int dy = -3; dy <= 3; ++dy)
+            for (int xo = 0; xo < 15; ++xo)
+                for (int j = 0; j < 15; ++j) {
+                    if (std::abs(j - xo) > 3) continue;
+                    const int w = block_weight(dy, j - xo);
+                    t[((static_cast<size_t>(kind) * kWtabDy + dy + 6) * 15 + xo) * 16 + j] = static_cast<int8_t>(kind == 0 ? (w != 0) : w);
+                }
+    // every row offset a lane can ask for lies inside the table: dy = 2 kt + h - yo for the K tiles its M tile visits
+    for (int cell = 0; cell < 224; ++cell)
+        for (int kt = dens_kt_lo(cell / 32); kt <= dens_kt_hi(cell / 32); ++kt)
+            for (int h = 0; h < 2; ++h) {
+                const int dy = 2 * kt + h - cell / 15;
+                if (dy < -6 || dy > 6) { gmk::set_error("density weight table: dy %d of cell %d out of range", dy, cell); return GMK_ERR_STATE; }
+            }
+    // ... and every tap of every cell lies in one of the K tiles its M tile visits
     for (int cell = 0; cell < 224; ++cell)
         for (int dy = -3; dy <= 3; ++dy) {
             const int y = cell / 15 + dy, m = cell / 32;
             if (y < 0 || y > 14) continue;
-            if (y / 2 < dens_kt_lo(m) || y / 2 > dens_kt_hi(m)) { gmk::set_error("density operand table: row %d of cell %d is not covered", y, cell); return GMK_ERR_STATE; }
+            if (y / 2 < dens_kt_lo(m) || y / 2 > dens_kt_hi(m)) { gmk::set_error("density weight table: row %d of cell %d is not covered", y, cell); return GMK_ERR_STATE; }
         }
-    GMK_HIP_CHECK(hipMalloc(d_out, a.size()));
-    GMK_HIP_CHECK(hipMemcpy(*d_out, a.data(), a.size(), hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMalloc(d_out, t.size()));
+    GMK_HIP_CHECK(hipMemcpy(*d_out, t.data(), t.size(), hipMemcpyHostToDevice));
     return GMK_OK;
 }
 
@@ -746,7 +743,7 @@ Launch plan_launch(int n, const gmk::DeviceState& st) {
 }
 
 bool g_jobs_uploaded = false;
-int8_t* g_dens_a = nullptr;
+uint32_t* g_wtab = nullptr;
 
 }  // namespace
 
@@ -759,7 +756,7 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
     if (!g_jobs_uploaded) {
         int rc = upload_lane_jobs();
         if (rc != GMK_OK) return rc;
-        rc = upload_density_operands(&g_dens_a);
+        rc = upload_density_weights(&g_wtab);
         if (rc != GMK_OK) return rc;
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_positions_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_jobs_uploaded = true;
@@ -769,7 +766,7 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
     static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x7F;
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
                        d_planes, n, l.n_groups, d_scores, d_density, d_totals, d_status,
-                       st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, reinterpret_cast<const v4i*>(g_dens_a), phase_mask);
+                       st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, g_wtab, phase_mask);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }

@@ -1,10 +1,14 @@
 #!/bin/bash
-# VALU / SALU / LDS wave-instructions per board of K1 with phases 0..p enabled (profiling aid).
+# K1 per-phase figures (profiling aid): kernel time and VALU / SALU / LDS wave-instructions per board with subsets of the phases
+# enabled (GMK_EVAL_PHASE_MASK: 1 phase 0, 2 scan, 4 deposits, 8 phase 3, 16 rescans, 32 score stores, 64 phase D;
+# 512 density passes without their stores, 1024 no density passes).  Results are wrong unless the mask is 127.
 cd "${GRAFT_REPO_ROOT:-.}" && export TMPDIR=/tmp
 out=gpurun_out/pmc_k1p; rm -rf $out; mkdir -p $out
-for m in ${MASKS:-1 3 7 15 31 63}; do
-  GMK_EVAL_PHASE_MASK=$m timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES -d $out/m_$m -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --mcts-games 0 --no-cpu-baseline > $out/run_$m.log 2>&1 || { echo "mask $m failed"; tail -5 $out/run_$m.log; exit 1; }
-  python3 - $m <<'PY'
+export GMK_EVAL_REPS=20
+for m in ${MASKS:-1 3 7 15 31 63 127 1151 639}; do
+  t=$(GMK_EVAL_PHASE_MASK=$m GMK_EVAL_REPS=100 timeout -k 10 120 python3 tools/eval_time.py all | tail -1)
+  GMK_EVAL_PHASE_MASK=$m timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $out/m_$m -o p --output-format csv -- python3 tools/eval_time.py all > $out/run_$m.log 2>&1 || { echo "mask $m failed"; tail -5 $out/run_$m.log; exit 1; }
+  python3 - $m "$t" <<'PY'
 import csv, glob, collections, sys
 m = sys.argv[1]
 v = collections.defaultdict(list)
@@ -12,6 +16,7 @@ for p in glob.glob("gpurun_out/pmc_k1p/m_%s/**/*counter_collection.csv" % m, rec
     for r in csv.DictReader(open(p)):
         if "eval_positions" in r["Kernel_Name"]:
             v[r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("mask", m, " ".join("%s %.1f" % (k[3:], sum(x) / len(x) / 65536) for k, x in sorted(v.items())))
+print("mask %5s  %s  " % (m, sys.argv[2]) + " ".join("%s %.1f" % (k[3:], sum(x) / len(x) / 65536) for k, x in sorted(v.items())))
 PY
+  rm -rf $out/m_$m
 done
