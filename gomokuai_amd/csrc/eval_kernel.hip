@@ -58,9 +58,9 @@ constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560;   // lane jobs,
 // Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
 __constant__ uint32_t c_line_init[kLineWords];   // all cells blank: (1 << 2 len) - 1
-__constant__ int c_scan_steps;
+constexpr int kScanSteps = 19;                    // symbols in the longest lane stream (upload_lane_jobs checks it)
 
-__device__ __forceinline__ int dir_stride(int dir) { return dir == 0 ? 1 : dir == 1 ? 15 : dir == 2 ? 16 : 14; }
+__device__ __forceinline__ int dir_stride(int dir) { return (0x0E100F01u >> (8 * dir)) & 0xFFu; }      // 1, 15, 16, 14: a shift, not three branches
 
 // '?' cells '?' '?' of one line as a symbol stream, first symbol in the low bits: exactly 2 * (len + 3) bits
 // (1 leading + 2 trailing pads instead of the reference's 6 + 6; '?' = 2 is the off-board symbol)
@@ -72,6 +72,11 @@ __device__ __forceinline__ uint64_t line_symbols(uint32_t line_word, int len) {
 // one wave execute in issue order, so all that is needed between phases is that the compiler keeps the order:
 // a wavefront-scope fence (no instruction) instead of a workgroup barrier, which would make the independent
 // boards of a block wait for each other at every phase.
+// the 32-bit word at a byte address of LDS (no base added: the staged automaton starts at address 0)
+__device__ __forceinline__ const __attribute__((address_space(3))) uint32_t* lds_word(uint32_t byte_address) {
+    return reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(byte_address));
+}
+
 __device__ __forceinline__ void wave_phase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -369,8 +374,6 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     uint32_t* s_misc = s_queue + kQueueCap;
 
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
-    const int scan_steps = c_scan_steps;
-    const char* lds_bytes = reinterpret_cast<const char*>(lds);           // the transition table starts at LDS address 0
 
     // groups of sixteen boards: consecutive groups go to different workgroups first (small batches still use every CU)
     for (int group = blockIdx.x + gridDim.x * wave; group < n_groups; group += gridDim.x * kBoardsPerBlock) {
@@ -425,7 +428,16 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             if (lane < kMiscWords) s_misc[lane] = 0;
             const uint32_t my_row = take_row(board);
             wave_phase_fence();
-            if (lane < 15) atomicAdd(&s_misc[0], static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16));
+            {
+                // stones per colour: a row reduction in registers (an atomicAdd of fifteen lanes on one word is turned by the compiler
+                // into a serial loop over those lanes)
+                uint32_t cnt = static_cast<uint32_t>(__popc(my_row & 0x7FFFu)) | (static_cast<uint32_t>(__popc(my_row >> 16)) << 16);
+                cnt += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(cnt), 0x118, 0xF, 0xF, false));       // row_shr:8
+                cnt += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(cnt), 0x114, 0xF, 0xF, false));       // row_shr:4
+                cnt += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(cnt), 0x112, 0xF, 0xF, false));       // row_shr:2
+                cnt += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(cnt), 0x111, 0xF, 0xF, false));       // row_shr:1
+                if (lane == 15) s_misc[0] = cnt;                // lane 15 holds the sum of lanes 0 .. 15 (my_row is zero in lane 15)
+            }
             {
                 // a stone turns its cell's blank (3) into black (0) or white (1) in the four lines through it: one XOR each.
                 // Four lanes share a row (cells 0-3, 4-7, 8-11, 12-14), so the loop runs as long as the fullest quarter row.
@@ -460,18 +472,20 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 uint32_t cur = static_cast<uint32_t>(syms) << 2;    // symbols 0..14 at bits 2..31
                 const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2..
                 uint32_t tw = 0;                                    // the previous step's table word (row 0 = root)
-                for (int step = 0; step < scan_steps; ++step) {
+#pragma unroll
+                for (int step = 0; step < kScanSteps; ++step) {
                     if (step == 15) cur = rest;
                     const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
                     cur >>= 2;
-                    tw = *reinterpret_cast<const uint32_t*>(lds_bytes + addr);
+                    tw = *lds_word(addr);                       // (the table is at LDS address 0: the address is used as it is)
                     const uint32_t rec = gmk::dev_trans_record(tw);
                     const unsigned long long emitters = __ballot(rec != 0u);
                     if (emitters) {
                         if (rec) {
                             const int slot = n_queued + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
                                                                          __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u)));
-                            if (slot < kQueueCap) s_queue[slot] = rec | lane_tag | (static_cast<uint32_t>(step) << 16);
+                            // (beyond the capacity every entry lands on the last slot: the board is flagged below)
+                            s_queue[min(slot, kQueueCap - 1)] = rec | (lane_tag + (static_cast<uint32_t>(step) << 16));
                         }
                         n_queued += __popcll(emitters);
                     }
@@ -611,7 +625,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                         uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;      // kept shifted left by 2 as in phase 1
     #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            if (start + i <= k) tw = *reinterpret_cast<const uint32_t*>(lds_bytes + ((tw & 0x3FFFu) | (cur & 12u)));
+                            if (start + i <= k) tw = *lds_word((tw & 0x3FFFu) | (cur & 12u));
                             cur >>= 2;
                         }
                         if ((gmk::dev_trans_kinds(tw) >> tslot) & 1u) {                     // the record holds the wanted type
@@ -697,7 +711,7 @@ int upload_lane_jobs() {
     for (int d = 0; d <= 28; ++d) init[kDiagBase + d] = init[kAntiBase + d] = (1u << (2 * (15 - std::abs(d - 14)))) - 1u;
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_line_init), init, sizeof init));
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lane_jobs), jobs, sizeof jobs));
-    GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_scan_steps), &steps, sizeof steps));
+    if (steps != kScanSteps) { gmk::set_error("lane jobs: %d scan steps, the kernel is built for %d", steps, kScanSteps); return GMK_ERR_STATE; }
     return GMK_OK;
 }
 
