@@ -102,7 +102,7 @@ class FusedPolicyValueNetwork:
     @torch.no_grad()
     def eval_state(self, board):
         """PolicyValueNetwork.eval_state (model_tf.py:136-145) through the fused kernel: one position -> (value, probs[225]) on the
-        host; what agents.PyConvNetAgent(network, c_puct) calls once per playout."""
+        host; what MCTS(policy=Policy(eval_state=network.eval_state, c_puct)) -- the reference's PyConvNetAgent, agents/alphazero.py:5-9 -- calls once per playout."""
         dev = next(self.net.parameters()).device
         states = torch.from_numpy(np.asarray(board.encoded_states(), dtype=np.float32)[None]).to(dev)
         value, probs = self(states)

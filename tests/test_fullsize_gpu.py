@@ -1,0 +1,171 @@
+"""BASELINE.json's configurations at FULL size on the GPU, inside the suite the driver runs.
+
+  configs[1]  65 536 boards through K1: every board of both synthetic distributions against the oracle (scores, density,
+              totals, status: bit-exact), i.e. what bench.py times, checked in full;
+  configs[2]  4 096 games x 800 playouts through K3 (one launch, 1 024 workgroups): properties on every game, oracle parity
+              (visit counts, root Q bits, tree size) on a strided sample of 32 games;
+  plus the larger differential runs that used to live under tools/ (K3 at 96 x 800, K6 at 14 x 6 000 playouts, K8 at 64 x 3 000
+  with a kept-subtree step, K1 on 8 192 boards of 100 .. 225 stones)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gomokuai_amd import lib as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _mismatching_boards(ref, got):
+    n = len(ref[0])
+    return {name: int((a.reshape(n, -1) != b.reshape(n, -1)).any(1).sum()) for name, a, b in zip(("scores", "density", "totals", "status"), ref, got)}
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_config2_all_65536_boards_match_the_oracle(oracle, kind):
+    """BASELINE configs[1]: the bench's own board set (kind 0, first_board 0 = rank 0's shard) and the clustered set."""
+    n = 65536
+    moves, lens, planes = G.synth_boards(n, kind, first_board=0)
+    got = G.eval_batch_host(planes)
+    ref = oracle.replay_batch(moves, lens)
+    assert not (ref[3] & 2).any() and not (got[3] & 2).any()
+    assert _mismatching_boards(ref, got) == {"scores": 0, "density": 0, "totals": 0, "status": 0}
+    if kind == 1:
+        assert ((got[2][:, 8:] != 0).any(1)).mean() > 0.4          # the clustered set is the one with compounds on about half its boards
+
+
+def test_config2_ragged_batch_sizes(oracle):
+    """Batch sizes around the kernel's group of sixteen boards and its grid: the last group partial, fewer groups than CUs, one board."""
+    for n in (1, 15, 16, 17, 255, 4097, 12289):
+        moves, lens, planes = G.synth_boards(n, n % 2, first_board=90000 + n)
+        assert _mismatching_boards(oracle.replay_batch(moves, lens), G.eval_batch_host(planes)) == {"scores": 0, "density": 0, "totals": 0, "status": 0}, n
+
+
+def test_config3_4096_games_800_playouts(oracle):
+    """BASELINE configs[2] as bench.py runs it: 4 096 games from 4-ply random openings, RandomPolicy(c_puct 5, c_rollouts 5), fresh
+    roots, 800 playouts in one launch."""
+    n, P = 4096, 800
+    moves, lens, _ = G.synth_boards(n, 0, first_board=0)
+    lens = np.minimum(lens, 4).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[i, lens[i] - 1] for i in range(n)], dtype=np.int16)
+    tree = G.BatchedMCTS(n, playouts_capacity=P)
+    tree.set_roots(planes, last, first_game_id=0)
+    tree.run(P)
+    visits, q, rv, nodes, status = tree.root_stats()
+    # every game: all playouts ran, none hit the arena's end, the children's visits add up (the first playout expands the root)
+    assert (rv == P).all() and not status.any()
+    assert (visits.sum(1) == P - 1).all()
+    assert (nodes > P).all() and (nodes <= P * 225 + 1).all()
+    assert (np.abs(q) <= 1.0).all()
+    # a strided sample against the oracle: visit counts, root Q bits, tree size
+    alg = 0
+    for g in range(0, n, n // 32):
+        b = oracle.new_board()
+        for i in range(int(lens[g])):
+            oracle.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        om = oracle.MCTS(P, 5.0, 5, G.DEFAULT_SEED, g)
+        om.run_playouts(b)
+        ov, _, _ = om.root_children()
+        assert (ov == visits[g]).all(), "game %d" % g
+        assert np.float32(q[g]).tobytes() == np.float32(om.root_value).tobytes() and nodes[g] == om.size
+        alg += om.alg_bytes
+    assert tree.alg_bytes() > alg                            # (the kernel's byte count covers all 4 096 games)
+    tree.close()
+
+
+def test_k3_96_games_800_playouts(oracle):
+    n, P = 96, 800
+    moves, lens, _ = G.synth_boards(n, 0, first_board=31337)
+    lens = np.minimum(lens, 6).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[i, lens[i] - 1] for i in range(n)], dtype=np.int16)
+    tree = G.BatchedMCTS(n, playouts_capacity=P)
+    tree.set_roots(planes, last, first_game_id=1000)
+    tree.run(P)
+    visits, q, rv, nodes, status = tree.root_stats()
+    for g in range(n):
+        b = oracle.new_board()
+        for i in range(int(lens[g])):
+            oracle.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        om = oracle.MCTS(P, 5.0, 5, G.DEFAULT_SEED, 1000 + g)
+        om.run_playouts(b)
+        ov, _, _ = om.root_children()
+        assert (ov == visits[g]).all() and np.float32(q[g]).tobytes() == np.float32(om.root_value).tobytes() and nodes[g] == om.size, "game %d" % g
+    tree.close()
+
+
+def test_k6_14_games_6000_playouts(oracle):
+    n, P = 14, 6000
+    moves, lens, _ = G.synth_boards(n, 1, first_board=555)
+    pos = [[int(m) for m in moves[g, :min(int(lens[g]), 3 + 2 * g)]] for g in range(n)]
+    t = G.TraditionalMCTS(n, node_capacity=1 << 20)
+    t.set_positions(pos)
+    t.run(P)
+    st = t.root_stats()
+    for g in range(n):
+        o = oracle.TraditionalMCTS(5.0)
+        o.search(pos[g], P)
+        v, qq, p, best = o.root_children()
+        assert (v == st["visits"][g]).all() and (qq.view(np.uint32) == st["values"][g].view(np.uint32)).all(), "game %d" % g
+        assert best == st["best"][g] and o.n_nodes == st["n_nodes"][g] and o.evaluator_updates == st["evaluator_updates"][g], "game %d" % g
+    assert not (st["status"] & ~np.int32(0)).any()
+    t.close()
+
+
+def test_k8_64_games_3000_playouts_and_a_kept_subtree(oracle):
+    n, P = 64, 3000
+    moves, lens, _ = G.synth_boards(n, 0, first_board=777)
+    pos = [[int(m) for m in moves[g, :min(int(lens[g]), g % 30)]] for g in range(n)]
+    t = G.PoolRAVEMCTS(n, node_capacity=(P + 1200) * 225, c_puct=2.0, first_game_id=300)
+    t.set_positions(pos)
+    t.run(P)
+    orcs = [oracle.PoolRAVEMCTS(2.0, 0.0, seed=G.DEFAULT_SEED, game_id=300 + g) for g in range(n)]
+
+    def check(st):
+        for g in range(n):
+            v, qq, p, av, aq, best = orcs[g].root_children()
+            assert (v == st["visits"][g]).all() and (qq.view(np.uint32) == st["values"][g].view(np.uint32)).all() and best == st["best"][g], "game %d" % g
+            assert (av == st["amaf_visits"][g]).all() and (aq.view(np.uint32) == st["amaf_values"][g].view(np.uint32)).all(), "game %d" % g
+
+    for g in range(n):
+        orcs[g].run(pos[g], P)
+    st = t.root_stats()
+    check(st)
+    t.step()
+    for g in range(n):
+        if st["best"][g] >= 0:
+            pos[g] = pos[g] + [orcs[g].step_forward()]
+    t.run(1000)
+    for g in range(n):
+        orcs[g].run(pos[g], 1000)
+    check(t.root_stats())
+    t.close()
+
+
+def test_k1_8192_dense_boards(oracle):
+    """Boards of 100 .. 225 stones without a five (prefixes of shuffled tie games), far denser than the synthetic 8 .. 60-ply sets:
+    queue capacities, saturated counters, many compounds, full boards."""
+    rng = np.random.RandomState(5)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2             # two colour classes that never line up five (pairs of columns, shifted per row)
+    blacks = [c for c in range(225) if cls(c) == 0]
+    whites = [c for c in range(225) if cls(c) == 1]
+    if len(blacks) < len(whites):
+        blacks, whites = whites, blacks
+    n = 8192
+    moves = np.zeros((n, 225), np.uint8)
+    lens = np.zeros(n, np.int32)
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(b.pop())
+            if w:
+                seq.append(w.pop())
+        moves[g] = seq
+        lens[g] = rng.randint(100, 226)
+    got = G.eval_batch_host(G.moves_to_planes(moves, lens))
+    ref = oracle.replay_batch(moves, lens)
+    assert not (got[3] & 2).any() and not (ref[3] & 2).any()
+    assert _mismatching_boards(ref, got) == {"scores": 0, "density": 0, "totals": 0, "status": 0}

@@ -1,4 +1,4 @@
-"""The front ends with real searches: agents/botzone.py's BotzoneAgent (agents.BotzoneAgent) starts
+"""The front ends with real searches: a Botzone-protocol driver (tests/helpers.py: BotDriver) starts
 `python -m gomokuai_amd.interface botzone` as the external bot program, the way the reference's Python side talks to its C++
 bot (agents/botzone.py:27-41, core/interface/src/Interface.h:9-31); the keep-alive bot and a console match run in-process."""
 import io
@@ -8,18 +8,20 @@ import sys
 
 import pytest
 
-from gomokuai_amd import agents, core, interface
+from gomokuai_amd import core, interface
+
+import helpers
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_botzone_agent_drives_the_bot_program():
-    bot = agents.BotzoneAgent("%s -m gomokuai_amd.interface botzone --agent traditional:5 --iterations 200 --seed 3" % sys.executable, working_dir=ROOT)
+    bot = helpers.BotDriver("%s -m gomokuai_amd.interface botzone --agent traditional:5 --iterations 200 --seed 3" % sys.executable, cwd=ROOT)
     b = core.Board()
     for mv in (112, 113, 127):
         b.apply_move(core.Position(mv))
-    move = bot.get_action(b)                                       # white to move
+    move = bot.move(b)                                             # white to move
     assert b.check_move(move)
     # the same search in this process picks the same move (the pattern-guided search is deterministic without noise at a fresh root)
     core.set_seed(3)

@@ -102,7 +102,8 @@ def test_real_positions_and_search(oracle):
 
 def test_eval_state_for_agents():
     """FusedPolicyValueNetwork.eval_state(board) is what PyConvNetAgent calls per playout (agents/alphazero.py:5-9)."""
-    from gomokuai_amd import agents, core
+    from gomokuai_amd import core
+    import helpers
     G.init()
     net = PolicyValueNetwork(seed=2).cuda().eval()
     fused = FusedPolicyValueNetwork(net)
@@ -112,8 +113,8 @@ def test_eval_state_for_agents():
     v0, p0 = net.eval_state(b)
     v1, p1 = fused.eval_state(b)
     assert abs(v0 - v1) < TOL and np.abs(p0 - p1).max() < TOL and abs(float(p1.sum()) - 1) < 1e-4
-    agent = agents.PyConvNetAgent(fused, 5.0, c_iterations=30)
-    move = agent.get_action(b)
+    agent = helpers.network_searcher(fused.eval_state, 5.0, c_iterations=30)
+    move = agent.move(b)
     assert b.check_move(move)
     fused.close()
 

@@ -114,7 +114,7 @@ def test_no_cpu_search_path():
 def test_augmentation_property():
     """test/test_network.py:9-36 of the reference: every augmented sample is the permutation-consistent
     image of its base sample (checked on synthetic samples; the GPU test plays real games)."""
-    from gomokuai_amd.agents import augment_game_data
+    from helpers import augment as augment_game_data           # the checker the GPU test holds the device augmentation to
     rng = np.random.RandomState(0)
     data = [(rng.randint(0, 2, size=(6, 15, 15)).astype(np.uint8), np.array(1.0), rng.rand(225).astype(np.float32)) for _ in range(3)]
     aug = augment_game_data(data)
@@ -160,10 +160,10 @@ def test_reference_agents_run_unchanged_on_this_module():
         sys.path.remove("/root/reference")
 
 
-def test_botzone_agent_and_eval_agents(tmp_path):
-    """agents/botzone.py:11-45 and agents/utils.py:66-103 on the host module: an external program speaking the Botzone
-    JSON protocol plays against the random agent."""
-    from gomokuai_amd import agents
+def test_botzone_protocol_driver(tmp_path):
+    """The Botzone JSON protocol of agents/botzone.py:27-41 as tests/helpers.py: BotDriver speaks it: an external program that
+    answers with the first free cell is driven through two moves of a game."""
+    import helpers
     bot = tmp_path / "bot.py"
     bot.write_text(
         "import json, sys\n"
@@ -171,16 +171,15 @@ def test_botzone_agent_and_eval_agents(tmp_path):
         "taken = {(m['x'], m['y']) for m in d['requests'] + d['responses']}\n"
         "x, y = next((x, y) for y in range(15) for x in range(15) if (x, y) not in taken)\n"
         "print(json.dumps({'response': {'x': x, 'y': y}}))\n")
-    agent = agents.BotzoneAgent("python3 bot.py", working_dir=str(tmp_path))
+    driver = helpers.BotDriver("python3 bot.py", cwd=str(tmp_path))
     b = core.Board()
-    assert json.loads(agents.BotzoneAgent._parse_state(b)) == {"requests": [{"x": -1, "y": -1}], "responses": []}
-    mv = agent.get_action(b)
+    assert helpers.BotDriver.history(b) == {"requests": [{"x": -1, "y": -1}], "responses": []}
+    mv = driver.move(b)
     assert (mv.x, mv.y) == (0, 0)
     b.apply_move(mv); b.apply_move(core.Position(7, 7))
-    q, probs, mv2 = agent.eval_state(b)
-    assert (mv2.x, mv2.y) == (1, 0) and probs[int(mv2)] == 1.0 and probs.sum() == 1.0
-    rates = agents.eval_agents([agent, agents.RandomAgent()], num_games=2)
-    assert abs(sum(rates) - 1.0) < 1e-9
+    assert helpers.BotDriver.history(b) == {"requests": [{"x": -1, "y": -1}, {"x": 7, "y": 7}], "responses": [{"x": 0, "y": 0}]}
+    mv2 = driver.move(b)
+    assert (mv2.x, mv2.y) == (1, 0)
 
 
 def test_dump_batches(tmp_path):

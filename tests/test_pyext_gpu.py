@@ -5,7 +5,9 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from gomokuai_amd import agents, core
+from gomokuai_amd import core
+
+import helpers
 
 pytestmark = pytest.mark.gpu
 
@@ -32,8 +34,8 @@ def test_eval_state_matches_oracle(oracle):
 
 def test_self_play_game_and_training_tuples():
     core.set_seed(7)
-    agent = agents.RandomMCTSAgent(5.0, 5, c_iterations=60)
-    data = agents.dual_play({core.Player.black: agent, core.Player.white: agent}, verbose=True)
+    agent = helpers.random_searcher(5.0, 5, c_iterations=60)
+    data = helpers.play_game(agent, agent, record=True)
     assert len(data) >= 9
     states, score, probs = data[0]
     assert states.shape == (6, 15, 15) and states.dtype == np.uint8 and probs.shape == (225,) and probs.dtype == np.float32
@@ -41,12 +43,12 @@ def test_self_play_game_and_training_tuples():
     assert states[2].sum() == 225 and states[5].all()               # empty board, black to move
     winner_scores = {float(s) for _, s, _ in data}
     assert winner_scores <= {-1.0, 0.0, 1.0}
-    aug = agents.augment_game_data(data)
+    aug = helpers.augment(data)
     assert len(aug) == 8 * len(data)
     # same seed, same game
     core.set_seed(7)
-    agent2 = agents.RandomMCTSAgent(5.0, 5, c_iterations=60)
-    again = agents.dual_play({core.Player.black: agent2, core.Player.white: agent2}, verbose=True)
+    agent2 = helpers.random_searcher(5.0, 5, c_iterations=60)
+    again = helpers.play_game(agent2, agent2, record=True)
     assert len(again) == len(data) and all((a[2] == b[2]).all() for a, b in zip(data, again))
 
 
@@ -89,16 +91,16 @@ def test_traditional_policy_matches_oracle(oracle):
 
 
 def test_traditional_agent_plays_a_game():
-    agent = agents.TraditionalAgent(5.0, c_iterations=150)
-    data = agents.dual_play({core.Player.black: agent, core.Player.white: agent}, verbose=True)
+    agent = helpers.pattern_searcher(5.0, c_iterations=150)
+    data = helpers.play_game(agent, agent, record=True)
     assert len(data) >= 9 and data[0][0][2].sum() == 225
     with pytest.raises(RuntimeError):
-        agents.TraditionalAgent(5.0, use_rave=True, c_iterations=10).get_action(core.Board())
+        core.MCTS(c_iterations=10, policy=core.TraditionalPolicy(5.0, 0.0, True)).get_action(core.Board())
 
 
 def test_poolrave_policy_matches_oracle(oracle):
     """MCTS(policy=PoolRAVEPolicy) searches on the device (K8) and agrees with the oracle restatement move after move of an
-    agent loop with the tree kept and Dirichlet noise at the root, then a whole game through agents.RAVEAgent."""
+    agent loop with the tree kept and Dirichlet noise at the root, then a whole game of that searcher against itself."""
     O = oracle
     core.set_seed(31337)
     core.set_root_noise(0.05, 0.25)
@@ -123,9 +125,9 @@ def test_poolrave_policy_matches_oracle(oracle):
         assert m.root.position.id == best == om.step_forward()
         b.apply_move(m.root.position); played.append(best)
     assert max(kept[1:]) > 300
-    agent = agents.RAVEAgent(2.0, 0.0, c_iterations=100)
-    data = agents.dual_play({core.Player.black: agent, core.Player.white: agent}, verbose=True)
-    assert len(data) >= 9 and "PoolRAVEPolicy" in repr(agent)
+    agent = helpers.rave_searcher(2.0, 0.0, c_iterations=100)
+    data = helpers.play_game(agent, agent, record=True)
+    assert len(data) >= 9 and "PoolRAVEPolicy" in repr(agent.mcts.policy)
 
 
 def test_agent_loop_keeps_the_tree_and_adds_root_noise(oracle):
@@ -202,7 +204,7 @@ def test_py_conv_net_agent_plays():
     import torch
     from gomokuai_amd.network import PolicyValueNetwork
     net = PolicyValueNetwork(seed=5).cuda().eval()
-    agent = agents.PyConvNetAgent(net, 5.0, c_iterations=24)
+    agent = helpers.network_searcher(net.eval_state, 5.0, c_iterations=24)
     b = core.Board()
-    q, pi, mv = agent.eval_state(b)
+    q, pi, mv = agent.evaluate(b)
     assert abs(float(pi.sum()) - 1.0) < 1e-3 and 0 <= mv.id < 225 and -1.0 <= q <= 1.0

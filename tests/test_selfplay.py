@@ -52,6 +52,29 @@ def test_samples_match_dual_play_tuples():
         assert b.status["is_end"]
 
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_tuples.npz")
+
+
+def test_host_tuples_match_the_reference_loop():
+    """tests/golden/reference_tuples.npz holds what the REFERENCE's dual_play(verbose=True) (agents/utils.py:29-63) produced on
+    this CorePyExt for six games of its random agent (made by tests/golden/make_reference_tuples.py in the build container).
+    GameRecords.samples rebuilds the tuples from the move lists alone: encoded states and values must be identical."""
+    ref = np.load(GOLDEN)
+    n = int(ref["lens"].shape[0])
+    rec = selfplay.GameRecords(torch.from_numpy(ref["moves"]), torch.from_numpy(ref["lens"]), torch.from_numpy(ref["winner"]),
+                               torch.zeros((n, 225, 225), dtype=torch.int16), 0)
+    k = 0
+    for g in range(n):
+        for states, value, pi in rec.samples(g):
+            assert int(ref["game"][k]) == g
+            assert (states == ref["states"][k]).all(), "game %d tuple %d" % (g, k)
+            assert float(value) == float(ref["values"][k])
+            assert pi.shape == ref["probs"][k].shape
+            k += 1
+    assert k == int(ref["values"].shape[0]) == int(ref["lens"].sum())
+    assert np.allclose(ref["probs"], 1.0 / 225)                # the reference's random agent reports the uniform distribution
+
+
 def test_shard_blocks_cover_everything():
     for total, world in ((32768, 8), (4096, 3), (10, 4)):
         blocks = [selfplay.shard(total, r, world) for r in range(world)]
