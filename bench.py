@@ -24,6 +24,14 @@ def measured_traffic(kernel, units_key, units):
         return None
 
 
+def measured_counter(kernel, key):
+    """A derived figure of the committed rocprofv3 PMC passes (profiles/traffic.json), e.g. the share of VALU lanes that were active."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[kernel].get(key)
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_sample, kind):
     """The CPU oracle (restatement of the reference's incremental evaluator: replay of each move list)
     timed single-threaded on this host, on a bounded sample of the same workload."""
@@ -90,13 +98,94 @@ def bench_mcts(args, G, torch, dev, rank, world, distributed):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     tree.close()
+    saturated = None
+    if args.mcts_saturated_games > n:
+        # configs[2]'s 4 096 games are one wavefront per SIMD (20 480 rollout lanes of 65 536): the same search with the chip full
+        ns = args.mcts_saturated_games
+        _, _, planes_s, last_s = mcts_openings(G, np, ns, rank * ns)
+        big = G.BatchedMCTS(ns, playouts_capacity=P)
+        big.set_roots(planes_s, last_s, first_game_id=rank * ns)
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        big.run(P, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_s = e0.elapsed_time(e1)
+        if distributed:
+            t = torch.tensor([ms_s], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ms_s = float(t[0])
+        big.close()
+        saturated = {"games_per_gpu": ns, "value": ns * world * P / (ms_s * 1e-3), "unit": "playouts/s", "ms_per_search": ms_s,
+                     "note": "the same search with %d games per GPU (4 wavefronts per SIMD): what the chip sustains when the batch fills it" % ns}
     achieved = alg / (ms * 1e-3) / 1e9
-    return {"metric": "mcts-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms,
+    return {"metric": "mcts-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms, "saturated": saturated,
+            "lane_utilisation": measured_counter("mcts_playouts_kernel", "valu_lane_utilisation"),
             "config": {"workload": "batched MCTS (K3), %d games x %d playouts per GPU, RandomPolicy c_puct=5 c_rollouts=5, 4-ply openings, fresh roots" % (n, P)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("mcts_playouts_kernel", "playouts_per_launch", n * P),
                          "kernel": "mcts_playouts_kernel", "kernel_ms": ms, "alg_bytes_per_launch": alg,
                          "note": "tree bytes only (select 8 B/child, expand 16 B/node, backup 16 B/level); rollouts run in LDS/registers, the kernel is latency/issue bound"}}
+
+
+def bench_evalstate(args, G, torch, dev, rank, world, distributed):
+    """K2: the incrementally maintained evaluator (Evaluator::applyMove / revertMove, Pattern.cpp:306-342), which bounds K6: n games
+    side by side, each applies the moves of its clustered synthetic game (<= 60) and takes them back again, one launch each way."""
+    import numpy as np
+    n, k = args.evalstate_games, 60
+    moves, lens, _ = G.synth_boards(n, 1, first_board=rank * n)
+    script = np.full((n, k), -1, np.int16)
+    for g in range(n):
+        m = min(int(lens[g]), k)
+        script[g, :m] = moves[g, :m]
+    d_apply = torch.from_numpy(script).to(dev)
+    d_revert = torch.full((n, k), -2, dtype=torch.int16, device=dev)
+    d_revert[torch.from_numpy(script < 0).to(dev)] = -1
+    states = G.EvaluatorStates(n)
+    L = G.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    def both():
+        L.gmk_evalstate_update(states.h, d_apply.data_ptr(), k, stream)
+        L.gmk_evalstate_update(states.h, d_revert.data_ptr(), k, stream)
+    both()
+    torch.cuda.synchronize()
+    if distributed:
+        torch.distributed.barrier()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        both()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    if distributed:
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = float(t[0])
+    meta = states.read()["meta"]
+    states.close()
+    updates = 2 * int((script >= 0).sum())
+    return {"metric": "evaluator-updates/s", "value": updates * world / (ms * 1e-3), "unit": "updates/s", "ms_per_pair_of_launches": ms,
+            "us_per_update_per_game": ms * 1e3 / (updates / n),
+            "config": {"workload": "incremental evaluator states (K2), %d games per GPU, each applies its clustered synthetic game (<= 60 moves, %.1f on average) and reverts it" % (n, updates / 2 / n),
+                       "states_back_at_the_empty_board": bool((meta[:, 0] == 0).all())},
+            "note": "one wavefront per game, the 17.8 KB state in LDS: a chain of dependent LDS round trips per update, bound by latency, not by bandwidth; no roofline fraction is claimed"}
+
+
+def cpu_baseline_evalstate(G, n_sample):
+    """The oracle's evaluator applying the same games move by move (in-order replay), single thread."""
+    from oracle import oracle as O
+    moves, lens, _ = G.synth_boards(n_sample, 1)
+    O.lib()
+    t0 = time.perf_counter()
+    O.replay_batch(moves, lens)
+    dt = time.perf_counter() - t0
+    return {"value": float(lens.sum()) / dt, "unit": "updates/s", "cores": 1, "kind": "port",
+            "sample": "%d clustered synthetic games (%d moves) applied move by move through the oracle evaluator, %.1f s" % (n_sample, int(lens.sum()), dt)}
 
 
 def trad_positions(G, n, first):
@@ -305,6 +394,8 @@ def parse_args(argv=None):
     ap.add_argument("--mcts-games", type=int, default=4096, help="games per GPU for the secondary MCTS measurement (BASELINE configs[2]); 0 = skip")
     ap.add_argument("--mcts-playouts", type=int, default=800)
     ap.add_argument("--mcts-reps", type=int, default=3)
+    ap.add_argument("--mcts-saturated-games", type=int, default=16384, help="games per GPU for the saturated-batch K3 figure beside configs[2]; 0 = skip")
+    ap.add_argument("--evalstate-games", type=int, default=1792, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
     ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
     ap.add_argument("--az-playouts", type=int, default=60)
     ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
@@ -446,6 +537,10 @@ def main():
     if args.mcts_games > 0:
         mcts = bench_mcts(args, G, torch, dev, rank, world, distributed)
 
+    incremental = None
+    if args.evalstate_games > 0:
+        incremental = bench_evalstate(args, G, torch, dev, rank, world, distributed)
+
     trad = None
     if args.trad_games > 0:
         trad = bench_trad(args, G, torch, dev, rank, world, distributed)
@@ -485,6 +580,8 @@ def main():
         }
         if mcts is not None:
             out["secondary"] = mcts
+        if incremental is not None:
+            out["incremental"] = incremental
         if trad is not None:
             out["supervisor"] = trad
         if rave is not None:
@@ -495,6 +592,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.kind)
             if mcts is not None:
                 out["secondary"]["cpu_baseline"] = cpu_baseline_mcts(args.mcts_playouts)
+            if incremental is not None:
+                out["incremental"]["cpu_baseline"] = cpu_baseline_evalstate(G, 16384)
             if trad is not None:
                 out["supervisor"]["cpu_baseline"] = cpu_baseline_trad(G, args.trad_playouts)
             if rave is not None:

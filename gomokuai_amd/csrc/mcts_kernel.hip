@@ -338,6 +338,20 @@ __global__ void mcts_init_roots_kernel(const GameHeader* __restrict__ headers, u
     parent[base] = kNone;
 }
 
+// Continuous batching for whole-game self-play (gmk_selfplay_run): the handle's games are SLOTS; slot g plays game slot_game[g] of
+// n_total, its records go to that game's rows, and when the game ends the slot takes the next game nobody has started (a counter in
+// device memory): its opening position becomes the slot's root, its global id the slot's random-number key.  So the search
+// launches stay full until fewer games than slots remain, instead of waiting for the longest game of a fixed batch.
+struct SlotRefill {
+    int32_t* slot_game;             // [n_slots] game played by each slot, -1 = none (null: slot g plays game g and is not refilled)
+    int32_t* next_game;             // [1] first game not started yet
+    int n_total;
+    const uint8_t* open_moves;      // [n_total][open_stride] opening moves (black first), may be null
+    const int32_t* open_lens;       // [n_total] (<= 8: an opening cannot be a finished game)
+    int open_stride;
+    uint32_t first_game_id;
+};
+
 // One self-play move per unfinished game: MCTS::stepForward() (MCTS.cpp:129-134) + Board::applyMove with the
 // victory check (Game.cpp:37-47, 88-136) on the root position, the (move, visit counts) record of
 // agents/utils.py:29-41, and the new root.  One wavefront per game.
@@ -347,10 +361,13 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
                          uint32_t* __restrict__ parent2, size_t cap, int n_games,
                          uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
                          int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse,
-                         const int16_t* __restrict__ forced /* null, or per game: the move to step to (MCTS::stepForward(move)), -1 = the most visited child */) {
+                         const int16_t* __restrict__ forced /* null, or per game: the move to step to (MCTS::stepForward(move)), -1 = the most visited child */,
+                         SlotRefill slots) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (g >= n_games) return;
     GameHeader& hdr = headers[g];
+    const int rec = slots.slot_game ? slots.slot_game[g] : g;      // the records' row of this slot's game
+    if (rec < 0) return;                                            // a slot that never got a game
     const size_t base = static_cast<size_t>(g) * cap;
     const uint32_t root = hdr.root, stones = hdr.stones;
     const uint32_t first = link[base + root] >> 8;
@@ -387,9 +404,9 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
     const uint32_t child = first + static_cast<uint32_t>(best_i);
     const uint32_t cell = first ? (link[base + child] & 0xFFu) : static_cast<uint32_t>(want);
     const bool keep = reuse && first;                               // an unexpanded root has no subtree to keep (MCTS.cpp:140-145 creates a node)
-    const int len = rec_lens[g];
+    const int len = rec_lens[rec];
     if (rec_visits) {
-        uint16_t* rv = rec_visits + (static_cast<size_t>(g) * 225 + static_cast<size_t>(len)) * 225;
+        uint16_t* rv = rec_visits + (static_cast<size_t>(rec) * 225 + static_cast<size_t>(len)) * 225;
         for (int i = lane; i < 225; i += 64) rv[i] = 0;
         __syncthreads();
         if (first)
@@ -397,32 +414,55 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
                 rv[link[base + first + i] & 0xFFu] = static_cast<uint16_t>(min(stats[base + first + i].x, 65535u));
     }
     __syncthreads();
+    bool refilled = false;                                          // (lane 0) the slot starts a new game: fresh root whatever `keep` says
     if (lane == 0) {
-        rec_moves[static_cast<size_t>(g) * 225 + len] = static_cast<uint8_t>(cell);
-        rec_lens[g] = len + 1;
+        rec_moves[static_cast<size_t>(rec) * 225 + len] = static_cast<uint8_t>(cell);
+        rec_lens[rec] = len + 1;
         const int x = static_cast<int>(cell % 15u), y = static_cast<int>(cell / 15u);
         const int shift = (stones & 1u) ? 16 : 0;                   // black moves on even stone counts
         hdr.rows[y] |= 1u << (x + shift);
         hdr.stones = stones + 1;
         hdr.last_move = cell;
         const bool five = five_through<1>(hdr.rows, x, y, shift);
+        uint32_t root_cell = cell;
         if (five || stones + 1 == 225u) {
             hdr.status |= 1u;
-            rec_winner[g] = five ? static_cast<int8_t>(shift ? -1 : 1) : static_cast<int8_t>(0);
+            rec_winner[rec] = five ? static_cast<int8_t>(shift ? -1 : 1) : static_cast<int8_t>(0);
+            const int next = slots.slot_game ? atomicAdd(slots.next_game, 1) : slots.n_total;
+            if (slots.slot_game && next < slots.n_total) {          // the slot takes the next unstarted game: its opening is the new root
+                refilled = true;
+                slots.slot_game[g] = next;
+                const int olen = slots.open_lens ? slots.open_lens[next] : 0;
+                for (int y = 0; y < 16; ++y) hdr.rows[y] = 0u;
+                for (int i = 0; i < olen; ++i) {
+                    const uint32_t c = slots.open_moves[static_cast<size_t>(next) * slots.open_stride + i];
+                    hdr.rows[c / 15u] |= 1u << (c % 15u + ((i & 1) ? 16u : 0u));
+                    rec_moves[static_cast<size_t>(next) * 225 + i] = static_cast<uint8_t>(c);
+                    root_cell = c;
+                }
+                if (olen == 0) root_cell = 255u;
+                rec_lens[next] = olen;
+                hdr.stones = static_cast<uint32_t>(olen);
+                hdr.last_move = root_cell;
+                hdr.game_id = slots.first_game_id + static_cast<uint32_t>(next);
+                hdr.status = 0u;
+                atomicAdd(unfinished, 1);
+            }
         } else {
             atomicAdd(unfinished, 1);
         }
         hdr.playouts_done = 0;
         hdr.noise = 0;
-        if (!keep) {                                                // MCTS::reset + syncWithBoard: a fresh one-node tree
+        if (!keep || refilled) {                                    // MCTS::reset + syncWithBoard: a fresh one-node tree
             hdr.root = 0;
             hdr.n_nodes = 1;
             (reuse ? stats2 : stats)[base] = make_uint2(0u, 0u);    // with reuse the live arena flips for every game
-            (reuse ? link2 : link)[base] = cell;
+            (reuse ? link2 : link)[base] = root_cell;
             (reuse ? parent2 : parent)[base] = kNone;
         }
     }
-    if (!keep) return;
+    refilled = __shfl(static_cast<int>(refilled), 0, 64) != 0;
+    if (!keep || refilled) return;
 
     // The subtree of the move becomes the tree (updateRoot, MCTS.cpp:63-67); the reference frees the siblings, here
     // the kept subtree is copied level by level into the other arena so that node indices stay dense.  In the new
@@ -506,6 +546,10 @@ struct gmk_mcts {
     uint32_t* d_parent2 = nullptr;
     float* d_root_prior = nullptr;     // [n_games][225] by child index, used while GameHeader::noise is set
     float* d_value = nullptr;          // [2 * c_rollouts + 1] rollout sum -> state value
+    SlotRefill slots{};                // continuous batching (gmk_selfplay_run); all null otherwise
+    int32_t* d_slot_state = nullptr;   // [n_games + 1] slot_game, next_game
+    uint8_t* d_open_moves = nullptr;
+    int32_t* d_open_lens = nullptr;
     void* d_step_scratch = nullptr;    // record outputs of gmk_mcts_step_host
     hipStream_t last_stream = nullptr;
     bool rooted = false;               // gmk_mcts_set_roots has run: headers and arenas hold trees
@@ -558,6 +602,7 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
 extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     if (!m) return GMK_OK;
     (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent); (void)hipFree(m->d_value);
+    (void)hipFree(m->d_slot_state); (void)hipFree(m->d_open_moves); (void)hipFree(m->d_open_lens);
     (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2); (void)hipFree(m->d_root_prior); (void)hipFree(m->d_step_scratch);
     delete m;
     return GMK_OK;
@@ -649,7 +694,7 @@ extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t
     GMK_HIP_CHECK(hipMemsetAsync(d_unfinished, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(mcts_advance_kernel, dim3(m->n_games), dim3(64), 0, s, m->d_headers, m->d_stats, m->d_link, m->d_parent,
                        m->d_stats2, m->d_link2, m->d_parent2, static_cast<size_t>(m->node_capacity), m->n_games,
-                       d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, d_forced_moves);
+                       d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, d_forced_moves, m->slots);
     GMK_HIP_CHECK(hipGetLastError());
     if (reuse_subtree) {                                            // the copy is the live tree from here on
         std::swap(m->d_stats, m->d_stats2);
@@ -661,6 +706,82 @@ extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t
 
 // gmk_mcts_step for callers without device buffers of their own (the one-game searcher behind CorePyExt): the moves
 // come from the host, the record outputs go to scratch buffers owned by the handle.
+// Whole games with continuous batching, resident on the device: see SlotRefill.  The host's part is the launch loop (one search and one
+// step per move of the slots) and a 4-byte readback per move.
+extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id, int playouts, int reuse_subtree, float noise_alpha, float noise_epsilon,
+                                const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens,
+                                uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int32_t* h_steps, void* stream) {
+    if (!m || n_total <= 0 || playouts < 0 || !d_moves || !d_lens || !d_winner || (h_open_moves && (!h_open_lens || open_stride <= 0))) {
+        gmk::set_error("gmk_selfplay_run: bad arguments");
+        return GMK_ERR_ARG;
+    }
+    const int n_slots = m->n_games;
+    const size_t nt = static_cast<size_t>(n_total);
+    std::vector<int32_t> open_lens(nt, 0);
+    if (h_open_moves)
+        for (size_t g = 0; g < nt; ++g) {
+            if (h_open_lens[g] < 0 || h_open_lens[g] > 8 || h_open_lens[g] > open_stride) { gmk::set_error("gmk_selfplay_run: opening of game %zu has %d moves (0 .. 8)", g, h_open_lens[g]); return GMK_ERR_ARG; }
+            open_lens[g] = h_open_lens[g];
+        }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GMK_HIP_CHECK(hipStreamSynchronize(s));
+    // the first min(n_slots, n_total) games start in the slots (fresh roots from their openings), the rest wait for a free slot
+    std::vector<uint16_t> planes(static_cast<size_t>(n_slots) * 32, 0);
+    std::vector<int16_t> last(static_cast<size_t>(n_slots), -1);
+    std::vector<int32_t> slot_state(static_cast<size_t>(n_slots) + 1, -1);
+    std::vector<uint8_t> first_moves(nt * 225, 0);
+    for (size_t g = 0; g < nt; ++g)
+        for (int i = 0; i < open_lens[g]; ++i) {
+            const uint8_t c = h_open_moves[g * open_stride + i];
+            if (c >= 225) { gmk::set_error("gmk_selfplay_run: opening of game %zu holds cell %d", g, c); return GMK_ERR_ARG; }
+            first_moves[g * 225 + i] = c;
+            if (g < static_cast<size_t>(n_slots)) { planes[g * 32 + (i & 1) * 16 + c / 15] |= static_cast<uint16_t>(1u << (c % 15)); last[g] = c; }
+        }
+    const int started = std::min(n_slots, n_total);
+    for (int g = 0; g < started; ++g) slot_state[static_cast<size_t>(g)] = g;
+    slot_state[static_cast<size_t>(n_slots)] = started;                         // next_game
+    int rc = gmk_mcts_set_roots(m, planes.data(), last.data(), first_game_id);
+    if (rc != GMK_OK) return rc;
+    if (!m->d_slot_state) GMK_HIP_CHECK(hipMalloc(&m->d_slot_state, (static_cast<size_t>(n_slots) + 1) * 4));
+    (void)hipFree(m->d_open_moves); (void)hipFree(m->d_open_lens);
+    m->d_open_moves = nullptr; m->d_open_lens = nullptr;
+    GMK_HIP_CHECK(hipMalloc(&m->d_open_lens, nt * 4));
+    GMK_HIP_CHECK(hipMemcpy(m->d_open_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
+    if (h_open_moves) {
+        GMK_HIP_CHECK(hipMalloc(&m->d_open_moves, nt * static_cast<size_t>(open_stride)));
+        GMK_HIP_CHECK(hipMemcpy(m->d_open_moves, h_open_moves, nt * static_cast<size_t>(open_stride), hipMemcpyHostToDevice));
+    }
+    GMK_HIP_CHECK(hipMemcpy(m->d_slot_state, slot_state.data(), slot_state.size() * 4, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(d_moves, first_moves.data(), nt * 225, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(d_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemset(d_winner, 0, nt));
+    if (n_slots > n_total) {                                                    // slots without a game: finished from the start
+        std::vector<GameHeader> hdr(static_cast<size_t>(n_slots));
+        GMK_HIP_CHECK(hipMemcpy(hdr.data(), m->d_headers, hdr.size() * sizeof(GameHeader), hipMemcpyDeviceToHost));
+        for (int g = n_total; g < n_slots; ++g) hdr[static_cast<size_t>(g)].status |= 1u;
+        GMK_HIP_CHECK(hipMemcpy(m->d_headers, hdr.data(), hdr.size() * sizeof(GameHeader), hipMemcpyHostToDevice));
+    }
+    m->slots = SlotRefill{m->d_slot_state, m->d_slot_state + n_slots, n_total, m->d_open_moves, m->d_open_lens, open_stride, first_game_id};
+    int32_t* d_unfinished = nullptr;
+    GMK_HIP_CHECK(hipMalloc(&d_unfinished, 4));
+    int32_t steps = 0;
+    rc = GMK_OK;
+    for (long long step = 0; step < 226ll * (n_total / n_slots + 2); ++step) {
+        if (noise_alpha > 0.0f && reuse_subtree) rc = gmk_mcts_add_root_noise(m, noise_alpha, noise_epsilon, s);      // Default::AddNoise at the start of every search (MCTS.cpp:182)
+        if (rc == GMK_OK) rc = gmk_mcts_run(m, playouts, s);
+        if (rc == GMK_OK) rc = gmk_mcts_step(m, nullptr, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, s);
+        if (rc != GMK_OK) break;
+        ++steps;
+        int32_t unfinished = 0;
+        if (hipMemcpyAsync(&unfinished, d_unfinished, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { gmk::set_error("gmk_selfplay_run: readback failed"); rc = GMK_ERR_HIP; break; }
+        if (unfinished == 0) break;
+    }
+    (void)hipFree(d_unfinished);
+    m->slots = SlotRefill{};
+    if (h_steps) *h_steps = steps;
+    return rc;
+}
+
 extern "C" int gmk_mcts_step_host(gmk_mcts* m, const int16_t* h_moves, int reuse_subtree) {
     if (!m || !h_moves) { gmk::set_error("gmk_mcts_step_host: bad arguments"); return GMK_ERR_ARG; }
     const size_t n = static_cast<size_t>(m->n_games);

@@ -29,7 +29,7 @@ EXPORTS = [
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_set_game_ids", "gmk_mcts_run", "gmk_mcts_root_stats",
-    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_samples_from_records",
+    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_selfplay_run", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
     "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_root_stats",
     "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
@@ -87,6 +87,7 @@ def load():
     L.gmk_mcts_advance.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.gmk_mcts_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.gmk_mcts_step_host.argtypes = [vp, vp, C.c_int]
+    L.gmk_selfplay_run.argtypes = [vp, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
     L.gmk_mcts_add_root_noise.argtypes = [vp, C.c_float, C.c_float, vp]
     L.gmk_evalstate_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.gmk_evalstate_destroy.argtypes = [vp]
@@ -285,6 +286,25 @@ class BatchedMCTS:
 
     def add_root_noise(self, alpha=0.05, epsilon=0.25, stream=None):
         _check(load().gmk_mcts_add_root_noise(self.h, alpha, epsilon, stream))
+
+    def selfplay_run(self, n_total, first_game_id, playouts, d_moves, d_visits, d_lens, d_winner, open_moves=None, open_lens=None,
+                     reuse_subtree=False, root_noise=None, stream=None):
+        """gmk_selfplay_run: the handle's games are slots that play n_total whole games between them (continuous batching on the
+        device).  open_moves uint8[n_total, stride] / open_lens int32[n_total] (host) or None; outputs are device pointers (ints),
+        indexed by game.  Returns the number of search launches it took."""
+        played = C.c_int32()
+        om = ol = None
+        stride = 0
+        if open_moves is not None:
+            om = np.ascontiguousarray(open_moves, dtype=np.uint8)
+            ol = np.ascontiguousarray(open_lens, dtype=np.int32)
+            assert om.ndim == 2 and om.shape[0] == n_total and ol.shape == (n_total,)
+            stride = om.shape[1]
+        alpha, eps = root_noise if root_noise is not None else (0.0, 0.0)
+        _check(load().gmk_selfplay_run(self.h, int(n_total), int(first_game_id), int(playouts), int(reuse_subtree), float(alpha), float(eps),
+                                       None if om is None else om.ctypes.data, stride, None if ol is None else ol.ctypes.data,
+                                       d_moves, d_visits, d_lens, d_winner, C.byref(played), stream))
+        return played.value
 
     def alg_bytes(self):
         b = C.c_uint64()

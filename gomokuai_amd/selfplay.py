@@ -79,13 +79,34 @@ class GameRecords:
 
 def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5.0, c_rollouts=5,
                opening_plies=0, record_visits=True, reuse_subtree=False, root_noise=None, max_moves=N, device=None,
-               node_capacity=None):
+               node_capacity=None, slots=None):
     """Plays n_games complete games on the current GPU: every move = one K3 search of `playouts` playouts for all
     unfinished games, then `gmk_mcts_advance`.  Game g uses the global id first_game_id + g for its RNG streams, so
-    the records do not depend on how games are spread over GPUs."""
+    the records do not depend on how games are spread over GPUs.
+    slots: at most that many games in flight, with CONTINUOUS BATCHING on the device (gmk_selfplay_run): a slot whose game ends takes
+    the next unstarted game inside the step kernel, so the searches stay full instead of waiting for the longest game of the batch;
+    the records are the same as without slots (a game's random streams belong to the game)."""
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
+    if slots is not None and slots < n_games:
+        if opening_plies > 8:
+            raise ValueError("play_games: slots take openings of at most 8 plies")
+        open_moves = open_lens = None
+        if opening_plies > 0:
+            m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+            open_moves, open_lens = m, np.minimum(l, opening_plies).astype(np.int32)
+        cap = node_capacity if node_capacity is not None else playouts * N * (3 if reuse_subtree else 1) + 1
+        tree = G.BatchedMCTS(int(slots), c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap)
+        d_moves = torch.zeros((n_games, N), dtype=torch.uint8, device=dev)
+        d_lens = torch.zeros(n_games, dtype=torch.int32, device=dev)
+        d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
+        d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev) if record_visits else None
+        tree.selfplay_run(n_games, first_game_id, playouts, d_moves.data_ptr(), d_visits.data_ptr() if record_visits else None, d_lens.data_ptr(),
+                          d_winner.data_ptr(), open_moves, open_lens, reuse_subtree, root_noise if reuse_subtree else None, stream)
+        status = tree.root_stats()[4]
+        tree.close()
+        return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, bool((status & G.BatchedMCTS.STATUS_ARENA_FULL).any()))
     planes = np.zeros((n_games, 2, 16), dtype=np.uint16)
     last = np.full(n_games, -1, dtype=np.int16)
     moves0 = np.zeros((n_games, N), dtype=np.uint8)

@@ -153,6 +153,19 @@ int gmk_mcts_run(gmk_mcts *m, int playouts, void *stream);
  * Finished games are skipped by later gmk_mcts_run calls. */
 int gmk_mcts_advance(gmk_mcts *m, uint8_t *d_moves, uint16_t *d_visits, int32_t *d_lens, int8_t *d_winner,
                      int32_t *d_unfinished, int reuse_subtree, void *stream);
+/* Whole self-play games, resident on the device with CONTINUOUS BATCHING (replaces the data generation loop of
+ * network/data_helper.py:58-83 around agents/utils.py:29-63 for MCTS(RandomPolicy) on both sides): the handle's n_games are slots
+ * that play n_total games between them.  Every move of the slots is one gmk_mcts_run (`playouts` playouts) and one gmk_mcts_advance;
+ * a slot whose game ends takes the next game nobody has started -- its opening becomes the slot's root, its global id
+ * first_game_id + index the slot's random-number key -- so the searches stay full until fewer games than slots remain, and game g's
+ * record is the same whichever slot played it and however many slots there are.
+ * h_open_moves uint8[n_total][open_stride] / h_open_lens int32[n_total]: opening moves per game, black first, 0 .. 8 of them (NULL: empty boards).
+ * Device outputs, indexed by GAME: d_moves uint8[n_total][225] (openings included), d_visits uint16[n_total][225][225] or NULL,
+ * d_lens int32[n_total], d_winner int8[n_total].  noise_alpha > 0 with reuse_subtree applies Default::AddNoise before every search.
+ * Synchronous; *h_steps (optional) = search launches it took (each one move for every busy slot). */
+int gmk_selfplay_run(gmk_mcts *m, int n_total, uint32_t first_game_id, int playouts, int reuse_subtree, float noise_alpha, float noise_epsilon,
+                     const uint8_t *h_open_moves, int open_stride, const int32_t *h_open_lens,
+                     uint8_t *d_moves, uint16_t *d_visits, int32_t *d_lens, int8_t *d_winner, int32_t *h_steps, void *stream);
 /* The same step with the move given: MCTS::stepForward(next_move) (core/lib/src/MCTS.cpp:136-147), e.g. the opponent's
  * reply.  d_forced_moves int16[n] (device): the cell to step to, or -1 for the most visited child (= gmk_mcts_advance).
  * A root that was never expanded simply moves on; with reuse_subtree the child's subtree is kept.  An illegal cell

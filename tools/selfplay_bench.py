@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--reuse", action="store_true", help="keep the subtree of the played move (MCTS::stepForward)")
     ap.add_argument("--noise", action="store_true", help="Default::AddNoise(0.05, 0.25) before every search (needs --reuse)")
     ap.add_argument("--augment", action="store_true")
-    ap.add_argument("--slots", type=int, default=None, help="traditional / poolrave: games in flight (finished games hand their slot to the next one)")
+    ap.add_argument("--slots", type=int, default=None, help="games in flight: a finished game hands its slot to the next one (random: on the device, gmk_selfplay_run)")
     ap.add_argument("--policy", default="random", choices=["random", "traditional", "poolrave", "network"],
                     help="who plays: RandomPolicy (K3), TraditionalPolicy (K6), PoolRAVEPolicy (K8), the fused policy-value network (K7 + K9)")
     args = ap.parse_args()
@@ -37,7 +37,7 @@ def main():
     t0 = time.perf_counter()
     noise = (0.05, 0.25) if args.noise else None
     if args.policy == "random":
-        rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse, root_noise=noise)
+        rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse, root_noise=noise, slots=args.slots)
     elif args.policy == "network":
         from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
         net = FusedPolicyValueNetwork(PolicyValueNetwork(seed=1).cuda().eval())
