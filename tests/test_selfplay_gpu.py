@@ -328,7 +328,8 @@ def test_slots_do_not_change_noisy_supervisor_games():
     """Root noise (and PoolRAVE's rollouts) are keyed by the GAME's id, not by the slot it happens to run in: games played through a
     few slots equal the same games played all side by side, noise included; and the games of a slot are not copies of each other."""
     for policy, playouts in (("traditional", 60), ("poolrave", 40)):
-        kw = dict(c_puct=5.0 if policy == "traditional" else 2.0, seed=1234, first_game_id=50, opening_plies=0, root_noise=(0.3, 0.25), policy=policy)
+        # (Default::AddNoise only touches roots that have children: kept subtrees, i.e. every search of a game but its first)
+        kw = dict(c_puct=5.0 if policy == "traditional" else 2.0, seed=1234, first_game_id=50, opening_plies=0, root_noise=(0.3, 0.25), policy=policy, reuse_subtree=True)
         a = selfplay.play_supervisor_games(9, playouts, **kw).cpu()
         b = selfplay.play_supervisor_games(9, playouts, slots=3, **kw).cpu()
         assert (a.lens == b.lens).all() and (a.moves == b.moves).all() and (a.winner == b.winner).all(), policy
