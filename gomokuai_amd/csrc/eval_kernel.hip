@@ -36,7 +36,8 @@
 namespace {
 
 constexpr int kBoardsPerBlock = 16;               // wavefronts per workgroup, one board in flight each
-constexpr int kGroupBoards = 16;                  // boards a wavefront takes at a time (the columns of phase D's matrix product)
+constexpr int kGroupBoards = 16;                  // boards whose density planes are one unit of work (the columns of phase D's matrix product)
+constexpr int kChunkBoards = 4;                   // boards a wavefront draws from the work counter at a time
 constexpr int kThreads = 64 * kBoardsPerBlock;
 constexpr int kCells = 225;
 constexpr int kQueueCap = 448;
@@ -50,10 +51,11 @@ constexpr int kZeroWords = kScoreWords + kCntWords;                   // cleared
 constexpr int kLineWords = 96;                   // line words, 2 bits per cell = its DFA symbol (0 black, 1 white, 3 blank), cell p of the line at bits 2p:
                                                  // rows [0,15), columns [20,35), diagonals x-y+14 at [36,65), anti-diagonals x+y at [65,94)
 constexpr int kColBase = 20, kDiagBase = 36, kAntiBase = 65;
-constexpr int kMiscWords = 16;                   // [0] stones black | white << 16, [1] winner bits, [2] error, [3] compound queue count, [4..14] totals
+constexpr int kMiscWords = 48;                   // [0] stones black | white << 16, [1] winner bits, [2] error, [3] compound queue count, [4..14] totals,
+                                                 // [16..31] the rows (black | white << 16), [32..46] per row: cells where the colour's density count is >= 1
 constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
 static_assert(kZeroWords % 4 == 0 && kBoardWords % 4 == 0, "16-byte alignment of the per-board blocks");
-constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560;   // lane jobs, initial line words, the bits-to-bytes table and the weight table of phase D
+constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560 + 4;   // lane jobs, initial line words, the bits-to-bytes table and the weight table of phase D, a flag word
 
 // Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
@@ -145,7 +147,7 @@ __device__ __forceinline__ void add_counter_cells(uint32_t w0, int back, int q, 
 // of v_mfma_i32_32x32x32_i8; an M tile is 32 consecutive cells (7 tiles cover cells 0..223, cell 224 is done by hand), a K tile
 // two board rows of 16 (k = 16 y + x: the stones of a row become the bytes of its tile as they lie).  A tile of cells only
 // reaches rows y0-3 .. y1+3, so 31 (M, K) tile pairs per plane kind hold non-zeros.
-constexpr int kDensTiles = 7;
+[[maybe_unused]] constexpr int kDensTiles = 7;       // M tiles of 32 cells (cells 0 .. 223; cell 224 is done by hand)
 __host__ __device__ constexpr int dens_kt_lo(int m) { return (((32 * m) / 15 - 3) < 0 ? 0 : (32 * m) / 15 - 3) / 2; }
 __host__ __device__ constexpr int dens_kt_hi(int m) { return (((32 * m + 31) / 15 + 3) > 14 ? 14 : (32 * m + 31) / 15 + 3) / 2; }
 // The weight operand of lane (cell c = (yo, xo), k half h) at K tile kt holds the taps from row y = 2 kt + h, columns 0..15, to c:
@@ -164,115 +166,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 struct __attribute__((packed, aligned(4))) Int4Unaligned { int32_t x, y, z, w; };      // a 16-byte store to a 4-byte aligned address
 
-// ---- phase D, part 1 (once per group): the gates ----
-// Lane l = (column n = l & 31, k half h = l >> 5); column n = board (n >> 1) of the group, plane (n & 1) (0 black, 1 white).
-// Count planes only, cells on the accumulator ROWS (A = weights, B = stones): lane (n, h) then holds, per M tile, sixteen cells of
-// ITS column, and "count >= 1", "count >= 2" pack into bit strings with two instructions per cell.  Nothing is stored from here
-// (except cell 224, which no tile covers): the planes leave in part 2, spread over the group's board iterations.
-// s_wtab: the weight table in LDS (above).
-// Returns, for THIS lane's column, bit strings over the cells, already restricted to empty cells, as four registers each:
-// register p of lane (n, h) holds cells 64 p + 32 h .. + 31, so that pass p of phase 3 (cell = 64 p + lane) finds its bit
-// with ONE ds_bpermute from lane (lane & 32) | n.  gate1: count >= 1 (<=> weight > 0), gate2: count >= 2.
-__device__ __forceinline__ void density_gates(const uint16_t* __restrict__ planes, int n_boards, int first_board, int lane,
-                                              const v4i* __restrict__ s_wtab, int32_t* __restrict__ out_density,
-                                              v4i* s_bt /* 8 KB of this wavefront's LDS */, uint32_t (&gate1)[4], uint32_t (&gate2)[4]) {
-    const int n = lane & 31, h = lane >> 5, plane = n & 1;
-    const int board = first_board + (n >> 1);
-    const bool live = board < n_boards;
-    uint32_t own[8], both[8];                       // rows 2k (low half) and 2k+1 (high half) of this column's plane / of both planes
-    {
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-        if (live) {
-            const uint4* p = reinterpret_cast<const uint4*>(planes + static_cast<size_t>(board) * 32);
-            a0 = p[plane * 2]; a1 = p[plane * 2 + 1]; b0 = p[2 - plane * 2]; b1 = p[3 - plane * 2];
-        }
-        own[0] = a0.x; own[1] = a0.y; own[2] = a0.z; own[3] = a0.w; own[4] = a1.x; own[5] = a1.y; own[6] = a1.z; own[7] = a1.w;
-        both[0] = a0.x | b0.x; both[1] = a0.y | b0.y; both[2] = a0.z | b0.z; both[3] = a0.w | b0.w;
-        both[4] = a1.x | b1.x; both[5] = a1.y | b1.y; both[6] = a1.z | b1.z; both[7] = a1.w | b1.w;
-    }
-    // stone operands: K tile kt, slot (h, j) = cell (row 2 kt + h, column j): the row's bits as bytes.  They wait in LDS (the
-    // board region is idle during this part) instead of 32 registers: one ds_read_b128 per MFMA, hidden behind it.
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-        const uint32_t r = (own[kt] >> (16 * h)) & 0x7FFFu;
-        v4i b;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) b[v] = static_cast<int>((((r >> (4 * v)) & 15u) * 0x204081u) & 0x01010101u);
-        s_bt[kt * 64 + lane] = b;
-    }
-    // occupied cells of the board as one string over the cells (bit q of the 225)
-    uint32_t occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-        const uint32_t pair = (both[kt] & 0x7FFFu) | ((both[kt] >> 16) << 15);          // rows 2 kt, 2 kt + 1: 30 cells
-        const int off = 30 * kt, w = off >> 5, sft = off & 31;
-        occ[w] |= pair << sft;
-        if (sft > 2) occ[w + 1] |= pair >> (32 - sft);
-    }
-    // cell 224 = (14, 14): the taps dy, dx in -3 .. 0 that lie on the board
-    uint32_t c224 = 0, w224 = 0;
-#pragma unroll
-    for (int dy = -3; dy <= 0; ++dy) {
-        const int y = 14 + dy;
-        const uint32_t r = (y & 1) ? own[y >> 1] >> 16 : own[y >> 1] & 0xFFFFu;
-#pragma unroll
-        for (int dx = -3; dx <= 0; ++dx) {
-            if (block_weight(dy, dx) == 0) continue;
-            const uint32_t bit = (r >> (14 + dx)) & 1u;
-            c224 += bit;
-            w224 += bit * static_cast<uint32_t>(block_weight(dy, dx));
-        }
-    }
-    if (live && out_density && h == 0) {            // [white, black][count, weight][cell]; occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
-        int32_t* out = out_density + static_cast<size_t>(board) * 4 * kCells + (1 - plane) * 2 * kCells;
-        const uint32_t neg = 0u - (occ[7] & 1u);
-        out[224] = static_cast<int32_t>(c224 ^ neg);
-        out[kCells + 224] = static_cast<int32_t>(w224 ^ neg);
-    }
-    // 31 MFMAs, both operands from LDS; one accumulator tile at a time
-    uint32_t gates[8];                              // per M tile: count >= 1 at bit pos, count >= 2 at bit pos + 4 (pos below)
-    wave_phase_fence();
-#pragma unroll
-    for (int m = 0; m < kDensTiles; ++m) {
-        const int cell = 32 * m + n, yo = (cell * 0x8889) >> 19, xo = cell - 15 * yo;    // (cell / 15 for cell < 2^15)
-        const v4i* w = s_wtab + (2 * dens_kt_lo(m) + h - yo + 6) * 15 + xo;
-        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int kt = dens_kt_lo(m); kt <= dens_kt_hi(m); ++kt)
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(w[30 * (kt - dens_kt_lo(m))], s_bt[kt * 64 + lane], acc, 0, 0, 0);
-        uint32_t t = 0;                             // accumulator i = cell 32 m + 8 (i / 4) + 4 h + (i % 4)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int pos = 8 * (i / 4) + (i % 4);
-            const uint32_t c = min(static_cast<uint32_t>(acc[i]), 2u);                  // 0, 1, 2
-            t |= (((c + 1u) >> 1) | ((c >> 1) << 4)) << pos;
-        }
-        asm volatile("" : "+v"(t));                 // (pins the sixteen-to-one reduction here: sunk to the end of the pass it would keep every tile's accumulators alive)
-        gates[m] = t;
-    }
-    gates[7] = 0;
-    uint32_t g1[8], g2[8];
-#pragma unroll
-    for (int m = 0; m < kDensTiles; ++m) {
-        g1[m] = (gates[m] & 0x0F0F0F0Fu) << (4 * h);
-        g2[m] = ((gates[m] >> 4) & 0x0F0F0F0Fu) << (4 * h);
-    }
-    g1[7] = h == 0 ? min(c224, 1u) : 0u;
-    g2[7] = h == 0 ? min(c224, 2u) >> 1 : 0u;
-    // both k halves of a column hold half of its cells' bits: exchange, restrict to empty cells, lay out for phase 3
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        g1[k] = (g1[k] | static_cast<uint32_t>(__shfl_xor(static_cast<int>(g1[k]), 32))) & ~occ[k];
-        g2[k] = (g2[k] | static_cast<uint32_t>(__shfl_xor(static_cast<int>(g2[k]), 32))) & ~occ[k];
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        gate1[p] = h ? g1[2 * p + 1] : g1[2 * p];
-        gate2[p] = h ? g2[2 * p + 1] : g2[2 * p];
-    }
-}
-
-// ---- phase D, part 2 (fourteen times per group, one per board iteration): one plane kind of one M tile leaves for HBM ----
+// ---- phase D: one plane kind of one M tile of a group of sixteen boards leaves for HBM ----
 // Here the BOARDS are on the accumulator rows (A = stones, B = weights): lane (n, h) holds cell 32 M + n of sixteen board-colour
 // columns, so a store instruction writes 2 x 128 contiguous bytes (with the cells on the rows a lane would own 16 bytes of 64
 // different cache lines: measured 2.4 TB/s for the density planes alone).  Spreading the fourteen passes over the group's board
@@ -337,6 +231,26 @@ __device__ __forceinline__ void density_planes_out(const uint16_t* __restrict__ 
         own[0] = a0.x; own[1] = a0.y; own[2] = a0.z; own[3] = a0.w; own[4] = a1.x; own[5] = a1.y; own[6] = a1.z; own[7] = a1.w;
         other[0] = b0.x; other[1] = b0.y; other[2] = b0.z; other[3] = b0.w; other[4] = b1.x; other[5] = b1.y; other[6] = b1.z; other[7] = b1.w;
     }
+    // cell 224 = (14, 14), which no tile covers: the taps dy, dx in -3 .. 0 that lie on the board, by hand (one lane per column)
+    if ((lane >> 5) == 0 && board < n_boards && plane_stride > 0) {
+        uint32_t c224 = 0, w224 = 0;
+#pragma unroll
+        for (int dy = -3; dy <= 0; ++dy) {
+            const int y = 14 + dy;
+            const uint32_t r = (y & 1) ? own[y >> 1] >> 16 : own[y >> 1] & 0xFFFFu;
+#pragma unroll
+            for (int dx = -3; dx <= 0; ++dx) {
+                if (block_weight(dy, dx) == 0) continue;
+                const uint32_t bit = (r >> (14 + dx)) & 1u;
+                c224 += bit;
+                w224 += bit * static_cast<uint32_t>(block_weight(dy, dx));
+            }
+        }
+        const uint32_t neg = 0u - (((own[7] | other[7]) >> 14) & 1u);             // occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
+        int32_t* out = out_density + static_cast<size_t>(board) * 4 * plane_stride + (1 - plane) * 2 * plane_stride;
+        out[224] = static_cast<int32_t>(c224 ^ neg);
+        out[plane_stride + 224] = static_cast<int32_t>(w224 ^ neg);
+    }
 #define GMK_PASS(K, M) density_tile_pass<K, M>(own, other, n_boards, first_board, lane, s_wtab, out_density, s_lut, plane_stride); __builtin_amdgcn_sched_barrier(0);
     GMK_PASS(0, 0) GMK_PASS(1, 0) GMK_PASS(0, 1) GMK_PASS(1, 1) GMK_PASS(0, 2) GMK_PASS(1, 2) GMK_PASS(0, 3) GMK_PASS(1, 3)
     GMK_PASS(0, 4) GMK_PASS(1, 4) GMK_PASS(0, 5) GMK_PASS(1, 5) GMK_PASS(0, 6) GMK_PASS(1, 6)
@@ -344,7 +258,7 @@ __device__ __forceinline__ void density_planes_out(const uint16_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(kThreads)
-void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int n_groups,
+void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int n_groups, uint32_t* __restrict__ sched,
                            int32_t* __restrict__ out_scores, int32_t* __restrict__ out_density,
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
@@ -375,45 +289,95 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
 
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
 
-    // groups of sixteen boards: consecutive groups go to different workgroups first (small batches still use every CU)
-    for (int group = blockIdx.x + gridDim.x * wave; group < n_groups; group += gridDim.x * kBoardsPerBlock) {
-    const int first_board = group * kGroupBoards;
-    uint32_t gate1[4] = {0, 0, 0, 0}, gate2[4] = {0, 0, 0, 0};
-    if (phase_mask & 64) density_gates(planes, n_boards, first_board, lane0, s_wtab, out_density, reinterpret_cast<v4i*>(s_scores), gate1, gate2);
+    // ---- work distribution ----
+    // Boards cost between a third and twice the average (8 .. 60 stones), so a fixed share of boards per wavefront leaves the
+    // kernel waiting for its unluckiest wavefront: with sixteen boards each, the slowest of 4 096 wavefronts takes 1.3 x the mean.
+    // Instead the boards are handed out in CHUNKS of kChunkBoards: every workgroup owns an equal range of chunks and a counter for
+    // it in device memory (one cache line each: a single counter for the whole chip serialises 16 384 atomics on one address); its
+    // wavefronts draw from that counter, and when the range is used up they go on to the next workgroup's counter, and so on round
+    // the ring, until every range is used up.  The density groups (phase D: the planes of sixteen boards, whose cost does not depend
+    // on the position) are dealt out statically, one per wavefront and sixteen boards, the wavefronts of a workgroup out of step so
+    // that one of them stores planes while the others evaluate.
+    // sched[16 g]: chunks drawn from workgroup g's range; sched[16 gridDim.x]: workgroups that are done (the last one zeroes everything).
     const bool planes_out = out_density != nullptr && (phase_mask & 64) && !(phase_mask & 1024);
-
-    // Everything the board phases derive from the lane number is derived from THIS copy, which the compiler cannot see through:
-    // those ~45 registers of per-lane constants are then computed after phase D (once per sixteen boards) instead of
-    // living through it, where they would spill.
+    const int n_chunks = (n_boards + kChunkBoards - 1) / kChunkBoards;
+    const int chunks_per_group = (n_chunks + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
     int lane = lane0;
-    asm volatile("" : "+v"(lane));
     const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
     const uint32_t lane_tag = static_cast<uint32_t>(lane) << 10;
-    // a board's 64 B are fetched while the board before it is evaluated (they were read by phase D: an L2 hit).  No branch around
-    // the loads (every lane reads some valid row, the result is masked where it is used): with one, the compiler waits for the
-    // data at the end of the branch, i.e. at once, and the wait covers every store issued before.
+    uint32_t* s_rows = s_misc + 16;
+    uint32_t* s_gate = s_misc + 32;
+    // a board's 64 B are fetched while the board before it is evaluated.  No branch around the loads (every lane reads some valid
+    // row, the result is masked where it is used), and the two halves stay apart until they are used: any arithmetic on a loaded
+    // value makes the compiler wait for it on the spot, and the wait covers every store issued before.
     const uint16_t* row_ptr = planes + (lane & 15);
-    uint32_t next_black = 0, next_white = 0;         // the two halves stay apart until they are used: combining them would be a use
-    uint32_t cur_black = 0, cur_white = 0;           // the rows of the board being evaluated: landed (see below)
+    uint32_t next_black = 0, next_white = 0, cur_black = 0, cur_white = 0;
     auto fetch_row = [&](int b) {
         const uint16_t* p = row_ptr + static_cast<size_t>(min(b, n_boards - 1)) * 32;
         next_black = p[0];
         next_white = p[16];
     };
     auto take_row = [&](int b) -> uint32_t { return lane < 16 && b < n_boards ? cur_black | (cur_white << 16) : 0u; };
-    fetch_row(first_board);
-    asm volatile("" : "+v"(next_black), "+v"(next_white));        // (once per group: wait for them here)
+    int victim = blockIdx.x;                                     // whose range this wavefront draws from
+    auto draw = [&]() -> uint32_t {                              // (the value lands in lane 0's register; it is read with readfirstlane once it is there)
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&sched[16 * victim], 1u);
+        return v;
+    };
+    // the chunk a drawn number stands for, or n_chunks (= none) when the victim's range is used up
+    auto chunk_of = [&](uint32_t raw, int from) -> int {
+        const int local = __builtin_amdgcn_readfirstlane(static_cast<int>(raw));
+        const int c = from * chunks_per_group + local;
+        return local < chunks_per_group && c < n_chunks ? c : n_chunks;
+    };
+    // ... and when it is: look at the other workgroups' counters, 64 at a time round the ring, draw from the first range that still
+    // holds chunks, and so on until a chunk turns up or every range is found empty (a counter only grows: empty stays empty)
+    auto settle = [&](uint32_t raw, int from) -> int {
+        int c = chunk_of(raw, from);
+        while (c >= n_chunks) {
+            int found = -1;
+            for (int base = 1; base < static_cast<int>(gridDim.x) && found < 0; base += 64) {
+                const int g = (victim + base + lane) % static_cast<int>(gridDim.x);
+                const bool in_ring = base + lane < static_cast<int>(gridDim.x);
+                uint32_t drawn = in_ring ? __hip_atomic_load(&sched[16 * g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+                asm volatile("" : "+v"(drawn));
+                const int range = min(chunks_per_group, n_chunks - g * chunks_per_group);
+                const unsigned long long holders = __ballot(in_ring && static_cast<int>(drawn) < range);
+                if (holders) found = __builtin_amdgcn_readlane(g, __ffsll(static_cast<long long>(holders)) - 1);
+            }
+            if (found < 0) return n_chunks;
+            victim = found;
+            uint32_t again = draw();
+            asm volatile("" : "+v"(again));
+            c = chunk_of(again, victim);
+        }
+        return c;
+    };
+    uint32_t first_raw = draw();
+    asm volatile("" : "+v"(first_raw));
+    int chunk = settle(first_raw, victim);
+    int next_chunk = n_chunks;
+    int planes_group = blockIdx.x + gridDim.x * wave;            // this wavefront's next density group
+    int until_planes = wave + 1;                                 // boards until it is due
+    int board = chunk * kChunkBoards, left_in_chunk = kChunkBoards;
+    fetch_row(board);
+    asm volatile("" : "+v"(next_black), "+v"(next_white));
+    uint32_t pending_raw = 0;
+    int pending_from = victim;
 
 #pragma unroll 1
-    for (int bi = 0; bi < kGroupBoards; ++bi) {
-        const int board = first_board + bi;
+    while (chunk < n_chunks) {
         const bool live = board < n_boards;
-        // the next board's planes are requested here, ahead of phases 0 .. 4, and waited for just before this iteration's stores:
+        // what this iteration needs from memory next is requested HERE, ahead of phases 0 .. 4 -- the next board's planes and,
+        // at the start of a chunk, the number of the next chunk -- and waited for in ONE place, just before the iteration's stores:
         // loads and stores share one in-order counter (vmcnt), so wherever else the wait stood it would also wait for stores
         // issued moments before (the compiler cannot count across the loop, it waits for everything).  There, the youngest
-        // outstanding operation is this load, a board's work old.
+        // outstanding operation is a board's work old.
         cur_black = next_black; cur_white = next_white;
-        if (bi + 1 < kGroupBoards) fetch_row(board + 1);
+        const int board_after = left_in_chunk > 1 ? board + 1 : next_chunk * kChunkBoards;      // (resolved during the chunk's first board)
+        fetch_row(board_after);
+        const bool new_chunk = left_in_chunk == kChunkBoards;
+        if (new_chunk) { pending_from = victim; pending_raw = draw(); }
 
         if (live) {
             // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words ----
@@ -437,6 +401,26 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 cnt += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(cnt), 0x112, 0xF, 0xF, false));       // row_shr:2
                 cnt += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(cnt), 0x111, 0xF, 0xF, false));       // row_shr:1
                 if (lane == 15) s_misc[0] = cnt;                // lane 15 holds the sum of lanes 0 .. 15 (my_row is zero in lane 15)
+            }
+            {
+                // Where is a colour's density count positive (<=> its weight positive: the +160 of Pattern.cpp:268)?  Wherever a stone
+                // of the colour lies under the 7x7 BlockWeights mask (Pattern.cpp:598-609) around the cell: the rows, dilated by the
+                // mask's row patterns -- 1001001 three rows away, 0111110 one and two rows away, 1110111 in the row itself -- and OR-ed
+                // over the seven rows, for both colours at once (black in the low, white in the high half word), restricted to empty cells.
+                // (a shift must not carry bits from one half word into the other: they are cut off first)
+                const uint32_t r = my_row;
+                const uint32_t l1 = (r & 0x3FFF3FFFu) << 1, l2 = (r & 0x1FFF1FFFu) << 2, l3 = (r & 0x0FFF0FFFu) << 3;
+                const uint32_t r1 = (r & 0x7FFE7FFEu) >> 1, r2 = (r & 0x7FFC7FFCu) >> 2, r3 = (r & 0x7FF87FF8u) >> 3;
+                const int far = static_cast<int>(r | l3 | r3), near = static_cast<int>(r | l1 | l2 | r1 | r2);
+                uint32_t g = l1 | l2 | l3 | r1 | r2 | r3;
+                g |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, near, 0x111, 0xF, 0xF, true)) | static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, near, 0x101, 0xF, 0xF, true));     // rows y -+ 1
+                g |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, near, 0x112, 0xF, 0xF, true)) | static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, near, 0x102, 0xF, 0xF, true));     // rows y -+ 2
+                g |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, far, 0x113, 0xF, 0xF, true)) | static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, far, 0x103, 0xF, 0xF, true));       // rows y -+ 3
+                const uint32_t empty = ~(r | (r >> 16)) & 0x7FFFu;
+                if (lane < 16) {
+                    s_rows[lane] = r;
+                    s_gate[lane] = g & (empty | (empty << 16));
+                }
             }
             {
                 // a stone turns its cell's blank (3) into black (0) or white (1) in the four lines through it: one XOR each.
@@ -514,32 +498,26 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             wave_phase_fence();
 
             // ---- phase 3: one lane per cell: area bonus, compound candidates ----
-            // The density planes themselves left in phase D; here only its gates matter: bit (cell) of gate1 / gate2 of the
-            // board's black column (lane 2 bi of phase D) and white column (lane 2 bi + 1), one ds_bpermute each.
             int n_cand = 0;                                         // wave-uniform
             if (phase_mask & 8) {
-                const int src_black = ((lane & 32) | (2 * bi)) * 4, src_white = src_black + 4;
-                const uint32_t sh = lane & 31;
     #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
-                    const int q = 64 * pass + lane;                 // the last pass has 33 cells: the gates of the cells beyond are zero
-                    const uint32_t g1b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate1[pass]))) >> sh) & 1u;
-                    const uint32_t g1w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate1[pass]))) >> sh) & 1u;
-                    const uint32_t g2b = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_black, static_cast<int>(gate2[pass]))) >> sh) & 1u;
-                    const uint32_t g2w = (static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(src_white, static_cast<int>(gate2[pass]))) >> sh) & 1u;
+                    const int q = 64 * pass + lane, qc = min(q, kCells - 1);        // the last pass has 33 cells
+                    const int y = (qc * 0x8889) >> 19, x = qc - 15 * y;
+                    const uint32_t gw = q < kCells ? s_gate[y] >> x : 0u;
                     // +160 in the own view where the colour's weight is positive (Pattern.cpp:268); adding zero elsewhere is harmless
-                    atomicAdd(&s_scores[0 * kCells + q], g1w * 160u);
-                    atomicAdd(&s_scores[3 * kCells + q], g1b * 160u);
-                    // compound candidates (Compound::Test, Pattern.cpp:424-433, and the density gate, Pattern.cpp:182): empty cells whose
-                    // LiveThree / DeadThree / LiveTwo '_' counters, each clipped to 2 (the reference's 2-bit shift flags), OR-ed over the
-                    // types, sum to two or more over the directions; decided in phase 3b
-                    const int qc = min(q, kCells - 1);
+                    atomicAdd(&s_scores[0 * kCells + qc], ((gw >> 16) & 1u) * 160u);
+                    atomicAdd(&s_scores[3 * kCells + qc], (gw & 1u) * 160u);
+                    // compound candidates (Compound::Test, Pattern.cpp:424-433): cells whose LiveThree / DeadThree / LiveTwo '_' counters, each
+                    // clipped to 2 (the reference's 2-bit shift flags), OR-ed over the types, sum to two or more over the directions (only
+                    // empty cells have counters: a '_' piece is a blank).  Decided in phase 3b, with the density gate of Pattern.cpp:182.
                     const uint32_t any = s_cnt[qc] | s_cnt[kCells + qc] | s_cnt[2 * kCells + qc];
                     const uint32_t upper = (any >> 1) | (any >> 2) | (any >> 3);
                     const uint32_t ge2 = upper & 0x11111111u, ge1 = (any | upper) & 0x11111111u;         // one bit per field with count >= 2 / >= 1
                     uint32_t cand = 0;
-                    if (__popc(ge1 & 0xFFFFu) + __popc(ge2 & 0xFFFFu) >= 2 && g2w) cand |= 1u;
-                    if (__popc(ge1 >> 16) + __popc(ge2 >> 16) >= 2 && g2b) cand |= 2u;
+                    if (__popc(ge1 & 0xFFFFu) + __popc(ge2 & 0xFFFFu) >= 2) cand |= 1u;
+                    if (__popc(ge1 >> 16) + __popc(ge2 >> 16) >= 2) cand |= 2u;
+                    if (q >= kCells) cand = 0u;
                     const unsigned long long pushers = __ballot(cand != 0u);
                     if (pushers) {
                         if (cand) {
@@ -561,8 +539,23 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 const uint32_t ce = s_queue[m];
                 const int q = ce & 255;
                 const uint32_t cw_l3 = s_cnt[q], cw_d3 = s_cnt[kCells + q], cw_l2 = s_cnt[2 * kCells + q];
+                // the density gate (Pattern.cpp:182): the colour's density COUNT at the cell must be two or more: its stones under the
+                // non-zero cells of the 7x7 BlockWeights mask around q, counted from the rows (black low, white high half word)
+                uint32_t dens_black = 0, dens_white = 0;
+                {
+                    const int qy = (q * 0x8889) >> 19, qx = q - 15 * qy;
+    #pragma unroll
+                    for (int dy = -3; dy <= 3; ++dy) {
+                        const int yy = qy + dy;
+                        const uint32_t pattern = dy == 0 ? 0x77u : (dy == 3 || dy == -3) ? 0x49u : 0x3Eu;      // 1110111, 1001001, 0111110
+                        const uint32_t mask = ((pattern << qx) >> 3) & 0x7FFFu;
+                        const uint32_t rw = (yy >= 0 && yy <= 14) ? s_rows[min(max(yy, 0), 14)] : 0u;
+                        dens_black += __popc(rw & mask);
+                        dens_white += __popc((rw >> 16) & mask);
+                    }
+                }
                 for (int c = 0; c < 2; ++c) {
-                    if (!((ce >> (8 + c)) & 1u)) continue;
+                    if (!((ce >> (8 + c)) & 1u) || (c ? dens_black : dens_white) < 2u) continue;
                     // state machine S0,L2,LD3,To33,To43,To44 = 0..5; a counter counts like the reference's 2-bit shift flags: 0, 1, 2 or more (Pattern.cpp:395-400)
                     int state = 0, l3 = 0, triple = 0, n_comp = 0;
                     uint32_t comps = 0;                         // 4 bits per component: dir | tslot << 2
@@ -644,17 +637,18 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
 
         }
 
-        asm volatile("" : "+v"(next_black), "+v"(next_white));    // the wait for the next board's planes (a use the compiler must honour)
+        asm volatile("" : "+v"(next_black), "+v"(next_white), "+v"(pending_raw));    // the wait for this iteration's loads (a use the compiler must honour)
+        if (new_chunk) next_chunk = settle(pending_raw, pending_from);
 
-        // ---- phase D, part 2: the group's density planes leave, in the board iteration that is this wavefront's turn ----
-        if (planes_out && bi == wave) {
-            int lane_p = lane0, first_p = first_board;         // opaque copies: what the passes derive from them is computed here, not kept
-            asm volatile("" : "+v"(lane_p), "+s"(first_p));     // in registers from the top of the group
-            density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
-        }
-        if (!live) {
-            if (!planes_out || bi >= wave) break;
-            continue;
+        // ---- phase D: every sixteen boards the wavefront takes its next density group ----
+        if (planes_out && live && --until_planes == 0) {
+            until_planes = kGroupBoards;
+            if (planes_group < n_groups) {
+                int lane_p = lane0, first_p = __builtin_amdgcn_readfirstlane(planes_group * kGroupBoards);    // opaque copies: what the passes derive from them is computed here, not kept in registers
+                asm volatile("" : "+v"(lane_p), "+s"(first_p));
+                density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
+                planes_group += gridDim.x * kBoardsPerBlock;
+            }
         }
 
         // ---- phase 5: results leave LDS ----
@@ -678,7 +672,35 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             }
         }
         wave_phase_fence();
+
+        // ---- the next board: of this chunk, or the first of the next one ----
+        if (--left_in_chunk == 0) {
+            chunk = next_chunk;
+            left_in_chunk = kChunkBoards;
+            board = chunk * kChunkBoards;
+        } else {
+            ++board;
+        }
     }
+    // this wavefront's density groups that its boards did not pay for (it found fewer than sixteen, or the batch is small)
+    if (planes_out)
+        for (; planes_group < n_groups; planes_group += gridDim.x * kBoardsPerBlock) {
+            int lane_p = lane0, first_p = __builtin_amdgcn_readfirstlane(planes_group * kGroupBoards);
+            asm volatile("" : "+v"(lane_p), "+s"(first_p));
+            density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
+        }
+    // the last workgroup to finish leaves the counters at zero for the next launch
+    // (the flag lives in the dynamic LDS block: a static __shared__ variable would take LDS address 0 from the automaton)
+    uint32_t* s_last = s_wtab_words + kWtabWords;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        *s_last = atomicAdd(&sched[16 * gridDim.x], 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*s_last) {
+        for (int g = threadIdx.x; g <= static_cast<int>(gridDim.x); g += kThreads) sched[16 * g] = 0u;
+        __threadfence();
     }
 }
 
@@ -751,13 +773,21 @@ struct Launch { int grid, n_groups; size_t lds; };
 Launch plan_launch(int n, const gmk::DeviceState& st) {
     Launch l;
     l.n_groups = (n + kGroupBoards - 1) / kGroupBoards;
-    l.grid = std::max(1, std::min(l.n_groups, st.cu_count * kMaxBlocksPerCu));
+    const int chunks = (n + kChunkBoards - 1) / kChunkBoards;
+    // one workgroup per CU; a small batch takes as many workgroups as it has chunks to hand out two to every wavefront
+    l.grid = std::max(1, std::min((chunks + 2 * kBoardsPerBlock - 1) / (2 * kBoardsPerBlock), st.cu_count * kMaxBlocksPerCu));
     l.lds = static_cast<size_t>(kBoardsPerBlock * kBoardWords + st.n_states * 4 + st.n_records * 4 + kStaticTableWords) * 4;
     return l;
 }
 
 bool g_jobs_uploaded = false;
 uint32_t* g_wtab = nullptr;
+// work counters of the kernel (see "work distribution" there), one set per launch in flight: launches on different streams
+// must not share a set, launches on one stream reuse theirs (the kernel leaves it at zero)
+constexpr int kSchedSets = 16;
+uint32_t* g_sched = nullptr;
+unsigned g_sched_next = 0;
+size_t g_sched_set_words = 0;
 
 }  // namespace
 
@@ -772,14 +802,20 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
         if (rc != GMK_OK) return rc;
         rc = upload_density_weights(&g_wtab);
         if (rc != GMK_OK) return rc;
+        g_sched_set_words = 16 * (static_cast<size_t>(st.cu_count * kMaxBlocksPerCu) + 1);
+        GMK_HIP_CHECK(hipMalloc(&g_sched, kSchedSets * g_sched_set_words * 4));
+        GMK_HIP_CHECK(hipMemset(g_sched, 0, kSchedSets * g_sched_set_words * 4));
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_positions_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_jobs_uploaded = true;
     }
     const Launch l = plan_launch(n, st);
     if (l.lds > 160u * 1024u) { gmk::set_error("gmk_eval_batch: tables do not fit in LDS (%zu bytes)", l.lds); return GMK_ERR_CAPACITY; }
     static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x7F;
+    // (a stream's launches run one after the other and may share a set; a capturing stream gets a set of its own per capture position,
+    // replays of the graph being ordered as well)
+    uint32_t* sched = g_sched + g_sched_set_words * (g_sched_next++ % kSchedSets);
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
-                       d_planes, n, l.n_groups, d_scores, d_density, d_totals, d_status,
+                       d_planes, n, l.n_groups, sched, d_scores, d_density, d_totals, d_status,
                        st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, g_wtab, phase_mask);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
