@@ -37,7 +37,6 @@ namespace {
 
 constexpr int kBoardsPerBlock = 16;               // wavefronts per workgroup, one board in flight each
 constexpr int kGroupBoards = 16;                  // boards whose density planes are one unit of work (the columns of phase D's matrix product)
-constexpr int kChunkBoards = 4;                   // boards a wavefront draws from the work counter at a time
 constexpr int kThreads = 64 * kBoardsPerBlock;
 constexpr int kCells = 225;
 constexpr int kQueueCap = 448;
@@ -55,7 +54,7 @@ constexpr int kMiscWords = 48;                   // [0] stones black | white << 
                                                  // [16..31] the rows (black | white << 16), [32..46] per row: cells where the colour's density count is >= 1
 constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
 static_assert(kZeroWords % 4 == 0 && kBoardWords % 4 == 0, "16-byte alignment of the per-board blocks");
-constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560 + 4;   // lane jobs, initial line words, the bits-to-bytes table and the weight table of phase D, a flag word
+constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560;   // lane jobs, initial line words, the bits-to-bytes table and the weight table of phase D
 
 // Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
@@ -258,7 +257,7 @@ __device__ __forceinline__ void density_planes_out(const uint16_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(kThreads)
-void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int n_groups, uint32_t* __restrict__ sched,
+void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, int n_groups,
                            int32_t* __restrict__ out_scores, int32_t* __restrict__ out_density,
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
@@ -290,18 +289,13 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
 
     // ---- work distribution ----
-    // Boards cost between a third and twice the average (8 .. 60 stones), so a fixed share of boards per wavefront leaves the
-    // kernel waiting for its unluckiest wavefront: with sixteen boards each, the slowest of 4 096 wavefronts takes 1.3 x the mean.
-    // Instead the boards are handed out in CHUNKS of kChunkBoards: every workgroup owns an equal range of chunks and a counter for
-    // it in device memory (one cache line each: a single counter for the whole chip serialises 16 384 atomics on one address); its
-    // wavefronts draw from that counter, and when the range is used up they go on to the next workgroup's counter, and so on round
-    // the ring, until every range is used up.  The density groups (phase D: the planes of sixteen boards, whose cost does not depend
-    // on the position) are dealt out statically, one per wavefront and sixteen boards, the wavefronts of a workgroup out of step so
-    // that one of them stores planes while the others evaluate.
-    // sched[16 g]: chunks drawn from workgroup g's range; sched[16 gridDim.x]: workgroups that are done (the last one zeroes everything).
+    // A wavefront takes groups of sixteen consecutive boards (consecutive groups go to different workgroups first, so that small
+    // batches still use every CU and a batch sorted by density still loads the CUs evenly), evaluates them one after the other
+    // and, in the board iteration that is its turn within the workgroup, sends the group's density planes off (phase D).
+    // (Handing the boards out dynamically -- chunk counters per workgroup with stealing round the ring -- evened out the wavefronts'
+    // finishing times, 86 % instead of 72 % of the kernel's run time busy, and changed nothing: the SIMDs are what is busy, not
+    // the slowest wavefront; measured 0.215 ms against 0.206 ms, see DESIGN.md.)
     const bool planes_out = out_density != nullptr && (phase_mask & 64) && !(phase_mask & 1024);
-    const int n_chunks = (n_boards + kChunkBoards - 1) / kChunkBoards;
-    const int chunks_per_group = (n_chunks + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
     int lane = lane0;
     const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
     const uint32_t lane_tag = static_cast<uint32_t>(lane) << 10;
@@ -318,66 +312,22 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         next_white = p[16];
     };
     auto take_row = [&](int b) -> uint32_t { return lane < 16 && b < n_boards ? cur_black | (cur_white << 16) : 0u; };
-    int victim = blockIdx.x;                                     // whose range this wavefront draws from
-    auto draw = [&]() -> uint32_t {                              // (the value lands in lane 0's register; it is read with readfirstlane once it is there)
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(&sched[16 * victim], 1u);
-        return v;
-    };
-    // the chunk a drawn number stands for, or n_chunks (= none) when the victim's range is used up
-    auto chunk_of = [&](uint32_t raw, int from) -> int {
-        const int local = __builtin_amdgcn_readfirstlane(static_cast<int>(raw));
-        const int c = from * chunks_per_group + local;
-        return local < chunks_per_group && c < n_chunks ? c : n_chunks;
-    };
-    // ... and when it is: look at the other workgroups' counters, 64 at a time round the ring, draw from the first range that still
-    // holds chunks, and so on until a chunk turns up or every range is found empty (a counter only grows: empty stays empty)
-    auto settle = [&](uint32_t raw, int from) -> int {
-        int c = chunk_of(raw, from);
-        while (c >= n_chunks) {
-            int found = -1;
-            for (int base = 1; base < static_cast<int>(gridDim.x) && found < 0; base += 64) {
-                const int g = (victim + base + lane) % static_cast<int>(gridDim.x);
-                const bool in_ring = base + lane < static_cast<int>(gridDim.x);
-                uint32_t drawn = in_ring ? __hip_atomic_load(&sched[16 * g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-                asm volatile("" : "+v"(drawn));
-                const int range = min(chunks_per_group, n_chunks - g * chunks_per_group);
-                const unsigned long long holders = __ballot(in_ring && static_cast<int>(drawn) < range);
-                if (holders) found = __builtin_amdgcn_readlane(g, __ffsll(static_cast<long long>(holders)) - 1);
-            }
-            if (found < 0) return n_chunks;
-            victim = found;
-            uint32_t again = draw();
-            asm volatile("" : "+v"(again));
-            c = chunk_of(again, victim);
-        }
-        return c;
-    };
-    uint32_t first_raw = draw();
-    asm volatile("" : "+v"(first_raw));
-    int chunk = settle(first_raw, victim);
-    int next_chunk = n_chunks;
-    int planes_group = blockIdx.x + gridDim.x * wave;            // this wavefront's next density group
-    int until_planes = wave + 1;                                 // boards until it is due
-    int board = chunk * kChunkBoards, left_in_chunk = kChunkBoards;
-    fetch_row(board);
-    asm volatile("" : "+v"(next_black), "+v"(next_white));
-    uint32_t pending_raw = 0;
-    int pending_from = victim;
+
+    for (int group = blockIdx.x + gridDim.x * wave; group < n_groups; group += gridDim.x * kBoardsPerBlock) {
+    const int first_board = group * kGroupBoards;
+    fetch_row(first_board);
+    asm volatile("" : "+v"(next_black), "+v"(next_white));        // (once per group: wait for them here)
 
 #pragma unroll 1
-    while (chunk < n_chunks) {
+    for (int bi = 0; bi < kGroupBoards; ++bi) {
+        const int board = first_board + bi;
         const bool live = board < n_boards;
-        // what this iteration needs from memory next is requested HERE, ahead of phases 0 .. 4 -- the next board's planes and,
-        // at the start of a chunk, the number of the next chunk -- and waited for in ONE place, just before the iteration's stores:
-        // loads and stores share one in-order counter (vmcnt), so wherever else the wait stood it would also wait for stores
+        // the next board's planes are requested HERE, ahead of phases 0 .. 4, and waited for in ONE place, just before the iteration's
+        // stores: loads and stores share one in-order counter (vmcnt), so wherever else the wait stood it would also wait for stores
         // issued moments before (the compiler cannot count across the loop, it waits for everything).  There, the youngest
         // outstanding operation is a board's work old.
         cur_black = next_black; cur_white = next_white;
-        const int board_after = left_in_chunk > 1 ? board + 1 : next_chunk * kChunkBoards;      // (resolved during the chunk's first board)
-        fetch_row(board_after);
-        const bool new_chunk = left_in_chunk == kChunkBoards;
-        if (new_chunk) { pending_from = victim; pending_raw = draw(); }
+        if (bi + 1 < kGroupBoards) fetch_row(board + 1);
 
         if (live) {
             // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words ----
@@ -637,18 +587,17 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
 
         }
 
-        asm volatile("" : "+v"(next_black), "+v"(next_white), "+v"(pending_raw));    // the wait for this iteration's loads (a use the compiler must honour)
-        if (new_chunk) next_chunk = settle(pending_raw, pending_from);
+        asm volatile("" : "+v"(next_black), "+v"(next_white));    // the wait for the next board's planes (a use the compiler must honour)
 
-        // ---- phase D: every sixteen boards the wavefront takes its next density group ----
-        if (planes_out && live && --until_planes == 0) {
-            until_planes = kGroupBoards;
-            if (planes_group < n_groups) {
-                int lane_p = lane0, first_p = __builtin_amdgcn_readfirstlane(planes_group * kGroupBoards);    // opaque copies: what the passes derive from them is computed here, not kept in registers
-                asm volatile("" : "+v"(lane_p), "+s"(first_p));
-                density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
-                planes_group += gridDim.x * kBoardsPerBlock;
-            }
+        // ---- phase D: the group's density planes leave, in the board iteration that is this wavefront's turn ----
+        if (planes_out && bi == wave) {
+            int lane_p = lane0, first_p = first_board;         // opaque copies: what the passes derive from them is computed here, not kept
+            asm volatile("" : "+v"(lane_p), "+s"(first_p));     // in registers from the top of the group
+            density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
+        }
+        if (!live) {
+            if (!planes_out || bi >= wave) break;
+            continue;
         }
 
         // ---- phase 5: results leave LDS ----
@@ -673,34 +622,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         }
         wave_phase_fence();
 
-        // ---- the next board: of this chunk, or the first of the next one ----
-        if (--left_in_chunk == 0) {
-            chunk = next_chunk;
-            left_in_chunk = kChunkBoards;
-            board = chunk * kChunkBoards;
-        } else {
-            ++board;
-        }
     }
-    // this wavefront's density groups that its boards did not pay for (it found fewer than sixteen, or the batch is small)
-    if (planes_out)
-        for (; planes_group < n_groups; planes_group += gridDim.x * kBoardsPerBlock) {
-            int lane_p = lane0, first_p = __builtin_amdgcn_readfirstlane(planes_group * kGroupBoards);
-            asm volatile("" : "+v"(lane_p), "+s"(first_p));
-            density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
-        }
-    // the last workgroup to finish leaves the counters at zero for the next launch
-    // (the flag lives in the dynamic LDS block: a static __shared__ variable would take LDS address 0 from the automaton)
-    uint32_t* s_last = s_wtab_words + kWtabWords;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        *s_last = atomicAdd(&sched[16 * gridDim.x], 1u) == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (*s_last) {
-        for (int g = threadIdx.x; g <= static_cast<int>(gridDim.x); g += kThreads) sched[16 * g] = 0u;
-        __threadfence();
     }
 }
 
@@ -773,22 +695,13 @@ struct Launch { int grid, n_groups; size_t lds; };
 Launch plan_launch(int n, const gmk::DeviceState& st) {
     Launch l;
     l.n_groups = (n + kGroupBoards - 1) / kGroupBoards;
-    const int chunks = (n + kChunkBoards - 1) / kChunkBoards;
-    // one workgroup per CU; a small batch takes as many workgroups as it has chunks to hand out two to every wavefront
-    l.grid = std::max(1, std::min((chunks + 2 * kBoardsPerBlock - 1) / (2 * kBoardsPerBlock), st.cu_count * kMaxBlocksPerCu));
+    l.grid = std::max(1, std::min(l.n_groups, st.cu_count * kMaxBlocksPerCu));
     l.lds = static_cast<size_t>(kBoardsPerBlock * kBoardWords + st.n_states * 4 + st.n_records * 4 + kStaticTableWords) * 4;
     return l;
 }
 
 bool g_jobs_uploaded = false;
 uint32_t* g_wtab = nullptr;
-// work counters of the kernel (see "work distribution" there), one set per launch in flight: launches on different streams
-// must not share a set, launches on one stream reuse theirs (the kernel leaves it at zero)
-constexpr int kSchedSets = 16;
-uint32_t* g_sched = nullptr;
-unsigned g_sched_next = 0;
-size_t g_sched_set_words = 0;
-
 }  // namespace
 
 extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores, int32_t* d_density,
@@ -802,20 +715,14 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
         if (rc != GMK_OK) return rc;
         rc = upload_density_weights(&g_wtab);
         if (rc != GMK_OK) return rc;
-        g_sched_set_words = 16 * (static_cast<size_t>(st.cu_count * kMaxBlocksPerCu) + 1);
-        GMK_HIP_CHECK(hipMalloc(&g_sched, kSchedSets * g_sched_set_words * 4));
-        GMK_HIP_CHECK(hipMemset(g_sched, 0, kSchedSets * g_sched_set_words * 4));
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_positions_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_jobs_uploaded = true;
     }
     const Launch l = plan_launch(n, st);
     if (l.lds > 160u * 1024u) { gmk::set_error("gmk_eval_batch: tables do not fit in LDS (%zu bytes)", l.lds); return GMK_ERR_CAPACITY; }
     static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x7F;
-    // (a stream's launches run one after the other and may share a set; a capturing stream gets a set of its own per capture position,
-    // replays of the graph being ordered as well)
-    uint32_t* sched = g_sched + g_sched_set_words * (g_sched_next++ % kSchedSets);
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
-                       d_planes, n, l.n_groups, sched, d_scores, d_density, d_totals, d_status,
+                       d_planes, n, l.n_groups, d_scores, d_density, d_totals, d_status,
                        st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, g_wtab, phase_mask);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
