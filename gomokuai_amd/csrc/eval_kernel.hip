@@ -416,8 +416,9 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     const unsigned long long emitters = __ballot(rec != 0u);
                     if (emitters) {
                         if (rec) {
-                            const int slot = n_queued + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u)));
+                            // (the running count goes in as the prefix count's start value: no separate add)
+                            const int slot = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), static_cast<uint32_t>(n_queued))));
                             // (beyond the capacity every entry lands on the last slot: the board is flagged below)
                             s_queue[min(slot, kQueueCap - 1)] = rec | (lane_tag + (static_cast<uint32_t>(step) << 16));
                         }
@@ -481,62 +482,61 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             }
             wave_phase_fence();
 
-            // ---- phase 3b: one lane per candidate cell: compound state machine (Pattern.cpp:440-486), critical-point deposits,
+            // ---- phase 3b: one lane per candidate cell and colour: compound state machine (Pattern.cpp:440-486), critical-point deposits,
             //      counter-move rescans queued in the upper half of the queue ----
             if (n_cand > kQueueCap / 2) { s_misc[2] = 1; n_cand = kQueueCap / 2; }
             if (phase_mask & 8)
-            for (int m = lane; m < n_cand; m += 64) {
-                const uint32_t ce = s_queue[m];
-                const int q = ce & 255;
-                const uint32_t cw_l3 = s_cnt[q], cw_d3 = s_cnt[kCells + q], cw_l2 = s_cnt[2 * kCells + q];
+            for (int v = lane; v < 2 * n_cand; v += 64) {                      // one lane per (candidate cell, colour): 0 white, 1 black
+                const uint32_t ce = s_queue[v >> 1];
+                const int q = ce & 255, c = v & 1;
+                if (!((ce >> (8 + c)) & 1u)) continue;
                 // the density gate (Pattern.cpp:182): the colour's density COUNT at the cell must be two or more: its stones under the
                 // non-zero cells of the 7x7 BlockWeights mask around q, counted from the rows (black low, white high half word)
-                uint32_t dens_black = 0, dens_white = 0;
+                uint32_t dens = 0;
                 {
-                    const int qy = (q * 0x8889) >> 19, qx = q - 15 * qy;
+                    const int qy = (q * 0x8889) >> 19, qx = q - 15 * qy, half = c ? 0 : 16;
     #pragma unroll
                     for (int dy = -3; dy <= 3; ++dy) {
                         const int yy = qy + dy;
                         const uint32_t pattern = dy == 0 ? 0x77u : (dy == 3 || dy == -3) ? 0x49u : 0x3Eu;      // 1110111, 1001001, 0111110
                         const uint32_t mask = ((pattern << qx) >> 3) & 0x7FFFu;
                         const uint32_t rw = (yy >= 0 && yy <= 14) ? s_rows[min(max(yy, 0), 14)] : 0u;
-                        dens_black += __popc(rw & mask);
-                        dens_white += __popc((rw >> 16) & mask);
+                        dens += __popc((rw >> half) & mask);
                     }
                 }
-                for (int c = 0; c < 2; ++c) {
-                    if (!((ce >> (8 + c)) & 1u) || (c ? dens_black : dens_white) < 2u) continue;
-                    // state machine S0,L2,LD3,To33,To43,To44 = 0..5; a counter counts like the reference's 2-bit shift flags: 0, 1, 2 or more (Pattern.cpp:395-400)
-                    int state = 0, l3 = 0, triple = 0, n_comp = 0;
-                    uint32_t comps = 0;                         // 4 bits per component: dir | tslot << 2
-                    for (int d = 0; d < 4; ++d) {
-                        const int f = 4 * (c * 4 + d);
-                        const int k3 = min((cw_l3 >> f) & 15u, 2u), kd = min((cw_d3 >> f) & 15u, 2u), k2 = min((cw_l2 >> f) & 15u, 2u);
-                        const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
-                        if (t < 0) continue;
-                        const int k = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
-                        if (t == 0) ++l3;
-                        for (int r = 0; r < k; ++r) {
-                            comps |= static_cast<uint32_t>(d | (t << 2)) << (4 * n_comp);
-                            ++n_comp;
-                            if (state == 0) state += cond;
-                            else if (state <= 2) state += cond + 1;
-                            else { triple = 1; state += (state == 5) ? 0 : cond - 1; }
-                        }
+                if (dens < 2u) continue;
+                // this colour's four direction fields of the three counter words
+                const uint32_t cw_l3 = s_cnt[q] >> (16 * c), cw_d3 = s_cnt[kCells + q] >> (16 * c), cw_l2 = s_cnt[2 * kCells + q] >> (16 * c);
+                // state machine S0,L2,LD3,To33,To43,To44 = 0..5; a counter counts like the reference's 2-bit shift flags: 0, 1, 2 or more (Pattern.cpp:395-400)
+                int state = 0, l3 = 0, triple = 0, n_comp = 0;
+                uint32_t comps = 0;                             // 4 bits per component: dir | tslot << 2
+                for (int d = 0; d < 4; ++d) {
+                    const int f = 4 * d;
+                    const int k3 = min((cw_l3 >> f) & 15u, 2u), kd = min((cw_d3 >> f) & 15u, 2u), k2 = min((cw_l2 >> f) & 15u, 2u);
+                    const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
+                    if (t < 0) continue;
+                    const int k = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
+                    if (t == 0) ++l3;
+                    for (int r = 0; r < k; ++r) {
+                        comps |= static_cast<uint32_t>(d | (t << 2)) << (4 * n_comp);
+                        ++n_comp;
+                        if (state == 0) state += cond;
+                        else if (state <= 2) state += cond + 1;
+                        else { triple = 1; state += (state == 5) ? 0 : cond - 1; }
                     }
-                    const int ctype = state - 3;
-                    if (ctype < 0 || ctype > 2) { s_misc[2] = 1; continue; }               // reference reads out of bounds here
-                    atomicAdd(&s_misc[12 + ctype], c ? 0x10000u : 1u);
-                    const int g_own = c ? 3 : 0, g_opp = c ? 2 : 1;
-                    atomicAdd(&s_scores[g_own * kCells + q], 600u * n_comp);               // updateCritical, both perspectives
-                    atomicAdd(&s_scores[g_opp * kCells + q], 600u * n_comp);
-                    if (triple || l3) continue;
-                    for (int i = 0; i < n_comp; ++i) {                                     // queue the counter-move rescans
-                        const uint32_t cd = (comps >> (4 * i)) & 15u;
-                        const uint32_t slot = atomicAdd(&s_misc[3], 1u);
-                        if (slot < kQueueCap / 2) s_queue[kQueueCap / 2 + slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(c) << 8) | (cd << 9);
-                        else s_misc[2] = 1;
-                    }
+                }
+                const int ctype = state - 3;
+                if (ctype < 0 || ctype > 2) { s_misc[2] = 1; continue; }                   // reference reads out of bounds here
+                atomicAdd(&s_misc[12 + ctype], c ? 0x10000u : 1u);
+                const int g_own = c ? 3 : 0, g_opp = c ? 2 : 1;
+                atomicAdd(&s_scores[g_own * kCells + q], 600u * n_comp);                   // updateCritical, both perspectives
+                atomicAdd(&s_scores[g_opp * kCells + q], 600u * n_comp);
+                if (triple || l3) continue;
+                for (int i = 0; i < n_comp; ++i) {                                         // queue the counter-move rescans
+                    const uint32_t cd = (comps >> (4 * i)) & 15u;
+                    const uint32_t slot = atomicAdd(&s_misc[3], 1u);
+                    if (slot < kQueueCap / 2) s_queue[kQueueCap / 2 + slot] = static_cast<uint32_t>(q) | (static_cast<uint32_t>(c) << 8) | (cd << 9);
+                    else s_misc[2] = 1;
                 }
             }
             wave_phase_fence();
