@@ -299,6 +299,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     int lane = lane0;
     const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
     const uint32_t lane_tag = static_cast<uint32_t>(lane) << 10;
+    const uint32_t line_init_lo = s_line_init[lane], line_init_hi = s_line_init[min(64 + lane, kLineWords - 1)];
     uint32_t* s_rows = s_misc + 16;
     uint32_t* s_gate = s_misc + 32;
     // a board's 64 B are fetched while the board before it is evaluated.  No branch around the loads (every lane reads some valid
@@ -337,8 +338,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 for (int i = 0; i < kZeroWords / 4; i += 64)
                     if (i + 64 <= kZeroWords / 4 || lane < kZeroWords / 4 - i) z[i] = make_uint4(0u, 0u, 0u, 0u);
             }
-            s_lines[lane] = s_line_init[lane];
-            if (lane < kLineWords - 64) s_lines[64 + lane] = s_line_init[64 + lane];
+            s_lines[lane] = line_init_lo;                       // (the all-blank line words wait in two registers, not in LDS: no read before the write)
+            if (lane < kLineWords - 64) s_lines[64 + lane] = line_init_hi;
             if (lane < kMiscWords) s_misc[lane] = 0;
             const uint32_t my_row = take_row(board);
             wave_phase_fence();
@@ -406,13 +407,10 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 uint32_t cur = static_cast<uint32_t>(syms) << 2;    // symbols 0..14 at bits 2..31
                 const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2..
                 uint32_t tw = 0;                                    // the previous step's table word (row 0 = root)
-#pragma unroll
-                for (int step = 0; step < kScanSteps; ++step) {
-                    if (step == 15) cur = rest;
-                    const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
-                    cur >>= 2;
-                    tw = *lds_word(addr);                       // (the table is at LDS address 0: the address is used as it is)
-                    const uint32_t rec = gmk::dev_trans_record(tw);
+                // The emission of step s is queued BEHIND the lookup of step s + 1 (the next address needs the table word only): the
+                // prefix count and the queue write then run in the shadow of that lookup's LDS round trip.
+                auto push = [&](uint32_t word, int step) {
+                    const uint32_t rec = gmk::dev_trans_record(word);
                     const unsigned long long emitters = __ballot(rec != 0u);
                     if (emitters) {
                         if (rec) {
@@ -424,26 +422,39 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                         }
                         n_queued += __popcll(emitters);
                     }
+                };
+#pragma unroll
+                for (int step = 0; step < kScanSteps; ++step) {
+                    if (step == 15) cur = rest;
+                    const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
+                    cur >>= 2;
+                    const uint32_t before = tw;
+                    tw = *lds_word(addr);                       // (the table is at LDS address 0: the address is used as it is)
+                    if (step > 0) push(before, step - 1);
                 }
+                push(tw, kScanSteps - 1);
                 if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
             }
             wave_phase_fence();
 
             // ---- phase 2: one lane per emitting transition: the score deposits of its 1-2 matches ----
             if (phase_mask & 4) {
+                uint32_t qe_next = s_queue[min(lane, kQueueCap - 1)];
                 for (int m = lane; m < n_queued; m += 64) {
-                    const uint32_t qe = s_queue[m];
+                    const uint32_t qe = qe_next;
+                    qe_next = s_queue[min(m + 64, kQueueCap - 1)];      // (the next round's entry is on its way while this one is worked on;
+                                                                         //  fetching its record and line jobs ahead as well measured no gain)
                     // which line of which lane, and where on it (symbol 0 of a line is its leading pad)
                     const int src_lane = (qe >> 10) & 63, src_step = static_cast<int>(qe >> 16);
-                    const uint4 rec = s_rec[qe & 1023u];
-                    const uint32_t ja = s_jobs[src_lane * 2], jb = s_jobs[src_lane * 2 + 1];
-                    const int first_len = static_cast<int>(ja & 15u) + 3;
-                    const uint32_t job = src_step < first_len ? ja : jb;
+                    const uint4 rec_now = s_rec[qe & 1023u];
+                    const uint32_t ja_now = s_jobs[src_lane * 2], jb_now = s_jobs[src_lane * 2 + 1];
+                    const int first_len = static_cast<int>(ja_now & 15u) + 3;
+                    const uint32_t job = src_step < first_len ? ja_now : jb_now;
                     const int pos = (src_step < first_len ? src_step : src_step - first_len) - 1;
                     const int dir = (job >> 12) & 3, stride = dir_stride(dir);
                     const int cell_at = static_cast<int>(((job >> 8) & 15u) * 15u + ((job >> 4) & 15u)) + pos * stride;
-                    deposit_match(rec.x, rec.y, cell_at, dir, stride, s_scores, s_cnt, s_misc);
-                    if (rec.z) deposit_match(rec.z, rec.w, cell_at, dir, stride, s_scores, s_cnt, s_misc);
+                    deposit_match(rec_now.x, rec_now.y, cell_at, dir, stride, s_scores, s_cnt, s_misc);
+                    if (rec_now.z) deposit_match(rec_now.z, rec_now.w, cell_at, dir, stride, s_scores, s_cnt, s_misc);
                 }
             }
             wave_phase_fence();
@@ -451,18 +462,28 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             // ---- phase 3: one lane per cell: area bonus, compound candidates ----
             int n_cand = 0;                                         // wave-uniform
             if (phase_mask & 8) {
+                // (the reads of all four passes first: the compiler cannot move a read above the atomics of the pass before it, and
+                // four round trips in a row are four waits)
+                uint32_t gate_word[4], any_cnt[4];
     #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int q = 64 * pass + lane, qc = min(q, kCells - 1);        // the last pass has 33 cells
+                    const int y = (qc * 0x8889) >> 19;
+                    gate_word[pass] = s_gate[y];
+                    any_cnt[pass] = s_cnt[qc] | s_cnt[kCells + qc] | s_cnt[2 * kCells + qc];
+                }
+    #pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int q = 64 * pass + lane, qc = min(q, kCells - 1);
                     const int y = (qc * 0x8889) >> 19, x = qc - 15 * y;
-                    const uint32_t gw = q < kCells ? s_gate[y] >> x : 0u;
+                    const uint32_t gw = q < kCells ? gate_word[pass] >> x : 0u;
                     // +160 in the own view where the colour's weight is positive (Pattern.cpp:268); adding zero elsewhere is harmless
                     atomicAdd(&s_scores[0 * kCells + qc], ((gw >> 16) & 1u) * 160u);
                     atomicAdd(&s_scores[3 * kCells + qc], (gw & 1u) * 160u);
                     // compound candidates (Compound::Test, Pattern.cpp:424-433): cells whose LiveThree / DeadThree / LiveTwo '_' counters, each
                     // clipped to 2 (the reference's 2-bit shift flags), OR-ed over the types, sum to two or more over the directions (only
                     // empty cells have counters: a '_' piece is a blank).  Decided in phase 3b, with the density gate of Pattern.cpp:182.
-                    const uint32_t any = s_cnt[qc] | s_cnt[kCells + qc] | s_cnt[2 * kCells + qc];
+                    const uint32_t any = any_cnt[pass];
                     const uint32_t upper = (any >> 1) | (any >> 2) | (any >> 3);
                     const uint32_t ge2 = upper & 0x11111111u, ge1 = (any | upper) & 0x11111111u;         // one bit per field with count >= 2 / >= 1
                     uint32_t cand = 0;
@@ -492,6 +513,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 if (!((ce >> (8 + c)) & 1u)) continue;
                 // the density gate (Pattern.cpp:182): the colour's density COUNT at the cell must be two or more: its stones under the
                 // non-zero cells of the 7x7 BlockWeights mask around q, counted from the rows (black low, white high half word)
+                // this colour's four direction fields of the three counter words (read together with the rows below: one round trip)
+                const uint32_t cw_l3 = s_cnt[q] >> (16 * c), cw_d3 = s_cnt[kCells + q] >> (16 * c), cw_l2 = s_cnt[2 * kCells + q] >> (16 * c);
                 uint32_t dens = 0;
                 {
                     const int qy = (q * 0x8889) >> 19, qx = q - 15 * qy, half = c ? 0 : 16;
@@ -505,8 +528,6 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     }
                 }
                 if (dens < 2u) continue;
-                // this colour's four direction fields of the three counter words
-                const uint32_t cw_l3 = s_cnt[q] >> (16 * c), cw_d3 = s_cnt[kCells + q] >> (16 * c), cw_l2 = s_cnt[2 * kCells + q] >> (16 * c);
                 // state machine S0,L2,LD3,To33,To43,To44 = 0..5; a counter counts like the reference's 2-bit shift flags: 0, 1, 2 or more (Pattern.cpp:395-400)
                 int state = 0, l3 = 0, triple = 0, n_comp = 0;
                 uint32_t comps = 0;                             // 4 bits per component: dir | tslot << 2
@@ -607,7 +628,10 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             if (out_scores) {
                 int4* dst = reinterpret_cast<int4*>(out_scores + static_cast<size_t>(board) * kScoreWords);
                 const int4* src = reinterpret_cast<const int4*>(s_scores);
-                for (int i = lane_b; i < kScoreWords / 4; i += 64) dst[i] = src[i];
+                // (all reads first: one LDS round trip instead of four)
+                const int4 v0 = src[lane_b], v1 = src[lane_b + 64], v2 = src[lane_b + 128], v3 = src[min(lane_b + 192, kScoreWords / 4 - 1)];
+                dst[lane_b] = v0; dst[lane_b + 64] = v1; dst[lane_b + 128] = v2;
+                if (lane_b + 192 < kScoreWords / 4) dst[lane_b + 192] = v3;
             }
             if (out_totals && lane_b < 11) out_totals[static_cast<size_t>(board) * 11 + lane_b] = s_misc[4 + lane_b];
             if (out_status && lane_b == 0) {
