@@ -5,27 +5,29 @@
 // scores[4][225], density[2][2][225], pattern / compound totals and winner.  The formulation is the one
 // validated against in-order replay in tests/test_formulation.py.
 //
-// The kernel is bound by VALU issue (PMC: ~85 % VALU busy, HBM traffic = the algorithmic bytes), so the design rule
-// below is "fewest wave-instructions per board":
-//   * one 64-lane wavefront per board, sixteen boards per 1024-thread workgroup (one workgroup per CU), persistent
-//     grid-stride loop: the automaton (dense DFA 556x4 words + emission records, ~14 KB) is staged at LDS address 0
-//     ONCE per workgroup, so a DFA step's address is just (next-row offset | symbol * 4); after that single barrier
-//     the waves never wait for each other (phases of one board are ordered by wavefront-scope fences only);
-//   * a wavefront takes SIXTEEN consecutive boards at a time.  Phase D, once per group: the 7x7 density stencil of all sixteen
-//     boards (both colours) on the matrix cores -- Out[cell][board, colour] = W[cell][cell'] * Stone[cell'][board, colour] with
-//     the constant banded weight matrix as the A operand of v_mfma_i32_32x32x32_i8 (62 MFMAs per group, small integers: exact);
-//     the accumulators go straight to HBM as 16-byte stores, and what the other phases need from the density (count >= 1 for
-//     the area bonus, count >= 2 for the compound gate, per empty cell and colour) stays in eight registers as bit strings;
+// The binding resources are the SIMDs' issue slots and the LDS round trips of a board's dependent chains (rocprofv3 PMC: a wavefront
+// issues 37 %, waits 42 % and is issue-stalled 21 % of its time; HBM traffic = 1.06 x the algorithmic bytes), with 16 boards of LDS
+// per CU.  So: few wave-instructions per board, few dependent LDS round trips, and the one dense piece on the matrix cores:
+//   * one 64-lane wavefront per board, sixteen boards in flight per 1024-thread workgroup (one workgroup per CU); the automaton
+//     (dense DFA 556x4 words + emission records, ~14 KB) is staged at LDS address 0 ONCE per workgroup, so a DFA step's address is
+//     just (next-row offset | symbol * 4); after that single barrier the waves never wait for each other (phases of one board are
+//     ordered by wavefront-scope fences only).  A wavefront takes groups of SIXTEEN consecutive boards;
 //   * phase 0: the two bit-planes become 88 "line words" (rows, columns, both diagonals) that already hold the 2-bit
-//     DFA symbols of their cells (one LDS XOR per stone and line);
+//     DFA symbols of their cells (one LDS XOR per stone and line); where a colour's density count is positive (the area
+//     bonus) comes from the rows dilated by the three row patterns of the 7x7 mask, with DPP row shifts;
 //   * phase 1: the 72 lines that can hold a pattern (>= 5 cells) are spread over the 64 lanes (the 8 shortest ride
-//     behind the shortest primaries: 19 steps per lane); a lane's lines are one stream of 2-bit symbols,
-//     a step is one LDS lookup; emitting transitions are queued by ballot prefix;
+//     behind the shortest primaries: 19 steps per lane, fully unrolled); a lane's lines are one stream of 2-bit symbols,
+//     a step is one LDS lookup; emitting transitions are queued by ballot prefix, in the shadow of the next step's lookup;
 //   * phase 2: one lane per queued transition: one 16-byte record read gives the (<= 2) matches, each with a
 //     compact list of <= 4 score deposits (ds_add_u32) and 4-bit per-(cell, colour, direction, type) counters;
-//   * phase 3: one lane per cell: area bonus and compound candidates from the gate bits of phase D and the counters;
+//   * phase 3: one lane per cell: area bonus, compound candidates from the counters; phase 3b: one lane per (candidate, colour):
+//     the density gate "count >= 2" from seven row popcounts, the compound state machine, +-600 deposits;
 //   * phase 4: eight lanes per compound component: its counter-move cells from the 13-symbol window around it;
-//   * phase 5: the 3.6 KB score block leaves LDS as coalesced 16-byte stores.
+//   * phase 5: the 3.6 KB score block leaves LDS as coalesced 16-byte stores;
+//   * phase D, once per group, in the board iteration that is the wavefront's turn within its workgroup: the density planes of the
+//     sixteen boards on the matrix cores -- Out[board, colour][cell] = Stone[board, colour][cell'] * W[cell'][cell], the stones as
+//     the A operand and the constant banded weight matrix (rows of a 6 KB table in LDS) as the B operand of
+//     v_mfma_i32_32x32x32_i8 (14 passes of 3-5 MFMAs, small integers: exact), stored as 2 x 128 contiguous bytes per instruction.
 // HBM traffic per board: 64 B in, 7 248 B out (7 312 B algorithmic); everything else stays on chip.
 #include <algorithm>
 #include <cstdlib>
