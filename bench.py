@@ -24,6 +24,9 @@ def measured_traffic(kernel, units_key, units):
         return None
 
 
+REDUCE_DEVICE = None          # torch device the cross-rank reductions run on: the GPU with RCCL, the CPU in the gloo rehearsal mode
+
+
 def measured_counter(kernel, key):
     """A derived figure of the committed rocprofv3 PMC passes (profiles/traffic.json), e.g. the share of VALU lanes that were active."""
     try:
@@ -94,7 +97,7 @@ def bench_mcts(args, G, torch, dev, rank, world, distributed):
     ms = sorted(times)[len(times) // 2]
     alg = tree.alg_bytes()
     if distributed:
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([ms], dtype=torch.float64, device=REDUCE_DEVICE or dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     tree.close()
@@ -115,7 +118,7 @@ def bench_mcts(args, G, torch, dev, rank, world, distributed):
         torch.cuda.synchronize()
         ms_s = e0.elapsed_time(e1)
         if distributed:
-            t = torch.tensor([ms_s], dtype=torch.float64, device=dev)
+            t = torch.tensor([ms_s], dtype=torch.float64, device=REDUCE_DEVICE or dev)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             ms_s = float(t[0])
         big.close()
@@ -163,7 +166,7 @@ def bench_evalstate(args, G, torch, dev, rank, world, distributed):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     if distributed:
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([ms], dtype=torch.float64, device=REDUCE_DEVICE or dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     meta = states.read()["meta"]
@@ -222,7 +225,7 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
     ms = min(times)
     st = tree.root_stats()
     if distributed:
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([ms], dtype=torch.float64, device=REDUCE_DEVICE or dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     tree.close()
@@ -265,7 +268,7 @@ def bench_rave(args, G, torch, dev, rank, world, distributed):
     ms = min(times)
     st = tree.root_stats()
     if distributed:
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([ms], dtype=torch.float64, device=REDUCE_DEVICE or dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     tree.close()
@@ -326,7 +329,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
         dv, dp = fused(s), net(s)
         err = max(float((dv[0] - dp[0]).abs().max()), float((dv[1] - dp[1]).abs().max()))
     if distributed:
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([ms], dtype=torch.float64, device=REDUCE_DEVICE or dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     tree.close()
@@ -473,8 +476,17 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GMK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":                                    # RCCL: one rank per GPU
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (GMK_BENCH_BACKEND=gloo): the ranks share the GPUs there are,
+            # barriers and reductions go over gloo on the CPU; everything else is the code the RCCL run executes
+            global REDUCE_DEVICE
+            REDUCE_DEVICE = torch.device("cpu")
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -529,7 +541,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps           # HIP events on the launch stream
     if distributed:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=REDUCE_DEVICE or dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
@@ -570,7 +582,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "batched AC-automaton position eval (K1), %d %s boards per GPU, 15x15, inputs resident in HBM"
                                    % (n, "random-opening" if args.kind == 0 else "clustered"),
-                       "boards_per_gpu": n, "parallelism": "boards sharded by rank, no collective",
+                       "boards_per_gpu": n, "parallelism": "boards sharded by rank, no collective" + ("" if os.environ.get("GMK_BENCH_BACKEND", "nccl") == "nccl" or world == 1
+                                                                                                       else " (REHEARSAL: %d ranks over gloo sharing %d GPU(s))" % (world, torch.cuda.device_count())),
                        "launch": "hipGraph replay of the K steps" if graph is not None else "K stream launches"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
