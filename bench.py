@@ -346,6 +346,55 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
                     "the select and expand kernels take the remainder"}
 
 
+def bench_selfplay(args, torch, dev, rank, world, distributed):
+    """BASELINE configs[3], the self-play data pipeline (network/data_helper.py:58-113): --selfplay-games games IN TOTAL, sharded by global
+    game id; every rank plays its shard to the end (K3 with continuous batching on the device, gmk_selfplay_run), builds the training
+    tuples on the device (K4 + K5), and the compact records travel to rank 0 (selfplay.gather_records: one batch of point-to-point
+    transfers, RCCL over xGMI).  The total is fixed, so this leg scales STRONGLY; its time is the slowest rank's, barrier to barrier."""
+    import time
+    from gomokuai_amd import selfplay
+    first, n = selfplay.shard(args.selfplay_games, rank, world)
+    P = args.mcts_playouts
+    torch.cuda.synchronize()
+    if distributed:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    rec = selfplay.play_games(n, P, first_game_id=first)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    states, values, pi = rec.to_samples(augment=False)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    # the rehearsal mode's gloo has no device transfers: there the same exchange runs on host copies of the records
+    gathered = selfplay.gather_records(rec if REDUCE_DEVICE is None else rec.cpu())
+    torch.cuda.synchronize()
+    if distributed:
+        torch.distributed.barrier()
+    t3 = time.perf_counter()
+    moves = int(rec.lens.sum())
+    n_tuples = int(states.shape[0])
+    times = [t1 - t0, t2 - t1, t3 - t2, t3 - t0]
+    if distributed:
+        t = torch.tensor(times, dtype=torch.float64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        times = [float(v) for v in t]
+        c = torch.tensor([moves, n_tuples, int(rec.overflow)], dtype=torch.int64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
+        moves, n_tuples, overflow = int(c[0]), int(c[1]), bool(int(c[2]))
+    else:
+        overflow = bool(rec.overflow)
+    if rank != 0:
+        return None
+    return {"metric": "self-play games/s", "value": args.selfplay_games / times[3], "unit": "games/s", "scaling": "strong",
+            "playouts_per_s": moves * P / times[0], "seconds": times[3], "play_s": times[0], "tuples_s": times[1], "gather_s": times[2],
+            "moves": moves, "training_tuples": n_tuples, "gathered_games": len(gathered), "gathered_first_game_id": int(gathered.first_game_id),
+            "arena_overflow": overflow,
+            "config": {"workload": "self-play data pipeline (K3 -> K4 + K5 -> gather), %d games in total x %d playouts per move, RandomPolicy c_puct=5 "
+                                   "c_rollouts=5, empty openings, visit counts recorded" % (args.selfplay_games, P),
+                       "games_per_gpu": n, "slots_per_gpu": min(n, selfplay.SLOTS_PER_GPU), "search_handles_per_gpu": 2 if n >= selfplay.HANDLES_FROM_GAMES else 1,
+                       "parallelism": "games sharded by global id, one gather of the compact records to rank 0"}}
+
+
 def cpu_baseline_trad(G, playouts):
     """The oracle's restatement of the same search (oracle/go_trad.c), single thread, ~5 s."""
     from oracle import oracle as O
@@ -398,6 +447,8 @@ def parse_args(argv=None):
     ap.add_argument("--mcts-playouts", type=int, default=800)
     ap.add_argument("--mcts-reps", type=int, default=3)
     ap.add_argument("--mcts-saturated-games", type=int, default=16384, help="games per GPU for the saturated-batch K3 figure beside configs[2]; 0 = skip")
+    ap.add_argument("--selfplay-games", type=int, default=32768,
+                    help="games IN TOTAL (over all GPUs) for the self-play pipeline measurement (BASELINE configs[3]); 0 = skip")
     ap.add_argument("--evalstate-games", type=int, default=1792, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
     ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
     ap.add_argument("--az-playouts", type=int, default=60)
@@ -565,6 +616,13 @@ def main():
     if args.az_games > 0:
         az = bench_az(args, G, torch, dev, rank, world, distributed)
 
+    pipeline = pipeline_error = None
+    if args.selfplay_games > 0:
+        try:
+            pipeline = bench_selfplay(args, torch, dev, rank, world, distributed)
+        except Exception as exc:                                  # the headline line must not be lost to this leg
+            pipeline_error = "%s: %s" % (type(exc).__name__, exc)
+
     if rank == 0:
         achieved = ALG_BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -593,6 +651,8 @@ def main():
         }
         if mcts is not None:
             out["secondary"] = mcts
+        if pipeline is not None or pipeline_error is not None:
+            out["selfplay_pipeline"] = pipeline if pipeline is not None else {"error": pipeline_error}
         if incremental is not None:
             out["incremental"] = incremental
         if trad is not None:

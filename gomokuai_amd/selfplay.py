@@ -77,36 +77,85 @@ class GameRecords:
         return out
 
 
+# Games in flight per MI355X for whole-game RandomPolicy self-play, and the number of search handles they are split over.  A search
+# launch ends with its slowest wavefront, so (a) fewer slots leave SIMDs idle while more slots lengthen the tail where the last games
+# run alone, and (b) two handles searching side by side on two streams fill each other's ends of launches (three or more lose again).
+# Measured, 32 768 games x 800 playouts per move, M playouts/s: one handle 8 192 slots 57, 16 384 slots 71, 24 576 slots 58, all at once 63;
+# two handles x 8 192 slots 80, x 10 240 78, x 16 384 77; three x 6 144 79; four x 4 096 61.  4 096 games: one handle 29, two 28.
+SLOTS_PER_GPU = 16384
+HANDLES_FROM_GAMES = 8192
+
+
 def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5.0, c_rollouts=5,
                opening_plies=0, record_visits=True, reuse_subtree=False, root_noise=None, max_moves=N, device=None,
-               node_capacity=None, slots=None):
+               node_capacity=None, slots="auto", handles="auto"):
     """Plays n_games complete games on the current GPU: every move = one K3 search of `playouts` playouts for all
     unfinished games, then `gmk_mcts_advance`.  Game g uses the global id first_game_id + g for its RNG streams, so
-    the records do not depend on how games are spread over GPUs.
+    the records do not depend on how games are spread over GPUs, slots or handles.
     slots: at most that many games in flight, with CONTINUOUS BATCHING on the device (gmk_selfplay_run): a slot whose game ends takes
-    the next unstarted game inside the step kernel, so the searches stay full instead of waiting for the longest game of the batch;
-    the records are the same as without slots (a game's random streams belong to the game)."""
+    the next unstarted game inside the step kernel, so the searches stay full instead of waiting for the longest game of the batch.
+    "auto" = SLOTS_PER_GPU when there are more games than that, else all games at once; None = all games at once.
+    handles: the games are split into that many contiguous blocks, each with its own search handle, HIP stream and host thread
+    (the slots are shared out between them); "auto" = 2 from HANDLES_FROM_GAMES games on, else 1."""
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
-    if slots is not None and slots < n_games:
+    if handles == "auto":
+        handles = 2 if n_games >= HANDLES_FROM_GAMES and opening_plies <= 8 else 1
+    if slots == "auto":
+        slots = SLOTS_PER_GPU if n_games > SLOTS_PER_GPU and opening_plies <= 8 else None
+    handles = max(1, min(int(handles), n_games))
+    if (slots is not None and slots < n_games) or handles > 1:
         if opening_plies > 8:
-            raise ValueError("play_games: slots take openings of at most 8 plies")
+            raise ValueError("play_games: slots and handles take openings of at most 8 plies")
         open_moves = open_lens = None
         if opening_plies > 0:
             m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
             open_moves, open_lens = m, np.minimum(l, opening_plies).astype(np.int32)
         cap = node_capacity if node_capacity is not None else playouts * N * (3 if reuse_subtree else 1) + 1
-        tree = G.BatchedMCTS(int(slots), c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap)
         d_moves = torch.zeros((n_games, N), dtype=torch.uint8, device=dev)
         d_lens = torch.zeros(n_games, dtype=torch.int32, device=dev)
         d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
         d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev) if record_visits else None
-        tree.selfplay_run(n_games, first_game_id, playouts, d_moves.data_ptr(), d_visits.data_ptr() if record_visits else None, d_lens.data_ptr(),
-                          d_winner.data_ptr(), open_moves, open_lens, reuse_subtree, root_noise if reuse_subtree else None, stream)
-        status = tree.root_stats()[4]
-        tree.close()
-        return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, bool((status & G.BatchedMCTS.STATUS_ARENA_FULL).any()))
+        noise = root_noise if reuse_subtree else None
+        total_slots = n_games if slots is None else max(handles, min(int(slots), n_games))
+        blocks = [((n_games * i) // handles, (n_games * (i + 1)) // handles) for i in range(handles)]
+        trees = [G.BatchedMCTS(min(hi - lo, -(-total_slots // handles)), c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap) for lo, hi in blocks]
+
+        def run_block(i, hip_stream):
+            lo, hi = blocks[i]
+            trees[i].selfplay_run(hi - lo, first_game_id + lo, playouts, d_moves[lo:].data_ptr(), d_visits[lo:].data_ptr() if record_visits else None,
+                                  d_lens[lo:].data_ptr(), d_winner[lo:].data_ptr(), None if open_moves is None else open_moves[lo:hi],
+                                  None if open_lens is None else open_lens[lo:hi], reuse_subtree, noise, hip_stream)
+
+        if handles == 1:
+            run_block(0, stream)
+        else:
+            import threading
+            torch.cuda.current_stream(dev).synchronize()          # the record buffers above are zeroed before another stream writes them
+            side = [torch.cuda.Stream(dev) for _ in range(handles)]
+            failed = [None] * handles
+
+            def worker(i):
+                try:
+                    torch.cuda.set_device(dev)                     # the HIP device is a property of the thread
+                    run_block(i, side[i].cuda_stream)              # returns with its stream drained
+                except BaseException as exc:
+                    failed[i] = exc
+
+            threads = [threading.Thread(target=worker, args=(i,)) for i in range(handles)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for exc in failed:
+                if exc is not None:
+                    raise exc
+        overflow = False
+        for tree in trees:
+            overflow = overflow or bool((tree.root_stats()[4] & G.BatchedMCTS.STATUS_ARENA_FULL).any())
+            tree.close()
+        return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, overflow)
     planes = np.zeros((n_games, 2, 16), dtype=np.uint16)
     last = np.full(n_games, -1, dtype=np.int16)
     moves0 = np.zeros((n_games, N), dtype=np.uint8)

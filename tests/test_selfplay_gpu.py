@@ -68,6 +68,11 @@ def test_continuous_batching_gives_the_same_games(opening_plies, reuse, noise):
     assert int(a.lens.min()) >= 9                       # whole games
     c = selfplay.play_games(n, playouts, seed=77, first_game_id=900, opening_plies=opening_plies, reuse_subtree=reuse, root_noise=noise, slots=64).cpu()      # more slots than games
     assert (a.moves == c.moves).all() and (a.winner == c.winner).all()
+    # three search handles side by side (own streams and host threads), 6 slots between them, and two handles with all games at once
+    for kw in ({"slots": 6, "handles": 3}, {"slots": None, "handles": 2}):
+        d = selfplay.play_games(n, playouts, seed=77, first_game_id=900, opening_plies=opening_plies, reuse_subtree=reuse, root_noise=noise, **kw).cpu()
+        assert not d.overflow
+        assert (a.lens == d.lens).all() and (a.winner == d.winner).all() and (a.moves == d.moves).all() and (a.visits == d.visits).all()
 
 
 def _oracle_game_reuse(O, game_id, playouts, seed, noise=None):

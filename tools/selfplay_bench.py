@@ -20,7 +20,8 @@ def main():
     ap.add_argument("--reuse", action="store_true", help="keep the subtree of the played move (MCTS::stepForward)")
     ap.add_argument("--noise", action="store_true", help="Default::AddNoise(0.05, 0.25) before every search (needs --reuse)")
     ap.add_argument("--augment", action="store_true")
-    ap.add_argument("--slots", type=int, default=None, help="games in flight: a finished game hands its slot to the next one (random: on the device, gmk_selfplay_run)")
+    ap.add_argument("--slots", default=None, help="games in flight: a finished game hands its slot to the next one (random: on the device, gmk_selfplay_run; default there: "
+                    "selfplay.SLOTS_PER_GPU when a rank has more games than that); 0 = all games at once")
     ap.add_argument("--policy", default="random", choices=["random", "traditional", "poolrave", "network"],
                     help="who plays: RandomPolicy (K3), TraditionalPolicy (K6), PoolRAVEPolicy (K8), the fused policy-value network (K7 + K9)")
     args = ap.parse_args()
@@ -36,15 +37,16 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     noise = (0.05, 0.25) if args.noise else None
+    slots = None if args.slots in ("0", 0) else int(args.slots) if args.slots is not None else ("auto" if args.policy == "random" else None)
     if args.policy == "random":
-        rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse, root_noise=noise, slots=args.slots)
+        rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse, root_noise=noise, slots=slots)
     elif args.policy == "network":
         from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
         net = FusedPolicyValueNetwork(PolicyValueNetwork(seed=1).cuda().eval())
         rec = selfplay.play_network_games(n, net, args.playouts, first_game_id=first, opening_plies=2, reuse_subtree=args.reuse, root_noise=noise)
     else:
         rec = selfplay.play_supervisor_games(n, args.playouts, c_puct=5.0 if args.policy == "traditional" else 2.0, first_game_id=first, opening_plies=2,
-                                             reuse_subtree=args.reuse, root_noise=noise, policy=args.policy, slots=args.slots)
+                                             reuse_subtree=args.reuse, root_noise=noise, policy=args.policy, slots=slots)
     torch.cuda.synchronize()
     t_play = time.perf_counter() - t0
     t1 = time.perf_counter()
