@@ -264,7 +264,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
                            int trans_words, int record_words, const uint32_t* __restrict__ g_wtab,
-                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D (bit 8: its planes 1 KB apart, bit 9: passes without stores, bit 10: no passes); 0x7F in production */) {
+                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D (bit 8: its planes 1 KB apart, bit 9: passes without stores, bit 10: no passes; bit 11: no compounds = phases 3b and 4 skipped); 0x7F in production */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [trans (LDS address 0)][records (16-byte aligned)][lane jobs 128][initial line words 96][boards: kBoardsPerBlock * kBoardWords]
     const uint4* s_rec = reinterpret_cast<const uint4*>(lds + trans_words);
@@ -508,6 +508,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             // ---- phase 3b: one lane per candidate cell and colour: compound state machine (Pattern.cpp:440-486), critical-point deposits,
             //      counter-move rescans queued in the upper half of the queue ----
             if (n_cand > kQueueCap / 2) { s_misc[2] = 1; n_cand = kQueueCap / 2; }
+            if (phase_mask & 2048) n_cand = 0;
             if (phase_mask & 8)
             for (int v = lane; v < 2 * n_cand; v += 64) {                      // one lane per (candidate cell, colour): 0 white, 1 black
                 const uint32_t ce = s_queue[v >> 1];

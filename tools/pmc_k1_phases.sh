@@ -1,7 +1,7 @@
 #!/bin/bash
 # K1 per-phase figures (profiling aid): kernel time and VALU / SALU / LDS wave-instructions per board with subsets of the phases
 # enabled (GMK_EVAL_PHASE_MASK: 1 phase 0, 2 scan, 4 deposits, 8 phase 3, 16 rescans, 32 score stores, 64 phase D;
-# 512 density passes without their stores, 1024 no density passes).  Results are wrong unless the mask is 127.
+# 512 density passes without their stores, 1024 no density passes, 2048 no compounds = phases 3b and 4 skipped).  Results are wrong unless the mask is 127.
 cd "${GRAFT_REPO_ROOT:-.}" && export TMPDIR=/tmp
 out=gpurun_out/pmc_k1p; rm -rf $out; mkdir -p $out
 export GMK_EVAL_REPS=20
