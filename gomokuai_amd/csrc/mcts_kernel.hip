@@ -39,6 +39,7 @@ using namespace gmk::rollout;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kMaxGamesPerBlock = 16;
 constexpr int kPathCap = 32;           // deeper descents fall back to walking parent[] with loads
+constexpr int kCellBlocks = 30;        // Philox blocks of a rollout: 29 cover 225 plies, one more is read ahead
 
 struct GameHeader {                 // 128 B per game, in HBM
     uint32_t rows[16];              // root position: black | white << 16 per row
@@ -64,7 +65,6 @@ struct SearchParams {
     int node_capacity;
     int n_games;
     int playouts;
-    int rollout_stride_log2;
     int profile;                    // GMK_MCTS_PROFILE=1: per-phase shader-clock sums into GameHeader::pad (diagnostic runs only)
     const float* value_table;       // float(double(sum) / double(c_rollouts)) at index sum + c_rollouts (Random.h:30-33): owned by the HANDLE, since
                                     // handles with different c_rollouts run side by side (supervisor against candidate)
@@ -96,8 +96,9 @@ __device__ __forceinline__ int row_scan(int v) {                        // inclu
 __global__ __launch_bounds__(64)
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
                           uint32_t* __restrict__ parent, const float* __restrict__ root_prior, SearchParams prm) {
-    extern __shared__ uint32_t s_lane_lines[];                   // rollout positions as line words, [word][rollout lane]: kLineWords * G * R words
-    __shared__ uint32_t s_leaf[kMaxGamesPerBlock][kLineWords];   // leaf position of each game as line words (rows first)
+    // dynamic LDS, sized by the games G and rollouts R of the block (lds_words() below): the rollout positions as line words
+    // [word][rollout lane], the rollouts' random cells [block of eight plies][rollout lane], the games' leaf positions, their paths
+    extern __shared__ uint32_t s_lane_lines[];
     __shared__ uint32_t s_cur[kMaxGamesPerBlock], s_ply[kMaxGamesPerBlock], s_last[kMaxGamesPerBlock];
     __shared__ uint32_t s_need[kMaxGamesPerBlock];               // 1: leaf needs rollouts, 0: terminal
     __shared__ float s_term_value[kMaxGamesPerBlock];
@@ -106,9 +107,8 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     __shared__ unsigned long long s_bytes[kMaxGamesPerBlock];
     __shared__ uint32_t s_active[kMaxGamesPerBlock];
     // the descent path with the statistics select already loaded: backup needs no loads (MonteCarlo.hpp:90-95)
-    __shared__ uint32_t s_path_node[kMaxGamesPerBlock][kPathCap], s_path_visits[kMaxGamesPerBlock][kPathCap];
-    __shared__ float s_path_value[kMaxGamesPerBlock][kPathCap];
     __shared__ uint32_t s_depth[kMaxGamesPerBlock];             // 0: the game is over (status bit 0), nothing to search
+    __shared__ uint32_t s_rng_game[kMaxGamesPerBlock], s_rng_playout[kMaxGamesPerBlock], s_rng_stones[kMaxGamesPerBlock];   // Philox counter words of a game's rollouts
 
     const int lane = threadIdx.x, quarter = lane >> 4, l16 = lane & 15;
     const int G = prm.games_per_block, R = prm.c_rollouts;
@@ -123,8 +123,18 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         s_status[lane] = ok ? headers[game0 + lane].status : 0;
         s_bytes[lane] = 0;
         s_active[lane] = (ok && !(headers[game0 + lane].status & 1u)) ? 1u : 0u;
+        s_rng_game[lane] = ok ? headers[game0 + lane].game_id : 0u;
+        s_rng_playout[lane] = ok ? headers[game0 + lane].playouts_done : 0u;
+        s_rng_stones[lane] = ok ? headers[game0 + lane].stones << 8 : 0u;
     }
     __syncthreads();
+    const int n_rollout_lanes = G * R;
+    uint2* const s_cells = reinterpret_cast<uint2*>(s_lane_lines + kLineWords * n_rollout_lanes);
+    uint32_t (*const s_leaf)[kLineWords] = reinterpret_cast<uint32_t (*)[kLineWords]>(s_lane_lines + (kLineWords + 2 * kCellBlocks) * n_rollout_lanes);   // leaf position of each game as line words (rows first)
+    uint32_t (*const s_path_node)[kPathCap] = reinterpret_cast<uint32_t (*)[kPathCap]>(&s_leaf[G][0]);
+    uint32_t (*const s_path_visits)[kPathCap] = s_path_node + G;
+    float (*const s_path_value)[kPathCap] = reinterpret_cast<float (*)[kPathCap]>(s_path_visits + G);
+    const uint32_t inv_lanes = 0xFFFFFFFFu / static_cast<uint32_t>(n_rollout_lanes) + 1u, inv_r = 0xFFFFFFFFu / static_cast<uint32_t>(R) + 1u;   // t / d = umulhi(t, inv) for the small t here
 
     unsigned long long prof[4] = {0, 0, 0, 0}, t_mark = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;   // diagnostic build only
     for (int playout = 0; playout < prm.playouts; ++playout) {
@@ -232,18 +242,27 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         __syncthreads();
         if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[1] += t - t_mark; t_mark = t; }
 
-        // ---- simulate: one lane per rollout (Random.h:22-35) ----
+        // ---- simulate (Random.h:22-35).  First the random cells of all rollouts, with all 64 lanes: one Philox block = eight plies
+        //      per task, block-major, so that the rollout loop below only plays (the generator is ~150 instructions a block, and
+        //      a third of the lanes roll out) ----
+        for (int t = lane; t < 29 * n_rollout_lanes; t += 64) {
+            const uint32_t b = __umulhi(static_cast<uint32_t>(t), inv_lanes), rl = static_cast<uint32_t>(t) - b * static_cast<uint32_t>(n_rollout_lanes);
+            const uint32_t gs = __umulhi(rl, inv_r), r = rl - gs * static_cast<uint32_t>(R);
+            if (static_cast<int>(gs) < games_here && s_active[gs] && s_need[gs] && 8u * b < 225u - s_ply[gs])
+                s_cells[b * static_cast<uint32_t>(n_rollout_lanes) + rl] = rollout_cells(s_rng_game[gs], s_rng_playout[gs] + static_cast<uint32_t>(playout), s_rng_stones[gs] | r,
+                                                                                       b, prm.seed_lo, prm.seed_hi);
+        }
+        __syncthreads();
+        // one lane per rollout
         {
-            const int gs = lane / R, r = lane - gs * R;
+            const int gs = lane / R;
             if (gs < games_here && gs < G && s_active[gs] && s_need[gs]) {
-                const int rl_log2 = prm.rollout_stride_log2;         // rollout lanes of this block, rounded up to a power of two
-                for (int w = 0; w < kLineWords; ++w) s_lane_lines[(w << rl_log2) + lane] = s_leaf[gs][w];
+                for (int w = 0; w < kLineWords; ++w) s_lane_lines[w * n_rollout_lanes + lane] = s_leaf[gs][w];
                 const uint32_t ply = s_ply[gs];
                 const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
-                const GameHeader& hdr = headers[game0 + gs];
-                const int winner = random_rollout(&s_lane_lines[lane], rl_log2, init_player, static_cast<int>(ply), hdr.game_id,
-                                                  hdr.playouts_done + static_cast<uint32_t>(playout), (hdr.stones << 8) | static_cast<uint32_t>(r),
-                                                  prm.seed_lo, prm.seed_hi);
+                const uint2* my_cells = s_cells + lane;
+                const int winner = random_rollout_blocks(&s_lane_lines[lane], static_cast<uint32_t>(n_rollout_lanes), init_player, static_cast<int>(ply),
+                                                         [&](uint32_t b) { return my_cells[b * static_cast<uint32_t>(n_rollout_lanes)]; });
                 atomicAdd(&s_sum[gs], init_player * winner);         // CalcScore(init_player, winner)
             }
         }
@@ -645,6 +664,11 @@ extern "C" int gmk_mcts_set_game_ids(gmk_mcts* m, const uint32_t* h_ids) {
     return GMK_OK;
 }
 
+// dynamic LDS of mcts_playouts_kernel in words: line words and cell blocks per rollout lane, leaf position and path per game
+static size_t lds_words(int games_per_block, int c_rollouts) {
+    return static_cast<size_t>(kLineWords + 2 * kCellBlocks) * games_per_block * c_rollouts + static_cast<size_t>(kLineWords + 3 * kPathCap) * games_per_block;
+}
+
 extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     if (m && !m->rooted) { gmk::set_error("gmk_mcts_run: gmk_mcts_set_roots has not been called"); return GMK_ERR_STATE; }
     if (!m || playouts < 0) { gmk::set_error("gmk_mcts_run: bad arguments"); return GMK_ERR_ARG; }
@@ -654,13 +678,10 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     prm.c_rollouts = m->c_rollouts; prm.games_per_block = m->games_per_block;
     prm.node_capacity = m->node_capacity; prm.n_games = m->n_games; prm.playouts = playouts;
     const int grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
-    int stride_log2 = 0;
-    while ((1 << stride_log2) < m->games_per_block * m->c_rollouts) ++stride_log2;
-    prm.rollout_stride_log2 = stride_log2;
     prm.profile = std::getenv("GMK_MCTS_PROFILE") ? 1 : 0;
     prm.value_table = m->d_value;
     m->last_stream = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), (static_cast<size_t>(kLineWords) << stride_log2) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
+    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
                        m->d_root_prior, prm);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
@@ -840,7 +861,7 @@ extern "C" int gmk_mcts_launch_info(gmk_mcts* m, int* grid, int* block, int* lds
     if (!m) return GMK_ERR_ARG;
     if (grid) *grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
     if (block) *block = 64;
-    if (lds_bytes) *lds_bytes = kLineWords * m->games_per_block * m->c_rollouts * 4 + kMaxGamesPerBlock * (kLineWords * 4 + kPathCap * 12 + 48);
+    if (lds_bytes) *lds_bytes = static_cast<int>(lds_words(m->games_per_block, m->c_rollouts) * 4) + kMaxGamesPerBlock * 60;
     return GMK_OK;
 }
 

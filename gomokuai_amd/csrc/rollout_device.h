@@ -30,70 +30,70 @@ __device__ __forceinline__ uint2 rollout_cells(uint32_t game_id, uint32_t playou
     return make_uint2(cells_lo, cells_hi);
 }
 
-// Default::RandomRollout (MonteCarlo.hpp:37-47) on a lane-private set of line words; returns the winner (+1 / -1 / 0).
+// Default::RandomRollout (MonteCarlo.hpp:37-47) on a lane-private set of line words in LDS; returns the winner (+1 / -1 / 0).
 // A move sets one bit in the four lines through its cell; five-in-a-row through the new stone
 // (Board::checkGameEnd, Game.cpp:88-136) is a run of five in the mover's half of one of those four words.
-// Draws: block k >> 3 of the Philox stream (game_id, playout, c2), or, with Precomputed, cells[k >> 3] as rollout_cells
-// made them (a caller with idle lanes takes the generator off the serial chain that way).
-template <bool Precomputed>
-__device__ inline int random_rollout_impl(uint32_t* lines /* [word << stride_log2] */, int stride_log2, int to_move, int stones,
-                                          uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1, const uint2* cells) {
-    uint32_t cells_lo = 0, cells_hi = 0;                              // the next eight draws as bytes y | x << 4
-    uint2 ahead = Precomputed ? cells[0] : make_uint2(0u, 0u);
-    uint32_t stone = to_move > 0 ? 1u : 0x10000u, halves = to_move > 0 ? 0x05040100u : 0x07060302u;
-    // All rollouts of the wavefront step together (k is the same for all of them); a finished one is switched off by `live`
-    // and the loop ends on a wave-uniform test, so the back edge is a scalar branch instead of per-lane exec bookkeeping.
-    bool live = true;
-    int result = 0;
-    for (uint32_t k = 0;; ++k) {
-        if ((k & 7u) == 0u) {
-            if (Precomputed) {
-                cells_lo = ahead.x; cells_hi = ahead.y;
-                ahead = cells[min((k >> 3) + 1u, 28u)];               // in flight during the next eight plies
-            } else {
-                const uint2 c = rollout_cells(game_id, playout, c2, k >> 3, k0, k1);
-                cells_lo = c.x; cells_hi = c.y;
-            }
-        }
-        if (live) {
-        const uint32_t cell_byte = (((k & 4u) ? cells_hi : cells_lo) >> (8u * (k & 3u))) & 0xFFu;
-        int y = static_cast<int>(cell_byte & 15u);
-        int x = static_cast<int>(cell_byte >> 4);
-        uint32_t rw = lines[y << stride_log2];
-        uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
-        while (!open) {                                               // linear probe with wrap
-            y = (y == 14) ? 0 : y + 1;
-            rw = lines[y << stride_log2];
-            open = ~(rw | (rw >> 16)) & 0x7FFFu;
-        }
-        x = __ffs(open) - 1;
-        uint32_t* col = lines + ((kColBase + x) << stride_log2);
-        uint32_t* dia = lines + ((kDiagBase + x - y + 14) << stride_log2);
-        uint32_t* ant = lines + ((kAntiBase + x + y) << stride_log2);
-        const uint32_t r_new = rw | (stone << x);
-        const uint32_t c_new = *col | (stone << y);
-        const uint32_t d_new = *dia | (stone << min(x, y));
-        const uint32_t a_new = *ant | (stone << min(14 - x, y));
-        lines[y << stride_log2] = r_new; *col = c_new; *dia = d_new; *ant = a_new;
-        ++stones;
-        // the mover's halves of two line words side by side (bits 15 and 31 are gaps), one run test each
-        const uint32_t rc = __builtin_amdgcn_perm(c_new, r_new, halves), da = __builtin_amdgcn_perm(a_new, d_new, halves);
-        const uint32_t fives = (rc & (rc >> 1) & (rc >> 2) & (rc >> 3) & (rc >> 4)) | (da & (da >> 1) & (da >> 2) & (da >> 3) & (da >> 4));
-        if (fives != 0u || stones == 225) { result = fives ? to_move : 0; live = false; }     // one exit test per move
-        to_move = -to_move;
-        stone ^= 0x10001u;                                            // bit 0 for black, bit 16 for white
-        halves ^= 0x02020202u;                                        // byte selector: the low halves for black, the high halves for white
-        }
-        if (__ballot(live) == 0ull) return result;
-    }
-}
+// Draws: fetch(b) = block b of the lane's Philox stream as rollout_cells made it (the callers compute the blocks with all their lanes
+// before the rollout starts: the generator is ~150 instructions per eight plies, and a wavefront that is alone on its SIMD pays for
+// every instruction of the chain).  The loop body is one block = eight plies, unrolled: the cell's byte position, the mover's stone
+// bit and byte selector are then constants of the ply's position in the block, and line addresses are one multiply-add each.
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
+__device__ __forceinline__ lds_u32* lds_at(uint32_t byte_address) { return reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(byte_address)); }
 
-__device__ inline int random_rollout(uint32_t* lines, int stride_log2, int to_move, int stones,
-                                     uint32_t game_id, uint32_t playout, uint32_t c2, uint32_t k0, uint32_t k1) {
-    return random_rollout_impl<false>(lines, stride_log2, to_move, stones, game_id, playout, c2, k0, k1, nullptr);
-}
-__device__ inline int random_rollout_cells(uint32_t* lines, int stride_log2, int to_move, int stones, const uint2* cells /* [29] */) {
-    return random_rollout_impl<true>(lines, stride_log2, to_move, stones, 0u, 0u, 0u, 0u, 0u, cells);
+template <class Fetch>
+__device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], in LDS */, uint32_t stride /* words between a lane's line words */,
+                                            int to_move, int stones, Fetch fetch) {
+    const uint32_t sb = 4u * stride;                               // bytes (< 2^24: the multiply-adds below are 24-bit)
+    const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lines));
+    uint32_t col0 = base + kColBase * sb, dia0 = base + (kDiagBase + 14) * sb, ant0 = base + kAntiBase * sb;
+    asm volatile("" : "+v"(col0), "+v"(dia0), "+v"(ant0));         // kept in registers: a line's address is one multiply-add
+    // the movers of the even and of the odd plies: stone bit (bit 0 black, bit 16 white) and v_perm selector of the mover's halves
+    const uint32_t stone_even = to_move > 0 ? 1u : 0x10000u, stone_odd = stone_even ^ 0x10001u;
+    const uint32_t halves_even = to_move > 0 ? 0x05040100u : 0x07060302u, halves_odd = halves_even ^ 0x02020202u;
+    const int last_ply = 224 - stones;                             // the ply that fills the board
+    uint32_t won = 0;                                              // 2 | parity of the ply that made five, 0: none (yet)
+    // All rollouts of the wavefront step together; a finished one is switched off by `live` and the loop ends on a wave-uniform test
+    // (twice per block: the plies in between find no live lane and are skipped).
+    bool live = true;
+    uint2 cur = fetch(0u);
+    for (uint32_t b = 0;; ++b) {
+        const uint2 ahead = fetch(b + 1u);                          // in flight during these eight plies
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (live) {
+                const uint32_t cw = j < 4 ? cur.x : cur.y;
+                uint32_t y = (cw >> (8 * (j & 3))) & 15u, x = (cw >> (8 * (j & 3) + 4)) & 15u;
+                uint32_t row_at = base + __umul24(y, sb);
+                uint32_t rw = *lds_at(row_at);
+                uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
+                while (!open) {                                     // linear probe with wrap (Board::getRandomMove, Game.cpp:64-73)
+                    y = (y == 14u) ? 0u : y + 1u;
+                    row_at = base + __umul24(y, sb);
+                    rw = *lds_at(row_at);
+                    open = ~(rw | (rw >> 16)) & 0x7FFFu;
+                }
+                x = static_cast<uint32_t>(__ffs(open)) - 1u;
+                const uint32_t col_at = col0 + __umul24(x, sb), dia_at = dia0 + static_cast<uint32_t>(__mul24(static_cast<int>(x) - static_cast<int>(y), static_cast<int>(sb))),
+                               ant_at = ant0 + __umul24(x + y, sb);
+                const uint32_t stone = (j & 1) ? stone_odd : stone_even, halves = (j & 1) ? halves_odd : halves_even;
+                const uint32_t r_new = rw | (stone << x);
+                const uint32_t c_new = *lds_at(col_at) | (stone << y);
+                const uint32_t d_new = *lds_at(dia_at) | (stone << min(x, y));
+                const uint32_t a_new = *lds_at(ant_at) | (stone << min(14u - x, y));
+                *lds_at(row_at) = r_new; *lds_at(col_at) = c_new; *lds_at(dia_at) = d_new; *lds_at(ant_at) = a_new;
+                // the mover's halves of two line words side by side (bits 15 and 31 are gaps), one run test each
+                const uint32_t rc = __builtin_amdgcn_perm(c_new, r_new, halves), da = __builtin_amdgcn_perm(a_new, d_new, halves);
+                const uint32_t rc2 = rc & (rc >> 1), da2 = da & (da >> 1);                       // runs of two, of four, of five
+                const uint32_t rc4 = rc2 & (rc2 >> 2), da4 = da2 & (da2 >> 2);
+                const uint32_t fives = (rc4 & (rc >> 4)) | (da4 & (da >> 4));
+                if (fives != 0u) won = 2u | static_cast<uint32_t>(j & 1);
+                live = fives == 0u && static_cast<int>(8u * b) + j != last_ply;
+            }
+            if ((j & 3) == 3 && __ballot(live) == 0ull)
+                return won ? ((won & 1u) ? -to_move : to_move) : 0;
+        }
+        cur = ahead;
+    }
 }
 
 // five or more through cell (x, y) for the colour in bits [shift, shift+15), from line words at lines[word * Stride]
