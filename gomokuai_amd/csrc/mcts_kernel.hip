@@ -150,10 +150,11 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                 uint32_t cur = hdr.root, ply = hdr.stones, last = hdr.last_move;
                 unsigned long long bytes = 0;
                 uint2 cur_stats = stats[base + cur];
+                uint32_t cur_link = link[base + cur];
                 uint32_t depth = 0;
                 for (;;) {
                     if (l16 == 0 && depth < kPathCap) { s_path_node[gs][depth] = cur; s_path_visits[gs][depth] = cur_stats.x; s_path_value[gs][depth] = __uint_as_float(cur_stats.y); }
-                    const uint32_t first = link[base + cur] >> 8;
+                    const uint32_t first = cur_link >> 8;
                     if (!first) break;                               // Node::isLeaf
                     const int n_child = 225 - static_cast<int>(ply);
                     const double n_parent = static_cast<double>(cur_stats.x);
@@ -165,23 +166,43 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     double best = -2.0;
                     int best_i = 0;
                     uint2 best_st = make_uint2(0u, 0u);
+                    uint32_t best_link = 0u;
                     // all of this lane's children (i = l16, l16 + 16, ...: at most 15) are fetched before any is scored, so
-                    // the loads overlap instead of queueing behind each other's f64 divide
+                    // the loads overlap instead of queueing behind each other's f64 divide; their link words come with them:
+                    // the chosen child's is then at hand and the next level starts without a dependent load of its own
                     uint2 st[15];
+                    uint32_t lk[15];
 #pragma unroll
                     for (int j = 0; j < 15; ++j) {
                         const int i = l16 + 16 * j;
                         st[j] = (i < n_child) ? stats[base + first + i] : make_uint2(0u, 0u);
+                        lk[j] = (i < n_child) ? link[base + first + i] : 0u;
+                    }
+                    // the scores of all fifteen first, without a branch: fifteen independent f64 divide chains that the scheduler
+                    // interleaves (inside `if (i < n_child)` they ran one behind the other); a slot without a child scores explore / 1
+                    double score[15];
+                    if (__ballot(noisy) == 0ull) {
+#pragma unroll
+                        for (int j = 0; j < 15; ++j)
+                            score[j] = static_cast<double>(__uint_as_float(st[j].y)) + explore / static_cast<double>(st[j].x + 1u);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 15; ++j) {
+                            const int i = l16 + 16 * j;
+                            double bonus = explore;
+                            if (noisy && i < n_child) bonus = prm.c_puct * static_cast<double>(root_prior[static_cast<size_t>(game0 + gs) * 225 + i]) * root_n;
+                            score[j] = static_cast<double>(__uint_as_float(st[j].y)) + bonus / static_cast<double>(st[j].x + 1u);
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 15; ++j) {
                         const int i = l16 + 16 * j;
-                        if (i < n_child) {
-                            double bonus = explore;
-                            if (noisy) bonus = prm.c_puct * static_cast<double>(root_prior[static_cast<size_t>(game0 + gs) * 225 + i]) * root_n;
-                            const double score = static_cast<double>(__uint_as_float(st[j].y)) + bonus / static_cast<double>(st[j].x + 1u);
-                            if (score > best) { best = score; best_i = i; best_st = st[j]; }
-                        }
+                        const bool take = i < n_child && score[j] > best;
+                        best = take ? score[j] : best;
+                        best_i = take ? i : best_i;
+                        best_st.x = take ? st[j].x : best_st.x;
+                        best_st.y = take ? st[j].y : best_st.y;
+                        best_link = take ? lk[j] : best_link;
                     }
                     // first maximum wins (strict > in ascending order): (score, -index) is a total order, so rotating the
                     // row of 16 lanes by 8, 4, 2, 1 leaves the same winner in every lane - DPP moves, no LDS permute
@@ -191,6 +212,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     // the statistics of the chosen child sit in the lane that scored it (children i = l16 mod 16)
                     cur_stats.x = __shfl(best_st.x, best_i & 15, 16);
                     cur_stats.y = __shfl(best_st.y, best_i & 15, 16);
+                    cur_link = __shfl(best_link, best_i & 15, 16);
                     // its cell = the best_i-th empty cell of the current position in ascending order (children are created
                     // that way, MonteCarlo.hpp:71-80): no dependent load of link[]
                     {
@@ -257,7 +279,17 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         {
             const int gs = lane / R;
             if (gs < games_here && gs < G && s_active[gs] && s_need[gs]) {
-                for (int w = 0; w < kLineWords; ++w) s_lane_lines[w * n_rollout_lanes + lane] = s_leaf[gs][w];
+                // the leaf's line words into the lane's rollout position, 23 reads in flight at a time (one by one each copy is a
+                // round trip: the compiler cannot tell that the two regions are apart)
+                static_assert(kLineWords == 4 * 23, "copy batches");
+    #pragma unroll
+                for (int w0 = 0; w0 < kLineWords; w0 += 23) {
+                    uint32_t t[23];
+    #pragma unroll
+                    for (int i = 0; i < 23; ++i) t[i] = s_leaf[gs][w0 + i];
+    #pragma unroll
+                    for (int i = 0; i < 23; ++i) s_lane_lines[(w0 + i) * n_rollout_lanes + lane] = t[i];
+                }
                 const uint32_t ply = s_ply[gs];
                 const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
                 const uint2* my_cells = s_cells + lane;

@@ -54,17 +54,22 @@ __device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], 
     uint32_t won = 0;                                              // 2 | parity of the ply that made five, 0: none (yet)
     // All rollouts of the wavefront step together; a finished one is switched off by `live` and the loop ends on a wave-uniform test
     // (twice per block: the plies in between find no live lane and are skipped).
+    // The row word of a ply's cell is read one ply ahead, together with the three other lines of the ply before (one LDS round trip
+    // per ply instead of two: the wavefront is alone on its SIMD, nothing else covers the wait); that read is issued before the
+    // ply's writes, so the row the ply itself changes is taken from its registers instead.
     bool live = true;
     uint2 cur = fetch(0u);
+    uint32_t rw_ahead = *lds_at(base + __umul24(cur.x & 15u, sb));
     for (uint32_t b = 0;; ++b) {
         const uint2 ahead = fetch(b + 1u);                          // in flight during these eight plies
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (live) {
-                const uint32_t cw = j < 4 ? cur.x : cur.y;
+                const uint32_t cw = j < 4 ? cur.x : cur.y, cw_next = j + 1 < 4 ? cur.x : j + 1 < 8 ? cur.y : ahead.x;
                 uint32_t y = (cw >> (8 * (j & 3))) & 15u, x = (cw >> (8 * (j & 3) + 4)) & 15u;
+                const uint32_t y_next = (cw_next >> (8 * ((j + 1) & 3))) & 15u;
                 uint32_t row_at = base + __umul24(y, sb);
-                uint32_t rw = *lds_at(row_at);
+                uint32_t rw = rw_ahead;
                 uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
                 while (!open) {                                     // linear probe with wrap (Board::getRandomMove, Game.cpp:64-73)
                     y = (y == 14u) ? 0u : y + 1u;
@@ -76,11 +81,14 @@ __device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], 
                 const uint32_t col_at = col0 + __umul24(x, sb), dia_at = dia0 + static_cast<uint32_t>(__mul24(static_cast<int>(x) - static_cast<int>(y), static_cast<int>(sb))),
                                ant_at = ant0 + __umul24(x + y, sb);
                 const uint32_t stone = (j & 1) ? stone_odd : stone_even, halves = (j & 1) ? halves_odd : halves_even;
+                const uint32_t c_old = *lds_at(col_at), d_old = *lds_at(dia_at), a_old = *lds_at(ant_at);
+                const uint32_t next_row = *lds_at(base + __umul24(y_next, sb));
                 const uint32_t r_new = rw | (stone << x);
-                const uint32_t c_new = *lds_at(col_at) | (stone << y);
-                const uint32_t d_new = *lds_at(dia_at) | (stone << min(x, y));
-                const uint32_t a_new = *lds_at(ant_at) | (stone << min(14u - x, y));
+                const uint32_t c_new = c_old | (stone << y);
+                const uint32_t d_new = d_old | (stone << min(x, y));
+                const uint32_t a_new = a_old | (stone << min(14u - x, y));
                 *lds_at(row_at) = r_new; *lds_at(col_at) = c_new; *lds_at(dia_at) = d_new; *lds_at(ant_at) = a_new;
+                rw_ahead = y_next == y ? r_new : next_row;
                 // the mover's halves of two line words side by side (bits 15 and 31 are gaps), one run test each
                 const uint32_t rc = __builtin_amdgcn_perm(c_new, r_new, halves), da = __builtin_amdgcn_perm(a_new, d_new, halves);
                 const uint32_t rc2 = rc & (rc >> 1), da2 = da & (da >> 1);                       // runs of two, of four, of five
