@@ -633,8 +633,12 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 const int4* src = reinterpret_cast<const int4*>(s_scores);
                 // (all reads first: one LDS round trip instead of four)
                 const int4 v0 = src[lane_b], v1 = src[lane_b + 64], v2 = src[lane_b + 128], v3 = src[min(lane_b + 192, kScoreWords / 4 - 1)];
-                dst[lane_b] = v0; dst[lane_b + 64] = v1; dst[lane_b + 128] = v2;
-                if (lane_b + 192 < kScoreWords / 4) dst[lane_b + 192] = v3;
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i* dnt = reinterpret_cast<v4i*>(dst);
+                __builtin_nontemporal_store(v4i{v0.x, v0.y, v0.z, v0.w}, &dnt[lane_b]);
+                __builtin_nontemporal_store(v4i{v1.x, v1.y, v1.z, v1.w}, &dnt[lane_b + 64]);
+                __builtin_nontemporal_store(v4i{v2.x, v2.y, v2.z, v2.w}, &dnt[lane_b + 128]);
+                if (lane_b + 192 < kScoreWords / 4) __builtin_nontemporal_store(v4i{v3.x, v3.y, v3.z, v3.w}, &dnt[lane_b + 192]);
             }
             if (out_totals && lane_b < 11) out_totals[static_cast<size_t>(board) * 11 + lane_b] = s_misc[4 + lane_b];
             if (out_status && lane_b == 0) {
