@@ -30,17 +30,30 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
     if (game < n_games) {
         const uint4* src = reinterpret_cast<const uint4*>(states + static_cast<size_t>(game) * kStateWords);
         uint4* dst = reinterpret_cast<uint4*>(st);
-        for (int i = lane; i < kStateWords / 4; i += 64) dst[i] = src[i];
+        // six loads in flight per lane (one by one the copy is eighteen trips to memory in a row)
+        for (int i0 = lane; i0 < kStateWords / 4; i0 += 64 * 6) {
+            uint4 t[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) if (i0 + 64 * u < kStateWords / 4) t[u] = src[i0 + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) if (i0 + 64 * u < kStateWords / 4) dst[i0 + 64 * u] = t[u];
+        }
     }
     __syncthreads();
     if (game >= n_games) return;
     Ctx c{st, st + kStateWords, reinterpret_cast<const char*>(s_trans), reinterpret_cast<const uint4*>(s_trans + trans_words), lane,
           prof ? reinterpret_cast<unsigned long long*>(st + kStateWords + kScratchWords) : nullptr};
     if (prof && lane < 16) st[kStateWords + kScratchWords + lane] = 0u;
-    for (int m = 0; m < moves_per_game; ++m) {
-        const int mv = moves[static_cast<size_t>(game) * moves_per_game + m];
-        evaluator_step(c, mv);                                  // >= 0 apply, -2 revert, -1 nothing
-        wave_phase_fence();
+    // the script 64 steps at a time, one step per lane, handed out with v_readlane: a load per step would put a trip to memory in
+    // front of every update (the wavefront has nothing else to do meanwhile)
+    for (int m0 = 0; m0 < moves_per_game; m0 += 64) {
+        const int mine = m0 + lane < moves_per_game ? moves[static_cast<size_t>(game) * moves_per_game + m0 + lane] : -1;
+        const int steps = min(64, moves_per_game - m0);
+        for (int j = 0; j < steps; ++j) {
+            const int mv = __builtin_amdgcn_readlane(mine, j);
+            evaluator_step(c, mv);                              // >= 0 apply, -2 revert, -1 nothing
+            wave_phase_fence();
+        }
     }
     uint4* dst = reinterpret_cast<uint4*>(states + static_cast<size_t>(game) * kStateWords);
     const uint4* src = reinterpret_cast<const uint4*>(st);
