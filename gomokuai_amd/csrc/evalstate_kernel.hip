@@ -31,12 +31,15 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
         const uint4* src = reinterpret_cast<const uint4*>(states + static_cast<size_t>(game) * kStateWords);
         uint4* dst = reinterpret_cast<uint4*>(st);
         // six loads in flight per lane (one by one the copy is eighteen trips to memory in a row)
-        for (int i0 = lane; i0 < kStateWords / 4; i0 += 64 * 6) {
+        constexpr int kQuads = kStateWords / 4, kRounds = kQuads / 64;              // whole rounds of 64 lanes, then the rest
+        static_assert(kRounds % 6 == 5 && kQuads % 64 != 0, "copy batches below");
+#pragma unroll
+        for (int r0 = 0; r0 < kRounds + 1; r0 += 6) {
             uint4 t[6];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) if (i0 + 64 * u < kStateWords / 4) t[u] = src[i0 + 64 * u];
+            for (int u = 0; u < 6; ++u) t[u] = src[min(64 * (r0 + u) + lane, kQuads - 1)];          // (the last round is partly there: clamped, stored below only where it is)
 #pragma unroll
-            for (int u = 0; u < 6; ++u) if (i0 + 64 * u < kStateWords / 4) dst[i0 + 64 * u] = t[u];
+            for (int u = 0; u < 6; ++u) if (64 * (r0 + u) + lane < kQuads) dst[64 * (r0 + u) + lane] = t[u];
         }
     }
     __syncthreads();
