@@ -108,6 +108,12 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     __shared__ uint32_t s_active[kMaxGamesPerBlock];
     // the descent path with the statistics select already loaded: backup needs no loads (MonteCarlo.hpp:90-95)
     __shared__ uint32_t s_depth[kMaxGamesPerBlock];             // 0: the game is over (status bit 0), nothing to search
+    // the root as the launch found it (header fields) and as the playouts leave it (statistics, link word), and the leaf's link word:
+    // a playout then starts and expands without waiting for a load of its own
+    __shared__ uint32_t s_root[kMaxGamesPerBlock], s_root_stones[kMaxGamesPerBlock], s_root_last[kMaxGamesPerBlock], s_root_noise[kMaxGamesPerBlock];
+    __shared__ uint32_t s_root_rows[kMaxGamesPerBlock][16];
+    __shared__ uint2 s_root_stats[kMaxGamesPerBlock];
+    __shared__ uint32_t s_root_link[kMaxGamesPerBlock], s_leaf_link[kMaxGamesPerBlock];
     __shared__ uint32_t s_rng_game[kMaxGamesPerBlock], s_rng_playout[kMaxGamesPerBlock], s_rng_stones[kMaxGamesPerBlock];   // Philox counter words of a game's rollouts
 
     const int lane = threadIdx.x, quarter = lane >> 4, l16 = lane & 15;
@@ -126,7 +132,15 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         s_rng_game[lane] = ok ? headers[game0 + lane].game_id : 0u;
         s_rng_playout[lane] = ok ? headers[game0 + lane].playouts_done : 0u;
         s_rng_stones[lane] = ok ? headers[game0 + lane].stones << 8 : 0u;
+        const uint32_t root = ok ? headers[game0 + lane].root : 0u;
+        s_root[lane] = root;
+        s_root_stones[lane] = ok ? headers[game0 + lane].stones : 0u;
+        s_root_last[lane] = ok ? headers[game0 + lane].last_move : 255u;
+        s_root_noise[lane] = ok ? headers[game0 + lane].noise : 0u;
+        s_root_stats[lane] = ok ? stats[static_cast<size_t>(game0 + lane) * cap + root] : make_uint2(0u, 0u);
+        s_root_link[lane] = ok ? link[static_cast<size_t>(game0 + lane) * cap + root] : 0u;
     }
+    for (int i = lane; i < kMaxGamesPerBlock * 16; i += 64) s_root_rows[i >> 4][i & 15] = (i >> 4) < games_here ? headers[game0 + (i >> 4)].rows[i & 15] : 0u;
     __syncthreads();
     const int n_rollout_lanes = G * R;
     uint2* const s_cells = reinterpret_cast<uint2*>(s_lane_lines + kLineWords * n_rollout_lanes);
@@ -144,13 +158,13 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         for (int round = 0; round < rounds; ++round) {
             const int gs = round * 4 + quarter;
             if (gs < games_here && s_active[gs]) {
-                const GameHeader& hdr = headers[game0 + gs];
                 const size_t base = static_cast<size_t>(game0 + gs) * cap;
-                uint32_t row = hdr.rows[l16];                        // lane y holds row y of the board
-                uint32_t cur = hdr.root, ply = hdr.stones, last = hdr.last_move;
+                uint32_t row = s_root_rows[gs][l16];                 // lane y holds row y of the board
+                const uint32_t root = s_root[gs];
+                uint32_t cur = root, ply = s_root_stones[gs], last = s_root_last[gs];
                 unsigned long long bytes = 0;
-                uint2 cur_stats = stats[base + cur];
-                uint32_t cur_link = link[base + cur];
+                uint2 cur_stats = s_root_stats[gs];
+                uint32_t cur_link = s_root_link[gs];
                 uint32_t depth = 0;
                 for (;;) {
                     if (l16 == 0 && depth < kPathCap) { s_path_node[gs][depth] = cur; s_path_visits[gs][depth] = cur_stats.x; s_path_value[gs][depth] = __uint_as_float(cur_stats.y); }
@@ -160,7 +174,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     const double n_parent = static_cast<double>(cur_stats.x);
                     const double root_n = sqrt(n_parent);
                     const double explore = prm.c_puct * static_cast<double>(c_prior[n_child]) * root_n;   // MonteCarlo.hpp:23-28
-                    const bool noisy = hdr.noise && cur == hdr.root;  // only the root's children ever carry non-uniform priors
+                    const bool noisy = s_root_noise[gs] && cur == root;  // only the root's children ever carry non-uniform priors
                     // Default::Select starts from max_score = -1.0 with index 0 and takes strictly greater scores; every
                     // score is >= -1 (Q in [-1,1], bonus >= 0), so that equals "first maximum", which -2.0 yields lane-locally
                     double best = -2.0;
@@ -246,7 +260,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         atomicOr(&s_leaf[gs][kAntiBase + x + y], 1u << (min(14 - x, y) + cb));
                     }
                 }
-                if (l16 == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; s_depth[gs] = depth; }
+                if (l16 == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; s_depth[gs] = depth; s_leaf_link[gs] = cur_link; }
             }
         }
         __syncthreads();
@@ -327,7 +341,9 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                             parent[base + idx] = cur;
                         }
                         if (l16 == 0) {
-                            link[base + cur] = (first << 8) | (link[base + cur] & 0xFFu);
+                            const uint32_t expanded = (first << 8) | (s_leaf_link[gs] & 0xFFu);
+                            link[base + cur] = expanded;
+                            if (cur == s_root[gs]) s_root_link[gs] = expanded;
                             s_nodes[gs] = first + n_child;
                         }
                         bytes += static_cast<unsigned long long>(n_child) * 16ull;
@@ -347,6 +363,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         const float v = ((depth - d) & 1u) ? -value : value;
                         q += (v - q) / static_cast<float>(visits);
                         stats[base + s_path_node[gs][d]] = make_uint2(visits, __float_as_uint(q));
+                        if (d == 0u) s_root_stats[gs] = make_uint2(visits, __float_as_uint(q));          // level 0 of the path is the root
                     }
                     bytes += 16ull * (depth + 1u);
                 } else if (l16 == 0) {                               // very deep path: walk parent[] (loads)
@@ -357,6 +374,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         q += (value - q) / static_cast<float>(st.x);
                         st.y = __float_as_uint(q);
                         stats[base + node] = st;
+                        if (node == s_root[gs]) s_root_stats[gs] = st;
                         bytes += 16ull;
                     }
                 }
