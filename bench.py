@@ -617,7 +617,7 @@ def main():
         az = bench_az(args, G, torch, dev, rank, world, distributed)
 
     pipeline = pipeline_error = None
-    if args.selfplay_games > 0:
+    if args.selfplay_games >= world:                            # every rank needs a game (the same decision on all ranks: the leg has barriers)
         try:
             pipeline = bench_selfplay(args, torch, dev, rank, world, distributed)
         except Exception as exc:                                  # the headline line must not be lost to this leg

@@ -264,7 +264,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
                            int trans_words, int record_words, const uint32_t* __restrict__ g_wtab,
-                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D (bit 8: its planes 1 KB apart, bit 9: passes without stores, bit 10: no passes; bit 11: no compounds = phases 3b and 4 skipped); 0x7F in production */) {
+                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D (bit 8: its planes 1 KB apart, bit 9: passes without stores, bit 10: no passes; bit 11: no compounds = phases 3b and 4 skipped; bit 12: consecutive groups to different workgroups); 0x7F in production */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [trans (LDS address 0)][records (16-byte aligned)][lane jobs 128][initial line words 96][boards: kBoardsPerBlock * kBoardWords]
     const uint4* s_rec = reinterpret_cast<const uint4*>(lds + trans_words);
@@ -291,9 +291,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
 
     // ---- work distribution ----
-    // A wavefront takes groups of sixteen consecutive boards (consecutive groups go to different workgroups first, so that small
-    // batches still use every CU and a batch sorted by density still loads the CUs evenly), evaluates them one after the other
-    // and, in the board iteration that is its turn within the workgroup, sends the group's density planes off (phase D).
+    // A wavefront takes groups of sixteen consecutive boards, evaluates them one after the other and, in the board iteration that is
+    // its turn within the workgroup, sends the group's density planes off (phase D); which groups: see the loop below.
     // (Handing the boards out dynamically -- chunk counters per workgroup with stealing round the ring -- evened out the wavefronts'
     // finishing times, 86 % instead of 72 % of the kernel's run time busy, and changed nothing: the SIMDs are what is busy, not
     // the slowest wavefront; measured 0.215 ms against 0.206 ms, see DESIGN.md.)
@@ -316,7 +315,13 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     };
     auto take_row = [&](int b) -> uint32_t { return lane < 16 && b < n_boards ? cur_black | (cur_white << 16) : 0u; };
 
-    for (int group = blockIdx.x + gridDim.x * wave; group < n_groups; group += gridDim.x * kBoardsPerBlock) {
+    for (int base = 0; base < n_groups; base += gridDim.x * kBoardsPerBlock) {
+    // the workgroup's wavefronts take ADJACENT groups (as many per workgroup as it takes to give every workgroup some: sixteen in a
+    // full batch, one in a small one): what a CU writes at any time then lies within one megabyte, its density bursts follow one
+    // another through it (0.1859 -> 0.1805 ms against handing consecutive groups to different workgroups)
+    const int per_wg = min(kBoardsPerBlock, (n_groups - base + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x));
+    const int group = (phase_mask & 4096) ? base + static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) * wave : base + static_cast<int>(blockIdx.x) * per_wg + wave;
+    if (group >= n_groups || (!(phase_mask & 4096) && wave >= per_wg)) continue;
     const int first_board = group * kGroupBoards;
     fetch_row(first_board);
     asm volatile("" : "+v"(next_black), "+v"(next_white));        // (once per group: wait for them here)
