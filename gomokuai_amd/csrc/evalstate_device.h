@@ -21,9 +21,15 @@ constexpr int kCells = 225;
 // state layout, 32-bit words (the host mirrors it in gmk_evalstate_read)
 constexpr int kLineWords = 96, kColBase = 20, kDiagBase = 36, kAntiBase = 65;     // line words as in eval_kernel.hip: 2 bits per cell = its DFA
                                                                                  // symbol (0 black, 1 white, 3 blank), cell p of the line at bits 2p
+// The pattern distribution is [cell 0..225 (225 = the totals)][type 0..7] with ONE WORD OF SKEW EVERY EIGHT CELLS: the lanes of a phase
+// read the same type of cells along a line (strides 1, 15, 16, 14 cells = 8, 120, 128, 112 words: on 64 banks the diagonal's thirteen
+// cells shared ONE bank, the others 8 or 4 banks); with the skew a line's cells lie in different banks.  The host interface
+// (gmk_evalstate_read, gmk_trad_read_evaluators) keeps [226][8].
+__host__ __device__ constexpr int pdist_index(int cell, int type) { return cell * 8 + (cell >> 3) + type; }
+constexpr int kPdistWords = pdist_index(225, 7) + 1;
 constexpr int oLines = 0, oScores = oLines + kLineWords, oDensity = oScores + 4 * kCells, oPdist = oDensity + 4 * kCells,
-              oCdist = oPdist + 226 * 8, oRecord = oCdist + 226 * 3, oMeta = oRecord + 57;
-constexpr int kStateWords = (oMeta + 4 + 3) & ~3;                                // 4448 words = 17 792 B
+              oCdist = oPdist + kPdistWords, oRecord = oCdist + 226 * 3, oMeta = oRecord + 57;
+constexpr int kStateWords = (oMeta + 4 + 3) & ~3;                                // 4480 words = 17 920 B
 // meta: [0] moves played, [1] player to move (+1 black, -1 white, 0 game over), [2] winner, [3] error bits
 constexpr int kResultCap = 16;                                                   // matches covering the centre, per direction
 constexpr int kCompoundCap = 64;                                                 // compound components handled in one pass
@@ -46,6 +52,8 @@ struct Ctx {
     const uint4* rec;            // emission records
     int lane;
     unsigned long long* prof = nullptr;      // profiling aid (GMK_EVS_PROFILE): cycles per phase of update_move, summed by lane 0
+    int phases = 0x3F;                       // profiling aid (GMK_EVS_PHASE_MASK, K2 only): bit p runs phase p of update_move (match, compounds -, patterns -,
+                                             // board + block, patterns +, compounds +); the states are wrong unless it is 0x3F
 };
 
 __device__ __forceinline__ void prof_mark(const Ctx& c, int slot, unsigned long long& t_last) {
@@ -146,7 +154,7 @@ __device__ inline void update_patterns(const Ctx& c, int move, int slot, int del
     if (type == 8) { meta[1] = 0; meta[2] = fav ? 1 : -1; return; }                    // Five ends the game (:140-145)
     const int stride = dir_stride(dir);
     const int last_cell = move + back * stride;                                        // cell of the match's last symbol
-    atomicAdd(&c.st[oPdist + 225 * 8 + type], static_cast<uint32_t>(delta) << (16 * fav));      // Record::set(delta, favour) (:390-393)
+    atomicAdd(&c.st[oPdist + pdist_index(225, type)], static_cast<uint32_t>(delta) << (16 * fav));      // Record::set(delta, favour) (:390-393)
     const int score = delta * static_cast<int>(dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu));
     uint32_t* scores = c.st + oScores;
     const int n_dep = (w0 >> 8) & 7;
@@ -161,7 +169,7 @@ __device__ inline void update_patterns(const Ctx& c, int move, int slot, int del
         const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
         const int cell = last_cell - static_cast<int>(f & 7u) * stride;
         const bool blank = (f & 8u) != 0u;
-        words[d] = &c.st[oPdist + cell * 8 + type];
+        words[d] = &c.st[oPdist + pdist_index(cell, type)];
         lowers[d] = (d < n_dep ? 1u << ((4 * group2(fav, fav ^ 1) + dir) * 2) : 0u) |  // '_' and '^': the opponent's view
                     (blank ? 1u << ((4 * group2(fav, fav) + dir) * 2) : 0u);           // '_': the owner's view too
         olds[d] = set_flags_begin(words[d], delta, lowers[d]);
@@ -182,7 +190,7 @@ __device__ inline void update_patterns(const Ctx& c, int move, int slot, int del
 // Item: cell | black << 8 | compound type << 9 | direction << 11 | component type (0 L3, 1 D3, 2 L2) << 13 |
 //       look for counter moves << 15 | bump the compound total << 16
 __device__ inline void queue_compound(const Ctx& c, int cell, int pb /* player is black */, int delta) {
-    const uint32_t* pd = c.st + oPdist + cell * 8;
+    const uint32_t* pd = c.st + oPdist + pdist_index(cell, 0);
     const int g_own = group2(pb, pb);
     // locate(): state machine S0,L2,LD3,To33,To43,To44 = 0..5 over the directions; first present of L3, D3, L2 per direction
     int state = 0, l3 = 0, triple = 0, n_comp = 0;
@@ -301,7 +309,7 @@ __device__ inline void update_compounds(const Ctx& c, int move, int delta) {
         if (!(i == 6 && dir != 0) && ((syms >> (2 * i)) & 3u) == 3u) {
             const int cell = move + (i - 6) * dir_stride(dir);
             const int32_t* density = reinterpret_cast<const int32_t*>(c.st + oDensity);
-            const uint32_t* pd = c.st + oPdist + cell * 8;
+            const uint32_t* pd = c.st + oPdist + pdist_index(cell, 0);
             const uint32_t any = pd[5] | pd[4] | pd[3];
             for (int pb = 0; pb < 2; ++pb) {                    // { White, Black }
                 if (density[(pb * 2 + 0) * kCells + cell] < 2) continue;
@@ -366,13 +374,13 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     uint8_t* record = reinterpret_cast<uint8_t*>(c.st + oRecord);
     unsigned long long t_last = c.prof ? __builtin_amdgcn_s_memtime() : 0ull;
     // symbol the centre takes: the mover's stone (0 black, 1 white) when a move is applied, blank (3) when it is taken back
-    match_patterns_both(c, move, src != 0 ? (src > 0 ? 0u : 1u) : 3u);
+    if (c.phases & 1) match_patterns_both(c, move, src != 0 ? (src > 0 ? 0u : 1u) : 3u);
     wave_phase_fence();
     prof_mark(c, 0, t_last);
-    update_compounds(c, move, -1);
+    if (c.phases & 2) update_compounds(c, move, -1);
     wave_phase_fence();
     prof_mark(c, 1, t_last);
-    update_patterns(c, move, 0, -1);
+    if (c.phases & 4) update_patterns(c, move, 0, -1);
     wave_phase_fence();
     prof_mark(c, 2, t_last);
     // the stone itself (line words, move record, player to move) and the 7x7 block touch different words: one phase
@@ -390,13 +398,13 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
         if (c.lane == 0) { meta[0] = n - 1; meta[1] = mover; meta[2] = 0; }
         block_colour = mover > 0;
     }
-    update_block(c, move, src != 0 ? 1 : -1, block_colour);
+    if (c.phases & 8) update_block(c, move, src != 0 ? 1 : -1, block_colour);
     wave_phase_fence();
     prof_mark(c, 3, t_last);
-    update_patterns(c, move, 1, 1);
+    if (c.phases & 16) update_patterns(c, move, 1, 1);
     wave_phase_fence();
     prof_mark(c, 5, t_last);
-    update_compounds(c, move, 1);
+    if (c.phases & 32) update_compounds(c, move, 1);
     wave_phase_fence();
     prof_mark(c, 6, t_last);
     if (c.prof && c.lane == 0) c.prof[7] += 1;

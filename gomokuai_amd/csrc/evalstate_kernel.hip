@@ -18,7 +18,7 @@ constexpr int kThreads = 64 * kGamesPerBlock;
 __global__ __launch_bounds__(kThreads)
 void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __restrict__ moves, int moves_per_game, int n_games,
                              const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records, int trans_words, int record_words,
-                             unsigned long long* prof /* profiling aid, normally null: 8 counters per game */) {
+                             unsigned long long* prof /* profiling aid, normally null: 8 counters per game */, int phases /* profiling aid: 0x3F */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [games: kGamesPerBlock * (kStateWords + kScratchWords rounded)] [trans] [records]
     constexpr int kPerGame = (kStateWords + kScratchWords + 16 + 3) & ~3;     // + 8 profiling counters
@@ -45,7 +45,7 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
     __syncthreads();
     if (game >= n_games) return;
     Ctx c{st, st + kStateWords, reinterpret_cast<const char*>(s_trans), reinterpret_cast<const uint4*>(s_trans + trans_words), lane,
-          prof ? reinterpret_cast<unsigned long long*>(st + kStateWords + kScratchWords) : nullptr};
+          prof ? reinterpret_cast<unsigned long long*>(st + kStateWords + kScratchWords) : nullptr, phases};
     if (prof && lane < 16) st[kStateWords + kScratchWords + lane] = 0u;
     // the script 64 steps at a time, one step per lane, handed out with v_readlane: a load per step would put a trip to memory in
     // front of every update (the wavefront has nothing else to do meanwhile)
@@ -115,12 +115,13 @@ extern "C" int gmk_evalstate_update(gmk_evalstate* e, const int16_t* d_moves, in
     const int grid = (e->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
     unsigned long long* d_prof = nullptr;
     static const bool profile = std::getenv("GMK_EVS_PROFILE") != nullptr;
+    static const int phases = std::getenv("GMK_EVS_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVS_PHASE_MASK")) : 0x3F;
     if (profile) {
         GMK_HIP_CHECK(hipMalloc(&d_prof, static_cast<size_t>(e->n_games) * 8 * sizeof(unsigned long long)));
         GMK_HIP_CHECK(hipMemset(d_prof, 0, static_cast<size_t>(e->n_games) * 8 * sizeof(unsigned long long)));
     }
     hipLaunchKernelGGL(evalstate_update_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), e->d_states, d_moves,
-                       moves_per_game, e->n_games, st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, d_prof);
+                       moves_per_game, e->n_games, st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, d_prof, phases);
     GMK_HIP_CHECK(hipGetLastError());
     if (profile) {                                              // cycles per phase of Updater::updateMove, mean over games
         std::vector<unsigned long long> h(static_cast<size_t>(e->n_games) * 8);
@@ -161,7 +162,8 @@ extern "C" int gmk_evalstate_read(gmk_evalstate* e, int32_t* h_scores, int32_t* 
         const uint32_t* s = all.data() + static_cast<size_t>(g) * kStateWords;
         if (h_scores) std::memcpy(h_scores + static_cast<size_t>(g) * 900, s + oScores, 3600);
         if (h_density) std::memcpy(h_density + static_cast<size_t>(g) * 900, s + oDensity, 3600);
-        if (h_pattern_dist) std::memcpy(h_pattern_dist + static_cast<size_t>(g) * 226 * 8, s + oPdist, 226 * 8 * 4);
+        if (h_pattern_dist)
+            for (int cell = 0; cell < 226; ++cell) std::memcpy(h_pattern_dist + (static_cast<size_t>(g) * 226 + cell) * 8, s + oPdist + pdist_index(cell, 0), 32);
         if (h_compound_dist) std::memcpy(h_compound_dist + static_cast<size_t>(g) * 226 * 3, s + oCdist, 226 * 3 * 4);
         if (h_meta) std::memcpy(h_meta + static_cast<size_t>(g) * 4, s + oMeta, 16);
         if (h_record) std::memcpy(h_record + static_cast<size_t>(g) * 228, s + oRecord, 228);

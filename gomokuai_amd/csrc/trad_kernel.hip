@@ -128,7 +128,7 @@ __device__ __forceinline__ void decisive_filter(const uint32_t* st, int cur_blac
     // the totals the automaton looks at: pattern types 4..7 and the three compound types (one round of LDS reads)
     uint32_t totals[12];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) totals[i] = i >= 4 ? st[oPdist + 225 * 8 + i] : 0u;
+    for (int i = 0; i < 8; ++i) totals[i] = i >= 4 ? st[oPdist + pdist_index(225, i)] : 0u;
 #pragma unroll
     for (int i = 0; i < 3; ++i) totals[9 + i] = st[oCdist + 225 * 3 + i];
     totals[8] = 0u;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void decisive_filter(const uint32_t* st, int cur_blac
                 bool keep = false;
                 for (int k = head; k < n; ++k) {
                     const uint32_t pattern = (cands >> (16 * k)) & 0xFFu, pb = (cands >> (16 * k + 8)) & 1u;
-                    const uint32_t field = pattern < 9 ? st[oPdist + q * 8 + pattern] : st[oCdist + q * 3 + pattern - 9];
+                    const uint32_t field = pattern < 9 ? st[oPdist + pdist_index(q, static_cast<int>(pattern))] : st[oCdist + q * 3 + pattern - 9];
                     keep |= ((field >> (8 * group2(pb, cur_black))) & 0xFFu) != 0u;
                 }
                 if (!keep) probs.v[j] = 0.0f;
@@ -895,7 +895,8 @@ extern "C" int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t*
         const uint32_t* s = all.data() + static_cast<size_t>(g) * kStateWords;
         if (h_scores) std::memcpy(h_scores + static_cast<size_t>(g) * 900, s + oScores, 3600);
         if (h_density) std::memcpy(h_density + static_cast<size_t>(g) * 900, s + oDensity, 3600);
-        if (h_pattern_dist) std::memcpy(h_pattern_dist + static_cast<size_t>(g) * 226 * 8, s + oPdist, 226 * 8 * 4);
+        if (h_pattern_dist)
+            for (int cell = 0; cell < 226; ++cell) std::memcpy(h_pattern_dist + (static_cast<size_t>(g) * 226 + cell) * 8, s + oPdist + pdist_index(cell, 0), 32);
         if (h_compound_dist) std::memcpy(h_compound_dist + static_cast<size_t>(g) * 226 * 3, s + oCdist, 226 * 3 * 4);
         if (h_meta) std::memcpy(h_meta + static_cast<size_t>(g) * 4, s + oMeta, 16);
         if (h_record) std::memcpy(h_record + static_cast<size_t>(g) * 228, s + oRecord, 228);
