@@ -21,15 +21,16 @@ constexpr int kCells = 225;
 // state layout, 32-bit words (the host mirrors it in gmk_evalstate_read)
 constexpr int kLineWords = 96, kColBase = 20, kDiagBase = 36, kAntiBase = 65;     // line words as in eval_kernel.hip: 2 bits per cell = its DFA
                                                                                  // symbol (0 black, 1 white, 3 blank), cell p of the line at bits 2p
-// The pattern distribution is [cell 0..225 (225 = the totals)][type 0..7] with ONE WORD OF SKEW EVERY EIGHT CELLS: the lanes of a phase
-// read the same type of cells along a line (strides 1, 15, 16, 14 cells = 8, 120, 128, 112 words: on 64 banks the diagonal's thirteen
-// cells shared ONE bank, the others 8 or 4 banks); with the skew a line's cells lie in different banks.  The host interface
-// (gmk_evalstate_read, gmk_trad_read_evaluators) keeps [226][8].
-__host__ __device__ constexpr int pdist_index(int cell, int type) { return cell * 8 + (cell >> 3) + type; }
+// The pattern distribution is [cell 0..225 (225 = the totals)][type 0..7].  The lanes of a phase read ONE type of the cells along a line
+// (strides 1, 15, 16, 14 cells = 8, 120, 128, 112 words: on 64 banks a diagonal's thirteen cells share one bank, a row's or column's
+// eight, an anti-diagonal's four): this is where the update's 40 % bank-conflict share comes from.  A word of skew every eight cells
+// (cell * 8 + (cell >> 3) + type) halves the conflict cycles and leaves the time per update where it was, 25 index instructions per
+// update dearer (profiles/r02f_k2_phases.txt): measured, not kept.
+__host__ __device__ constexpr int pdist_index(int cell, int type) { return cell * 8 + type; }
 constexpr int kPdistWords = pdist_index(225, 7) + 1;
 constexpr int oLines = 0, oScores = oLines + kLineWords, oDensity = oScores + 4 * kCells, oPdist = oDensity + 4 * kCells,
               oCdist = oPdist + kPdistWords, oRecord = oCdist + 226 * 3, oMeta = oRecord + 57;
-constexpr int kStateWords = (oMeta + 4 + 3) & ~3;                                // 4480 words = 17 920 B
+constexpr int kStateWords = (oMeta + 4 + 3) & ~3;                                // 4448 words = 17 792 B
 // meta: [0] moves played, [1] player to move (+1 black, -1 white, 0 game over), [2] winner, [3] error bits
 constexpr int kResultCap = 16;                                                   // matches covering the centre, per direction
 constexpr int kCompoundCap = 64;                                                 // compound components handled in one pass

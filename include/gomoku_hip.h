@@ -98,7 +98,7 @@ int gmk_eval_batch_host(const uint16_t *h_planes, int n,
 int gmk_eval_launch_info(int n, int *grid, int *block, int *lds_bytes);
 
 /* ---- K2: incrementally maintained evaluator states ----
- * One handle = n_games Evaluator objects (core/lib/include/Pattern.h:142-220) living in HBM, 17 920 B each.  Unlike K1 it keeps
+ * One handle = n_games Evaluator objects (core/lib/include/Pattern.h:142-220) living in HBM, 17 792 B each.  Unlike K1 it keeps
  * everything the reference keeps, including the per-cell 2-bit flag words of m_patternDist / m_compoundDist, which are
  * order-dependent shift registers (Pattern.cpp:395-400) and can only be reproduced by replaying the update rule.
  * gmk_evalstate_update applies moves_per_game entries per game in one launch, entry m of game g at d_moves[g*moves_per_game+m]:
