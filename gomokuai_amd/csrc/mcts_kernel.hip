@@ -291,6 +291,10 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         __syncthreads();
         // one lane per rollout
         {
+            int no_tie_before = 224;                                 // the first ply at which a board of this wavefront can fill up
+            for (int g = 0; g < games_here; ++g)
+                if (s_active[g] && s_need[g]) no_tie_before = min(no_tie_before, 224 - static_cast<int>(s_ply[g]));
+            no_tie_before = __builtin_amdgcn_readfirstlane(no_tie_before);
             const int gs = lane / R;
             if (gs < games_here && gs < G && s_active[gs] && s_need[gs]) {
                 // the leaf's line words into the lane's rollout position, 23 reads in flight at a time (one by one each copy is a
@@ -307,7 +311,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                 const uint32_t ply = s_ply[gs];
                 const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
                 const uint2* my_cells = s_cells + lane;
-                const int winner = random_rollout_blocks(&s_lane_lines[lane], static_cast<uint32_t>(n_rollout_lanes), init_player, static_cast<int>(ply),
+                const int winner = random_rollout_blocks(&s_lane_lines[lane], static_cast<uint32_t>(n_rollout_lanes), init_player, static_cast<int>(ply), no_tie_before,
                                                          [&](uint32_t b) { return my_cells[b * static_cast<uint32_t>(n_rollout_lanes)]; });
                 atomicAdd(&s_sum[gs], init_player * winner);         // CalcScore(init_player, winner)
             }

@@ -216,7 +216,7 @@ void rave_playouts_kernel(RaveParams prm) {
         if (wave == roll_wave && lane < kWaves) {
             const int stones = s_ply[lane];
             if (stones >= 0)
-                s_winner[lane] = random_rollout_blocks(s_mem[lane], 1u, (stones & 1) ? -1 : 1, stones, [&](uint32_t b) { return s_cells[lane][b]; });
+                s_winner[lane] = random_rollout_blocks(s_mem[lane], 1u, (stones & 1) ? -1 : 1, stones, 0, [&](uint32_t b) { return s_cells[lane][b]; });
         }
         __syncthreads();
         if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_roll += t - prof_t0; prof_t0 = t; }

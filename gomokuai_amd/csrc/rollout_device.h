@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "board_device.h"
 #include "philox.h"
@@ -42,7 +43,8 @@ __device__ __forceinline__ lds_u32* lds_at(uint32_t byte_address) { return reint
 
 template <class Fetch>
 __device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], in LDS */, uint32_t stride /* words between a lane's line words */,
-                                            int to_move, int stones, Fetch fetch) {
+                                            int to_move, int stones, int no_tie_before /* wave-uniform: no rollout of the wavefront fills its board before this ply
+                                            (the smallest 224 - stones among them; 0 is always right) */, Fetch fetch) {
     const uint32_t sb = 4u * stride;                               // bytes (< 2^24: the multiply-adds below are 24-bit)
     const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lines));
     uint32_t col0 = base + kColBase * sb, dia0 = base + (kDiagBase + 14) * sb, ant0 = base + kAntiBase * sb;
@@ -60,8 +62,10 @@ __device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], 
     bool live = true;
     uint2 cur = fetch(0u);
     uint32_t rw_ahead = *lds_at(base + __umul24(cur.x & 15u, sb));
-    for (uint32_t b = 0;; ++b) {
-        const uint2 ahead = fetch(b + 1u);                          // in flight during these eight plies
+    // one block of eight plies; Tie: a board may fill up during it (the test costs three instructions a ply, and full boards are rare:
+    // the blocks before `no_tie_before` run without it)
+    auto play_block = [&](auto tie_tag, uint32_t b, const uint2 ahead) -> bool {
+        constexpr bool kTie = decltype(tie_tag)::value;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (live) {
@@ -95,11 +99,16 @@ __device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], 
                 const uint32_t rc4 = rc2 & (rc2 >> 2), da4 = da2 & (da2 >> 2);
                 const uint32_t fives = (rc4 & (rc >> 4)) | (da4 & (da >> 4));
                 if (fives != 0u) won = 2u | static_cast<uint32_t>(j & 1);
-                live = fives == 0u && static_cast<int>(8u * b) + j != last_ply;
+                live = fives == 0u && (!kTie || static_cast<int>(8u * b) + j != last_ply);
             }
-            if ((j & 3) == 3 && __ballot(live) == 0ull)
-                return won ? ((won & 1u) ? -to_move : to_move) : 0;
+            if ((j & 3) == 3 && __ballot(live) == 0ull) return true;
         }
+        return false;
+    };
+    for (uint32_t b = 0;; ++b) {
+        const uint2 ahead = fetch(b + 1u);                          // in flight during these eight plies
+        const bool over = static_cast<int>(8u * b) + 7 < no_tie_before ? play_block(std::false_type{}, b, ahead) : play_block(std::true_type{}, b, ahead);
+        if (over) return won ? ((won & 1u) ? -to_move : to_move) : 0;
         cur = ahead;
     }
 }
