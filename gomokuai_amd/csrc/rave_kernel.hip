@@ -213,10 +213,16 @@ void rave_playouts_kernel(RaveParams prm) {
         if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
         __syncthreads();
         // ---- Default::RandomRollout for the games of the workgroup, one lane each; a finished game stays in its `lines` ----
-        if (wave == roll_wave && lane < kWaves) {
-            const int stones = s_ply[lane];
-            if (stones >= 0)
-                s_winner[lane] = random_rollout_blocks(s_mem[lane], 1u, (stones & 1) ? -1 : 1, stones, 0, [&](uint32_t b) { return s_cells[lane][b]; });
+        if (wave == roll_wave) {
+            int no_tie_before = 224;                            // the first ply at which one of the boards can fill up (wave-uniform)
+            for (int g = 0; g < kWaves; ++g)
+                if (s_ply[g] >= 0) no_tie_before = min(no_tie_before, 224 - s_ply[g]);
+            no_tie_before = __builtin_amdgcn_readfirstlane(no_tie_before);
+            if (lane < kWaves) {
+                const int stones = s_ply[lane];
+                if (stones >= 0)
+                    s_winner[lane] = random_rollout_blocks(s_mem[lane], 1u, (stones & 1) ? -1 : 1, stones, no_tie_before, [&](uint32_t b) { return s_cells[lane][b]; });
+            }
         }
         __syncthreads();
         if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_roll += t - prof_t0; prof_t0 = t; }
