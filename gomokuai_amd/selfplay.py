@@ -86,6 +86,25 @@ SLOTS_PER_GPU = 16384
 HANDLES_FROM_GAMES = 8192
 
 
+def plan_games(n_games, slots="auto", handles="auto", opening_plies=0):
+    """How play_games spreads n_games over search handles and slots: a list of (first game, one past the last game, slots) per handle,
+    or None for the plain lock-step loop (one handle, every game in flight from the start).  Pure bookkeeping, no GPU."""
+    if n_games <= 0:
+        raise ValueError("play_games: n_games must be positive")
+    if handles == "auto":
+        handles = 2 if n_games >= HANDLES_FROM_GAMES and opening_plies <= 8 else 1
+    if slots == "auto":
+        slots = SLOTS_PER_GPU if n_games > SLOTS_PER_GPU and opening_plies <= 8 else None
+    handles = max(1, min(int(handles), n_games))
+    if not ((slots is not None and slots < n_games) or handles > 1):
+        return None
+    if opening_plies > 8:
+        raise ValueError("play_games: slots and handles take openings of at most 8 plies")
+    total_slots = n_games if slots is None else max(handles, min(int(slots), n_games))
+    blocks = [((n_games * i) // handles, (n_games * (i + 1)) // handles) for i in range(handles)]
+    return [(lo, hi, min(hi - lo, -(-total_slots // handles))) for lo, hi in blocks]
+
+
 def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5.0, c_rollouts=5,
                opening_plies=0, record_visits=True, reuse_subtree=False, root_noise=None, max_moves=N, device=None,
                node_capacity=None, slots="auto", handles="auto"):
@@ -100,14 +119,9 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
-    if handles == "auto":
-        handles = 2 if n_games >= HANDLES_FROM_GAMES and opening_plies <= 8 else 1
-    if slots == "auto":
-        slots = SLOTS_PER_GPU if n_games > SLOTS_PER_GPU and opening_plies <= 8 else None
-    handles = max(1, min(int(handles), n_games))
-    if (slots is not None and slots < n_games) or handles > 1:
-        if opening_plies > 8:
-            raise ValueError("play_games: slots and handles take openings of at most 8 plies")
+    plan = plan_games(n_games, slots, handles, opening_plies)
+    if plan is not None:
+        handles = len(plan)
         open_moves = open_lens = None
         if opening_plies > 0:
             m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
@@ -118,9 +132,8 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
         d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
         d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev) if record_visits else None
         noise = root_noise if reuse_subtree else None
-        total_slots = n_games if slots is None else max(handles, min(int(slots), n_games))
-        blocks = [((n_games * i) // handles, (n_games * (i + 1)) // handles) for i in range(handles)]
-        trees = [G.BatchedMCTS(min(hi - lo, -(-total_slots // handles)), c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap) for lo, hi in blocks]
+        blocks = [(lo, hi) for lo, hi, _ in plan]
+        trees = [G.BatchedMCTS(n_slots, c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap) for _, _, n_slots in plan]
 
         def run_block(i, hip_stream):
             lo, hi = blocks[i]

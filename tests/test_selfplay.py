@@ -185,3 +185,24 @@ def test_host_games_match_the_board():
         b.apply_move(core.Position(c))
         assert bool(tie.over[0]) == bool(b.status["is_end"])
     assert int(tie.winner[0]) == int(b.status["winner"])
+
+
+def test_plan_games_spreads_games_over_handles_and_slots():
+    """selfplay.plan_games: the bookkeeping behind play_games(slots=, handles=) -- contiguous blocks that cover every game once, the
+    slots shared out between the handles, the lock-step loop when neither is asked for."""
+    assert selfplay.plan_games(4096) is None                                    # one handle, all games at once
+    assert selfplay.plan_games(23, slots=64) is None                            # more slots than games
+    assert selfplay.plan_games(32768) == [(0, 16384, 8192), (16384, 32768, 8192)]
+    assert selfplay.plan_games(8192) == [(0, 4096, 4096), (4096, 8192, 4096)]   # two handles, every game in flight
+    assert selfplay.plan_games(23, slots=5) == [(0, 23, 5)]
+    for n, slots, handles in [(23, 6, 3), (23, None, 2), (7, 100, 7), (5, 1, 9), (40000, "auto", "auto"), (16385, "auto", 1)]:
+        plan = selfplay.plan_games(n, slots, handles)
+        assert plan[0][0] == 0 and plan[-1][1] == n and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+        assert all(1 <= s <= hi - lo for lo, hi, s in plan)
+        if isinstance(slots, int):
+            assert sum(s for _, _, s in plan) <= max(len(plan), min(slots, n)) + len(plan) - 1
+    assert selfplay.plan_games(20000, opening_plies=12) is None                 # long openings: the lock-step loop
+    with pytest.raises(ValueError):
+        selfplay.plan_games(20000, slots=100, opening_plies=12)
+    with pytest.raises(ValueError):
+        selfplay.plan_games(0)
