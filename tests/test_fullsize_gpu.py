@@ -169,3 +169,80 @@ def test_k1_8192_dense_boards(oracle):
     ref = oracle.replay_batch(moves, lens)
     assert not (got[3] & 2).any() and not (ref[3] & 2).any()
     assert _mismatching_boards(ref, got) == {"scores": 0, "density": 0, "totals": 0, "status": 0}
+
+
+# ---- extended sweeps (GMK_EXTENDED=1): more of the same differential runs on other boards, games and seeds; not part of the default
+#      suite (minutes of oracle time), run by hand on the GPU box after a kernel change ----
+import os
+
+extended = pytest.mark.skipif(not os.environ.get("GMK_EXTENDED"), reason="extended sweep: set GMK_EXTENDED=1")
+
+
+@extended
+@pytest.mark.parametrize("kind,first", [(0, 65536), (1, 65536), (0, 1 << 20), (1, 1 << 20), (0, 7777777), (1, 7777777)])
+def test_extended_k1_other_boards(oracle, kind, first):
+    n = 65536
+    moves, lens, planes = G.synth_boards(n, kind, first_board=first)
+    assert _mismatching_boards(oracle.replay_batch(moves, lens), G.eval_batch_host(planes)) == {"scores": 0, "density": 0, "totals": 0, "status": 0}
+
+
+@extended
+@pytest.mark.parametrize("seed,first,plies,playouts", [(1, 100000, 0, 800), (2, 5000000, 9, 500), (0xDEADBEEF, 31, 30, 300), (77, 1 << 30, 60, 200)])
+def test_extended_k3_other_games_and_seeds(oracle, seed, first, plies, playouts):
+    n = 128
+    moves, lens, _ = G.synth_boards(n, 0, first_board=first)
+    lens = np.minimum(lens, plies).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[i, lens[i] - 1] if lens[i] > 0 else -1 for i in range(n)], dtype=np.int16)
+    tree = G.BatchedMCTS(n, playouts_capacity=playouts, seed=seed)
+    tree.set_roots(planes, last, first_game_id=first)
+    tree.run(playouts)
+    visits, q, rv, nodes, status = tree.root_stats()
+    for g in range(0, n, 4):
+        b = oracle.new_board()
+        for i in range(int(lens[g])):
+            oracle.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        om = oracle.MCTS(playouts, 5.0, 5, seed, first + g)
+        om.run_playouts(b)
+        ov, _, _ = om.root_children()
+        assert (ov == visits[g]).all(), "game %d" % g
+        assert np.float32(q[g]).tobytes() == np.float32(om.root_value).tobytes() and nodes[g] == om.size
+    tree.close()
+
+
+@extended
+@pytest.mark.parametrize("first,kind,playouts", [(9000, 1, 2500), (123456, 0, 2500), (424242, 1, 4000)])
+def test_extended_k6_other_positions(oracle, first, kind, playouts):
+    n = 28
+    moves, lens, _ = G.synth_boards(n, kind, first_board=first)
+    pos = [[int(m) for m in moves[g, :min(int(lens[g]), 2 + g)]] for g in range(n)]
+    t = G.TraditionalMCTS(n, node_capacity=1 << 20)
+    t.set_positions(pos)
+    t.run(playouts)
+    st = t.root_stats()
+    for g in range(n):
+        o = oracle.TraditionalMCTS(5.0)
+        o.search(pos[g], playouts)
+        v, qq, p, best = o.root_children()
+        assert (v == st["visits"][g]).all() and (qq.view(np.uint32) == st["values"][g].view(np.uint32)).all(), "game %d" % g
+        assert best == st["best"][g] and o.n_nodes == st["n_nodes"][g] and o.evaluator_updates == st["evaluator_updates"][g], "game %d" % g
+    t.close()
+
+
+@extended
+@pytest.mark.parametrize("first,gid", [(1000, 0), (888888, 70000)])
+def test_extended_k8_other_games(oracle, first, gid):
+    n, P = 64, 2000
+    moves, lens, _ = G.synth_boards(n, 0, first_board=first)
+    pos = [[int(m) for m in moves[g, :min(int(lens[g]), (g * 7) % 40)]] for g in range(n)]
+    t = G.PoolRAVEMCTS(n, node_capacity=(P + 200) * 225, c_puct=2.0, first_game_id=gid)
+    t.set_positions(pos)
+    t.run(P)
+    st = t.root_stats()
+    for g in range(n):
+        o = oracle.PoolRAVEMCTS(2.0, 0.0, seed=G.DEFAULT_SEED, game_id=gid + g)
+        o.run(pos[g], P)
+        v, qq, p, av, aq, best = o.root_children()
+        assert (v == st["visits"][g]).all() and (qq.view(np.uint32) == st["values"][g].view(np.uint32)).all() and best == st["best"][g], "game %d" % g
+        assert (av == st["amaf_visits"][g]).all() and (aq.view(np.uint32) == st["amaf_values"][g].view(np.uint32)).all(), "game %d" % g
+    t.close()
