@@ -637,13 +637,15 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
     }
     gmk_mcts* m = new gmk_mcts;
     m->n_games = n_games; m->node_capacity = node_capacity; m->c_puct = c_puct; m->c_rollouts = c_rollouts; m->seed = seed;
-    // Games per wavefront.  A game is a sequential chain (select -> rollouts -> backup), so wall time is set by
-    // the chain's latency, not by lane utilisation: fewer games per wave = fewer sequential tree rounds and a
-    // shorter longest-rollout tail, as long as the chip has wave slots to spare (1024 SIMDs on MI355X).
+    // Games per wavefront.  A game is a sequential chain (select -> rollouts -> backup), so wall time is set by the chain's latency,
+    // not by lane utilisation: fewer games per wave = fewer sequential tree rounds and a shorter longest-rollout tail, as long as
+    // the chip has wave slots to spare (1024 SIMDs on MI355X, two of these wavefronts each): aim at two waves per SIMD, and never
+    // more than four games per wavefront (one quarter-wave round of the tree phases) -- a batch beyond 8 192 games then runs in
+    // several rounds of workgroups, which is faster than longer wavefronts (M playouts/s at 800 playouts, games per wavefront 4 / 6 /
+    // 8 / 12: 16 384 games 156 / 123 / 119 / 95, 32 768 games 159 / 132 / 117 / 99; 6 144 games: 3 -> 126, 4 -> 117).
     const int max_gpb = std::min(kMaxGamesPerBlock, 64 / c_rollouts);
     const int simds = std::max(1, st.cu_count * 4);
-    int gpb = (n_games + 2 * simds - 1) / (2 * simds);            // aim at ~2 waves per SIMD
-    gpb = ((gpb + 3) / 4) * 4;                                    // whole quarter-wave rounds
+    int gpb = std::min(4, (n_games + 2 * simds - 1) / (2 * simds));
     if (const char* env = std::getenv("GMK_MCTS_GAMES_PER_BLOCK")) gpb = std::atoi(env);
     m->games_per_block = std::max(1, std::min(max_gpb, gpb));
     const size_t nodes = static_cast<size_t>(n_games) * static_cast<size_t>(node_capacity);
