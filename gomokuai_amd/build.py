@@ -7,6 +7,10 @@ import sysconfig
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgomoku_hip.so")
+# The profiling flavour (-DGMK_PROFILE): the same sources with the phase masks / in-kernel timers / launch-shape overrides that
+# tools/*.sh drive through the environment compiled IN; the production library has none of them.  Loaded only when asked for
+# (GMK_HIP_LIB=prof, see lib.py); never by the tests, bench.py or __graft_entry__.
+PROF_LIB = os.path.join(HERE, "libgomoku_hip_prof.so")
 
 LIB_SOURCES = ["capi.hip", "eval_kernel.hip", "evalstate_kernel.hip", "trad_kernel.hip", "rave_kernel.hip", "az_kernel.hip", "pvnet_kernel.hip", "mcts_kernel.hip", "records_kernel.hip", "pattern_tables.cpp", "synth.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -24,24 +28,27 @@ def _stale(target, sources):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False):
+def build_lib(force=False, verbose=False, profile=False):
+    lib = PROF_LIB if profile else LIB
+    objdir = os.path.join(CSRC, "prof") if profile else CSRC
+    os.makedirs(objdir, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if not (force or _stale(LIB, srcs)):
-        return LIB
+    if not (force or _stale(lib, srcs)):
+        return lib
     objs = []
     for s in srcs:
-        o = os.path.join(CSRC, os.path.splitext(os.path.basename(s))[0] + ".o")
+        o = os.path.join(objdir, os.path.splitext(os.path.basename(s))[0] + ".o")
         if force or _stale(o, [s]):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + (["-DGMK_PROFILE"] if profile else []) + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 def build_pyext(force=False, verbose=False):
@@ -69,4 +76,7 @@ def build_all(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    if "--profile" in sys.argv:
+        print(build_lib(force="--force" in sys.argv, verbose=True, profile=True))
+    else:
+        print(build_all(force="--force" in sys.argv, verbose=True))

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/gomoku_hip.h"
 #include "pattern_tables.h"
@@ -22,6 +23,17 @@ struct DeviceState {
     int n_states = 0, n_patterns = 0, emit_words = 0, n_records = 0;
 };
 DeviceState& device_state();
+
+// Profiling switches (phase masks, in-kernel timers, launch-shape overrides) exist in the -DGMK_PROFILE build only:
+// `python -m gomokuai_amd.build --profile` makes libgomoku_hip_prof.so, which tools/*.sh load with GMK_HIP_LIB=prof.
+// The production library never reads the environment, so a stray variable cannot change a result.
+#ifdef GMK_PROFILE
+inline const char* profile_env(const char* name) { return std::getenv(name); }
+constexpr bool kProfileBuild = true;
+#else
+inline const char* profile_env(const char*) { return nullptr; }
+constexpr bool kProfileBuild = false;
+#endif
 
 #define GMK_HIP_CHECK(expr)                                                                   \
     do {                                                                                      \

@@ -58,7 +58,8 @@ constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
 static_assert(kZeroWords % 4 == 0 && kBoardWords % 4 == 0, "16-byte alignment of the per-board blocks");
 constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560;   // lane jobs, initial line words, the bits-to-bytes table and the weight table of phase D
 
-// Lane -> line jobs.  A job word: bits 0..3 len, 4..7 x0, 8..11 y0, 12..13 dir, bit 14 valid, 16..22 line word index.
+// Lane -> line jobs.  A job word holds what the scan and the deposits need of a line, ready to use: bits 0..4 symbols in its stream
+// segment (len + 3: one leading and two trailing pads), 5..6 dir, 7..11 cell stride, 12..19 its first cell, 20..26 line word index.
 __constant__ uint32_t c_lane_jobs[64 * 2];
 __constant__ uint32_t c_line_init[kLineWords];   // all cells blank: (1 << 2 len) - 1
 constexpr int kScanSteps = 19;                    // symbols in the longest lane stream (upload_lane_jobs checks it)
@@ -80,6 +81,10 @@ __device__ __forceinline__ const __attribute__((address_space(3))) uint32_t* lds
     return reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(byte_address));
 }
 
+__device__ __forceinline__ __attribute__((address_space(3))) uint32_t* lds_word_rw(uint32_t byte_address) {
+    return reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(byte_address));
+}
+
 __device__ __forceinline__ void wave_phase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -97,9 +102,10 @@ __device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell
     const uint32_t score = dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu);                  // int(1.2 * score) on diagonals (Pattern.cpp:151-152)
     uint32_t* own = s_scores + (fav ? 3 : 0) * kCells;                              // Group(favour, favour) (Pattern.h:159-161)
     uint32_t* opp = s_scores + (fav ? 2 : 1) * kCells;                              // Group(favour, -favour)
-    const int tslot = type == 5 ? 0 : type == 4 ? 1 : type == 3 ? 2 : -1;           // LiveThree, DeadThree, LiveTwo feed compounds
-    uint32_t* cnt = s_cnt + (tslot < 0 ? 0 : tslot) * kCells;
-    const uint32_t one = tslot < 0 ? 0u : 1u << (4 * (fav * 4 + dir));
+    const uint32_t tslot = 5u - static_cast<uint32_t>(type);                         // LiveThree 0, DeadThree 1, LiveTwo 2 feed compounds (no branches: one compare)
+    const bool feeds = tslot < 3u;
+    uint32_t* cnt = s_cnt + (feeds ? tslot : 0u) * kCells;
+    const uint32_t one = feeds ? 1u << (4 * (fav * 4 + dir)) : 0u;
     const int n_dep = (w0 >> 8) & 7;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -201,6 +207,45 @@ __device__ __forceinline__ void density_tile_pass(const uint32_t (&own_rows)[8],
     }
     // accumulator i = board-colour column 8 (i / 4) + 4 h + (i % 4) at cell 32 M + n; columns 2 b, 2 b + 1 are board b
     const int n_live = n_boards - first_board;      // >= 16 except in the last group
+#ifdef GMK_K1_D16
+    // Sixteen bytes per lane: the four accumulators of a register quad are four planes (two boards x two colours) at ONE cell; the four
+    // lanes of a lane quad hold four consecutive cells.  A 4 x 4 transpose inside the lane quad (two rounds of DPP exchanges, with the
+    // lane one and two away) leaves lane t of a quad with plane t at the quad's four cells: one 16-byte store per register quad,
+    // eight pieces of 128 contiguous bytes per instruction, 57 store instructions per group instead of 225.
+    const int t = n & 3;
+    const bool t0 = (t & 1) != 0, t1 = (t & 2) != 0;
+    auto swap_with = [](int v, bool by_two) -> int {
+        return by_two ? __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true)       // quad_perm [2, 3, 0, 1]
+                      : __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int a[4];
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const int b = 4 * q + j / 2;            // + 2 h
+            const uint32_t wd = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(8 * b + 16 * h, static_cast<int>(occ)));
+            const int neg = __builtin_amdgcn_sbfe(static_cast<int>(wd), n, 1);      // occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
+            a[j] = acc[4 * q + j] ^ neg;
+            a[j + 1] = acc[4 * q + j + 1] ^ neg;
+        }
+        {   // exchange with the lane one away: (a0, a1) and (a2, a3) become 2 x 2 transposed
+            const int r01 = swap_with(t0 ? a[0] : a[1], false), r23 = swap_with(t0 ? a[2] : a[3], false);
+            if (t0) { a[0] = r01; a[2] = r23; } else { a[1] = r01; a[3] = r23; }
+        }
+        {   // ... and with the lane two away: (a0, a2) and (a1, a3)
+            const int r02 = swap_with(t1 ? a[0] : a[2], true), r13 = swap_with(t1 ? a[1] : a[3], true);
+            if (t1) { a[0] = r02; a[1] = r13; } else { a[2] = r02; a[3] = r13; }
+        }
+        // lane t now holds plane t of the register quad (board 4 q + 2 h + t / 2; t even: black, the second colour block) at cells 32 M + 4 (n / 4) ..
+        const int board_in_group = 4 * q + 2 * h + (t >> 1);
+        if (board_in_group < n_live && plane_stride > 0) {
+            int32_t* dst = out_density + static_cast<size_t>(first_board + board_in_group) * 4 * plane_stride + ((t & 1) ? 0 : 2 * plane_stride)
+                           + KIND * plane_stride + 32 * M + (n & ~3);
+            *reinterpret_cast<Int4Unaligned*>(dst) = Int4Unaligned{a[0], a[1], a[2], a[3]};
+        }
+    }
+#else
     int32_t* out = out_density + static_cast<size_t>(first_board) * 4 * plane_stride + KIND * plane_stride + 32 * M + n + h * (2 * 4 * plane_stride);
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
@@ -212,6 +257,7 @@ __device__ __forceinline__ void density_tile_pass(const uint32_t (&own_rows)[8],
             out[b * 4 * plane_stride + 0 * 2 * plane_stride] = acc[i + 1] ^ neg;             // column 2 b + 1: white, the first
         }
     }
+#endif
 }
 
 // All fourteen passes of a group, back to back: the group's density planes are one contiguous block of 16 x 3 600 bytes, and written
@@ -264,7 +310,20 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                            uint32_t* __restrict__ out_totals, int32_t* __restrict__ out_status,
                            const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records,
                            int trans_words, int record_words, const uint32_t* __restrict__ g_wtab,
-                           int phase_mask /* profiling aid: bit p runs phase p, bit 6 phase D (bit 8: its planes 1 KB apart, bit 9: passes without stores, bit 10: no passes; bit 11: no compounds = phases 3b and 4 skipped; bit 12: consecutive groups to different workgroups); 0x7F in production */) {
+                           int phase_mask_arg, unsigned long long* __restrict__ prof) {
+    // Profiling aids, -DGMK_PROFILE build only (the production build runs every phase and reads no clock): phase_mask bit p runs
+    // phase p, bit 6 phase D (bit 8: its planes 1 KB apart, bit 9: passes without stores, bit 10: no passes; bit 11: no compounds =
+    // phases 3b and 4 skipped; bit 12: consecutive groups to different workgroups), any mask but 0x7F sets the error bit of every
+    // board's status word; prof != nullptr: s_memtime cycles per phase, summed over the wavefronts.
+#ifdef GMK_PROFILE
+    const int phase_mask = phase_mask_arg;
+    unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#define GMK_STAMP(k) do { if (prof) { const unsigned long long t_now_ = __builtin_amdgcn_s_memtime(); t_acc[k] += t_now_ - t_prev; t_prev = t_now_; } } while (0)
+#else
+    constexpr int phase_mask = 0x7F;
+    (void)phase_mask_arg; (void)prof;
+#define GMK_STAMP(k) do { } while (0)
+#endif
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     // layout: [trans (LDS address 0)][records (16-byte aligned)][lane jobs 128][initial line words 96][boards: kBoardsPerBlock * kBoardWords]
     const uint4* s_rec = reinterpret_cast<const uint4*>(lds + trans_words);
@@ -289,6 +348,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     uint32_t* s_misc = s_queue + kQueueCap;
 
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
+    GMK_STAMP(0);
 
     // ---- work distribution ----
     // A wavefront takes groups of sixteen consecutive boards, evaluates them one after the other and, in the board iteration that is
@@ -336,6 +396,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         // outstanding operation is a board's work old.
         cur_black = next_black; cur_white = next_white;
         if (bi + 1 < kGroupBoards) fetch_row(board + 1);
+        GMK_STAMP(11);
 
         if (live) {
             // ---- phase 0: clear accumulators, take the two bit-planes (64 B), turn them into line words ----
@@ -397,6 +458,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 if (row_sym) atomicXor(&s_lines[y], row_sym);
             }
             wave_phase_fence();
+            GMK_STAMP(1);
 
             // ---- phase 1: walk the DFA along this lane's lines; transitions that emit go to the queue ----
             // The lane's one or two lines become ONE stream of 2-bit DFA symbols:
@@ -407,27 +469,31 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             // (record, lane, step); the slot is a ballot prefix (this wave is the only producer), decoding happens in phase 2.
             int n_queued = 0;                                       // wave-uniform
             if (phase_mask & 2) {
-                const int len_a = job_a & 15, len_b = job_b & 15;
-                uint64_t syms = line_symbols(s_lines[(job_a >> 16) & 127u], len_a);
-                syms |= line_symbols(s_lines[(job_b >> 16) & 127u], len_b) << (2 * len_a + 6);
+                const int len_a = static_cast<int>(job_a & 31u) - 3, len_b = static_cast<int>(job_b & 31u) - 3;
+                uint64_t syms = line_symbols(s_lines[(job_a >> 20) & 127u], len_a);
+                syms |= line_symbols(s_lines[(job_b >> 20) & 127u], len_b) << (2 * len_a + 6);
                 syms |= 0xAAAAAAAAAAAAAAAAull << (2 * (len_a + len_b) + 12);
                 uint32_t cur = static_cast<uint32_t>(syms) << 2;    // symbols 0..14 at bits 2..31
                 const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2..
                 uint32_t tw = 0;                                    // the previous step's table word (row 0 = root)
                 // The emission of step s is queued BEHIND the lookup of step s + 1 (the next address needs the table word only): the
-                // prefix count and the queue write then run in the shadow of that lookup's LDS round trip.
+                // prefix count and the queue write then run in the shadow of that lookup's LDS round trip.  A queue entry is the table
+                // word itself with the low 17 bits (next row, kinds) replaced by lane | step << 6: the record number stays where it is.
+                // Where the queue stands is a byte address kept by the scalar unit; a lane adds its prefix count (the vector unit is
+                // what this kernel is bound by: 4 cycles per wave-instruction on a SIMD whatever the lanes do).
+                const uint32_t q_base = static_cast<uint32_t>(s_queue - lds) * 4u;     // (the kernel's LDS starts at address 0)
+                const uint32_t q_last = q_base + 4u * (kQueueCap - 1);
+                uint32_t q_at = q_base;                             // wave-uniform
                 auto push = [&](uint32_t word, int step) {
-                    const uint32_t rec = gmk::dev_trans_record(word);
-                    const unsigned long long emitters = __ballot(rec != 0u);
+                    const bool emits = word > 0x1FFFFu;
+                    const unsigned long long emitters = __ballot(emits);
                     if (emitters) {
-                        if (rec) {
-                            // (the running count goes in as the prefix count's start value: no separate add)
-                            const int slot = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32),
-                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), static_cast<uint32_t>(n_queued))));
+                        if (emits) {
+                            const uint32_t ahead = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u));
                             // (beyond the capacity every entry lands on the last slot: the board is flagged below)
-                            s_queue[min(slot, kQueueCap - 1)] = rec | (lane_tag + (static_cast<uint32_t>(step) << 16));
+                            *lds_word_rw(min(q_at + 4u * ahead, q_last)) = (word & ~0x1FFFFu) | (static_cast<uint32_t>(lane) | static_cast<uint32_t>(step) << 6);
                         }
-                        n_queued += __popcll(emitters);
+                        q_at += 4u * static_cast<uint32_t>(__popcll(emitters));
                     }
                 };
 #pragma unroll
@@ -440,31 +506,35 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     if (step > 0) push(before, step - 1);
                 }
                 push(tw, kScanSteps - 1);
+                n_queued = static_cast<int>((q_at - q_base) >> 2);
                 if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
             }
             wave_phase_fence();
+            GMK_STAMP(2);
 
             // ---- phase 2: one lane per emitting transition: the score deposits of its 1-2 matches ----
             if (phase_mask & 4) {
-                uint32_t qe_next = s_queue[min(lane, kQueueCap - 1)];
+                uint32_t qe_next = s_queue[min(lane, kQueueCap - 1)];      // (entry: record number << 17 | step << 6 | lane)
                 for (int m = lane; m < n_queued; m += 64) {
                     const uint32_t qe = qe_next;
                     qe_next = s_queue[min(m + 64, kQueueCap - 1)];      // (the next round's entry is on its way while this one is worked on;
                                                                          //  fetching its record and line jobs ahead as well measured no gain)
-                    // which line of which lane, and where on it (symbol 0 of a line is its leading pad)
-                    const int src_lane = (qe >> 10) & 63, src_step = static_cast<int>(qe >> 16);
-                    const uint4 rec_now = s_rec[qe & 1023u];
+                    // which line of which lane, and where on it (symbol 0 of a line's segment is its leading pad)
+                    const int src_lane = qe & 63, src_step = (qe >> 6) & 31;
+                    const uint4 rec_now = s_rec[qe >> 17];
                     const uint32_t ja_now = s_jobs[src_lane * 2], jb_now = s_jobs[src_lane * 2 + 1];
-                    const int first_len = static_cast<int>(ja_now & 15u) + 3;
-                    const uint32_t job = src_step < first_len ? ja_now : jb_now;
-                    const int pos = (src_step < first_len ? src_step : src_step - first_len) - 1;
-                    const int dir = (job >> 12) & 3, stride = dir_stride(dir);
-                    const int cell_at = static_cast<int>(((job >> 8) & 15u) * 15u + ((job >> 4) & 15u)) + pos * stride;
+                    const int seg_a = ja_now & 31u;
+                    const bool second = src_step >= seg_a;
+                    const uint32_t job = second ? jb_now : ja_now;
+                    const int pos = src_step - 1 - (second ? seg_a : 0);
+                    const int dir = (job >> 5) & 3, stride = (job >> 7) & 31;
+                    const int cell_at = static_cast<int>((job >> 12) & 255u) + pos * stride;
                     deposit_match(rec_now.x, rec_now.y, cell_at, dir, stride, s_scores, s_cnt, s_misc);
                     if (rec_now.z) deposit_match(rec_now.z, rec_now.w, cell_at, dir, stride, s_scores, s_cnt, s_misc);
                 }
             }
             wave_phase_fence();
+            GMK_STAMP(3);
 
             // ---- phase 3: one lane per cell: area bonus, compound candidates ----
             int n_cand = 0;                                         // wave-uniform
@@ -509,6 +579,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 }
             }
             wave_phase_fence();
+            GMK_STAMP(4);
 
             // ---- phase 3b: one lane per candidate cell and colour: compound state machine (Pattern.cpp:440-486), critical-point deposits,
             //      counter-move rescans queued in the upper half of the queue ----
@@ -569,6 +640,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 }
             }
             wave_phase_fence();
+            GMK_STAMP(5);
 
             // ---- phase 4: the counter-move cells of every compound component: the FIRST match of its type that runs through
             //      the cell with a blank there (Compound::updateAntis, Pattern.cpp:520-543), scanning the 13-symbol window
@@ -613,16 +685,19 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 }
             }
             wave_phase_fence();
+            GMK_STAMP(6);
 
         }
 
         asm volatile("" : "+v"(next_black), "+v"(next_white));    // the wait for the next board's planes (a use the compiler must honour)
+        GMK_STAMP(7);
 
         // ---- phase D: the group's density planes leave, in the board iteration that is this wavefront's turn ----
         if (planes_out && bi == wave) {
             int lane_p = lane0, first_p = first_board;         // opaque copies: what the passes derive from them is computed here, not kept
             asm volatile("" : "+v"(lane_p), "+s"(first_p));     // in registers from the top of the group
             density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
+            GMK_STAMP(8);
         }
         if (!live) {
             if (!planes_out || bi >= wave) break;
@@ -640,10 +715,17 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 const int4 v0 = src[lane_b], v1 = src[lane_b + 64], v2 = src[lane_b + 128], v3 = src[min(lane_b + 192, kScoreWords / 4 - 1)];
                 typedef int v4i __attribute__((ext_vector_type(4)));
                 v4i* dnt = reinterpret_cast<v4i*>(dst);
+#ifdef GMK_K1_PLAIN_SCORES
+                dnt[lane_b] = v4i{v0.x, v0.y, v0.z, v0.w};
+                dnt[lane_b + 64] = v4i{v1.x, v1.y, v1.z, v1.w};
+                dnt[lane_b + 128] = v4i{v2.x, v2.y, v2.z, v2.w};
+                if (lane_b + 192 < kScoreWords / 4) dnt[lane_b + 192] = v4i{v3.x, v3.y, v3.z, v3.w};
+#else
                 __builtin_nontemporal_store(v4i{v0.x, v0.y, v0.z, v0.w}, &dnt[lane_b]);
                 __builtin_nontemporal_store(v4i{v1.x, v1.y, v1.z, v1.w}, &dnt[lane_b + 64]);
                 __builtin_nontemporal_store(v4i{v2.x, v2.y, v2.z, v2.w}, &dnt[lane_b + 128]);
                 if (lane_b + 192 < kScoreWords / 4) __builtin_nontemporal_store(v4i{v3.x, v3.y, v3.z, v3.w}, &dnt[lane_b + 192]);
+#endif
             }
             if (out_totals && lane_b < 11) out_totals[static_cast<size_t>(board) * 11 + lane_b] = s_misc[4 + lane_b];
             if (out_status && lane_b == 0) {
@@ -653,13 +735,23 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 const int winner = (wbits & 1u) ? 1 : (wbits & 2u) ? -1 : 0;
                 const bool over = winner != 0 || stones_b + stones_w == kCells;
                 const int to_move = over ? 0 : (stones_b == stones_w ? 1 : -1);
-                out_status[board] = (over ? 1 : 0) | (s_misc[2] ? 2 : 0) | ((winner & 0xFF) << 8) | ((to_move & 0xFF) << 16);
+                out_status[board] = (over ? 1 : 0) | ((s_misc[2] || phase_mask != 0x7F) ? 2 : 0) | ((winner & 0xFF) << 8) | ((to_move & 0xFF) << 16);
             }
         }
         wave_phase_fence();
+        GMK_STAMP(9);
 
     }
     }
+#ifdef GMK_PROFILE
+    // [0] table staging, [1] phase 0, [2] scan, [3] deposits, [4] phase 3, [5] phase 3b, [6] rescans, [7] wait for the next planes,
+    // [8] phase D, [9] phase 5, [11] loop head; [15] wavefronts
+    if (prof && lane0 == 0) {
+        for (int k = 0; k < 12; ++k) atomicAdd(&prof[k], t_acc[k]);
+        atomicAdd(&prof[15], 1ull);
+    }
+#endif
+#undef GMK_STAMP
 }
 
 // ---- host side ----
@@ -673,10 +765,11 @@ int upload_lane_jobs() {
     for (int k = 4; k <= 24; ++k) { const int x0 = std::min(k, 14); lines.push_back({std::min(k, 28 - k) + 1, x0, k - x0, 3}); }
     std::stable_sort(lines.begin(), lines.end(), [](const LineJob& a, const LineJob& b) { return a.len > b.len; });
     uint32_t jobs[128];
-    for (uint32_t& j : jobs) j = 15u << 16;                       // "no line": length 0 on a line word that stays zero
+    for (uint32_t& j : jobs) j = 3u | (15u << 20);                // "no line": length 0 (three pads) on a line word that stays zero
     auto pack = [](const LineJob& l) {
         const int line = l.dir == 0 ? l.y0 : l.dir == 1 ? kColBase + l.x0 : l.dir == 2 ? kDiagBase + l.x0 - l.y0 + 14 : kAntiBase + l.x0 + l.y0;
-        return static_cast<uint32_t>(l.len | (l.x0 << 4) | (l.y0 << 8) | (l.dir << 12) | 0x4000 | (line << 16));
+        const int stride = l.dir == 0 ? 1 : l.dir == 1 ? 15 : l.dir == 2 ? 16 : 14;
+        return static_cast<uint32_t>((l.len + 3) | (l.dir << 5) | (stride << 7) | ((l.y0 * 15 + l.x0) << 12) | (line << 20));
     };
     int steps = 0;
     for (int lane = 0; lane < 64; ++lane) {
@@ -756,11 +849,30 @@ extern "C" int gmk_eval_batch(const uint16_t* d_planes, int n, int32_t* d_scores
     }
     const Launch l = plan_launch(n, st);
     if (l.lds > 160u * 1024u) { gmk::set_error("gmk_eval_batch: tables do not fit in LDS (%zu bytes)", l.lds); return GMK_ERR_CAPACITY; }
-    static const int phase_mask = std::getenv("GMK_EVAL_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVAL_PHASE_MASK")) : 0x7F;
+    static const int phase_mask = gmk::profile_env("GMK_EVAL_PHASE_MASK") ? std::atoi(gmk::profile_env("GMK_EVAL_PHASE_MASK")) : 0x7F;
+    unsigned long long* d_prof = nullptr;
+    static const bool stamps = gmk::profile_env("GMK_EVAL_PROFILE") != nullptr;
+    if (stamps) {
+        GMK_HIP_CHECK(hipMalloc(&d_prof, 16 * sizeof(unsigned long long)));
+        GMK_HIP_CHECK(hipMemset(d_prof, 0, 16 * sizeof(unsigned long long)));
+    }
     hipLaunchKernelGGL(eval_positions_kernel, dim3(l.grid), dim3(kThreads), l.lds, static_cast<hipStream_t>(stream),
                        d_planes, n, l.n_groups, d_scores, d_density, d_totals, d_status,
-                       st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, g_wtab, phase_mask);
+                       st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, g_wtab, phase_mask, d_prof);
     GMK_HIP_CHECK(hipGetLastError());
+    if (stamps) {                                               // (profile build only) cycles per phase and board, mean over the wavefronts
+        unsigned long long h[16];
+        GMK_HIP_CHECK(hipDeviceSynchronize());
+        GMK_HIP_CHECK(hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
+        (void)hipFree(d_prof);
+        const char* names[12] = {"staging", "phase0", "scan", "deposits", "phase3", "phase3b", "rescans", "wait-planes", "phaseD", "phase5", "-", "loop-head"};
+        const double boards = static_cast<double>(n), waves = static_cast<double>(h[15] ? h[15] : 1);
+        double total = 0;
+        for (int k = 0; k < 12; ++k) total += static_cast<double>(h[k]);
+        std::fprintf(stderr, "[GMK_EVAL_PROFILE] s_memtime cycles per board (wavefront time; %.0f wavefronts, %.0f cycles each):", waves, total / waves);
+        for (int k = 0; k < 12; ++k) if (k != 10) std::fprintf(stderr, " %s %.0f", names[k], static_cast<double>(h[k]) / boards);
+        std::fprintf(stderr, "\n");
+    }
     return GMK_OK;
 }
 

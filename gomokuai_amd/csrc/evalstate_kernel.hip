@@ -114,8 +114,8 @@ extern "C" int gmk_evalstate_update(gmk_evalstate* e, const int16_t* d_moves, in
     }
     const int grid = (e->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
     unsigned long long* d_prof = nullptr;
-    static const bool profile = std::getenv("GMK_EVS_PROFILE") != nullptr;
-    static const int phases = std::getenv("GMK_EVS_PHASE_MASK") ? std::atoi(std::getenv("GMK_EVS_PHASE_MASK")) : 0x3F;
+    static const bool profile = gmk::profile_env("GMK_EVS_PROFILE") != nullptr;
+    static const int phases = gmk::profile_env("GMK_EVS_PHASE_MASK") ? std::atoi(gmk::profile_env("GMK_EVS_PHASE_MASK")) : 0x3F;
     if (profile) {
         GMK_HIP_CHECK(hipMalloc(&d_prof, static_cast<size_t>(e->n_games) * 8 * sizeof(unsigned long long)));
         GMK_HIP_CHECK(hipMemset(d_prof, 0, static_cast<size_t>(e->n_games) * 8 * sizeof(unsigned long long)));

@@ -646,7 +646,7 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
     const int max_gpb = std::min(kMaxGamesPerBlock, 64 / c_rollouts);
     const int simds = std::max(1, st.cu_count * 4);
     int gpb = std::min(4, (n_games + 2 * simds - 1) / (2 * simds));
-    if (const char* env = std::getenv("GMK_MCTS_GAMES_PER_BLOCK")) gpb = std::atoi(env);
+    if (const char* env = gmk::profile_env("GMK_MCTS_GAMES_PER_BLOCK")) gpb = std::atoi(env);
     m->games_per_block = std::max(1, std::min(max_gpb, gpb));
     const size_t nodes = static_cast<size_t>(n_games) * static_cast<size_t>(node_capacity);
     if (hipMalloc(&m->d_headers, sizeof(GameHeader) * n_games) != hipSuccess || hipMalloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess ||
@@ -734,7 +734,7 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     prm.c_rollouts = m->c_rollouts; prm.games_per_block = m->games_per_block;
     prm.node_capacity = m->node_capacity; prm.n_games = m->n_games; prm.playouts = playouts;
     const int grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
-    prm.profile = std::getenv("GMK_MCTS_PROFILE") ? 1 : 0;
+    prm.profile = gmk::profile_env("GMK_MCTS_PROFILE") ? 1 : 0;
     prm.value_table = m->d_value;
     m->last_stream = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
@@ -957,7 +957,7 @@ extern "C" int gmk_mcts_alg_bytes(gmk_mcts* m, uint64_t* bytes) {
     GMK_HIP_CHECK(hipMemcpy(hdr.data(), m->d_headers, sizeof(GameHeader) * hdr.size(), hipMemcpyDeviceToHost));
     uint64_t total = 0;
     for (const GameHeader& h : hdr) total += h.alg_bytes;
-    if (std::getenv("GMK_MCTS_PROFILE")) {
+    if (gmk::profile_env("GMK_MCTS_PROFILE")) {
         double p[4] = {0, 0, 0, 0};
         for (const GameHeader& h : hdr) for (int k = 0; k < 4; ++k) p[k] += h.pad[k];
         std::fprintf(stderr, "[gmk profile] mean kilo-cycles per game-slot: select %.0f terminal %.0f rollout %.0f expand+backup %.0f\n",

@@ -338,7 +338,7 @@ extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, f
     prm.w1 = net->d_w1; prm.w2 = net->d_w2; prm.w3 = net->d_w3; prm.wh = net->d_wh;
     prm.b1 = net->d_b; prm.b2 = net->d_b + 32; prm.b3 = net->d_b + 96; prm.bh = net->d_b + 224;
     prm.pflat = d_pflat; prm.vflat = d_vflat;
-    static const bool profile = std::getenv("GMK_PVNET_PROFILE") != nullptr;
+    static const bool profile = gmk::profile_env("GMK_PVNET_PROFILE") != nullptr;
     prm.prof = nullptr;
     if (profile) GMK_HIP_CHECK(hipMalloc(&prm.prof, 6 * sizeof(unsigned long long)));
     const int grid = std::min(n, st.cu_count > 0 ? st.cu_count : 256);        // one workgroup per CU, each takes every grid-th position

@@ -356,7 +356,7 @@ extern "C" int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, u
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts;
     prm.seed_lo = static_cast<uint32_t>(seed); prm.seed_hi = static_cast<uint32_t>(seed >> 32); prm.first_game_id = first_game_id; prm.game_ids = t->d_game_ids;
     prm.c_puct = c_puct;
-    static const bool profile = std::getenv("GMK_RAVE_PROFILE") != nullptr;
+    static const bool profile = gmk::profile_env("GMK_RAVE_PROFILE") != nullptr;
     prm.profile = profile ? 1 : 0;
     const int grid = (t->n_games + kWaves - 1) / kWaves;
     hipLaunchKernelGGL(rave_playouts_kernel, dim3(grid), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), prm);

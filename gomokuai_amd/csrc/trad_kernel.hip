@@ -773,7 +773,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     prm.moves = t->d_moves; prm.lens = t->d_lens;
     prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
-    static const bool profile = std::getenv("GMK_TRAD_PROFILE") != nullptr;
+    static const bool profile = gmk::profile_env("GMK_TRAD_PROFILE") != nullptr;
     prm.profile = profile ? 1 : 0;
     const int grid = (t->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
     hipLaunchKernelGGL(trad_playouts_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), prm);

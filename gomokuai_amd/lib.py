@@ -6,6 +6,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libgomoku_hip.so")
+# tools/*.sh ask for the profiling flavour of the library explicitly (GMK_HIP_LIB=prof; built by `python -m gomokuai_amd.build
+# --profile`): only that one reads GMK_*_PHASE_MASK / GMK_*_PROFILE.  Anything else loads the production library, which ignores them.
+if os.environ.get("GMK_HIP_LIB") == "prof":
+    _SO = os.path.join(_HERE, "libgomoku_hip_prof.so")
+elif os.environ.get("GMK_HIP_LIB", "").endswith(".so"):          # an experiment build of tools/k1_variants.py, by path
+    _SO = os.environ["GMK_HIP_LIB"]
 
 N = 225
 

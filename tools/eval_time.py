@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """K1 timing aid: kernel time per launch with optional outputs switched off (NULL output pointers are allowed by the C-ABI).
-usage: eval_time.py [variant ...]   variants: all, no-density, no-scores, neither (default: every one of them)"""
+usage: eval_time.py [variant ...] [check]   variants: all, no-density, no-scores, neither (default: every one of them);
+check: also print a position-weighted checksum of the four outputs (tools/k1_variants.py compares it across builds)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,7 +18,8 @@ d_status = torch.empty((n,), dtype=torch.int32, device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 variants = {"all": (1, 1), "no-density": (1, 0), "no-scores": (0, 1), "neither": (0, 0)}
 reps = int(os.environ.get("GMK_EVAL_REPS", "100"))
-for name in (sys.argv[1:] or list(variants)):
+check = "check" in sys.argv
+for name in ([a for a in sys.argv[1:] if a != "check"] or list(variants)):
     sc, de = variants[name]
     f = lambda: G.eval_batch(d_planes.data_ptr(), n, d_scores.data_ptr() if sc else 0, d_density.data_ptr() if de else 0, d_totals.data_ptr(), d_status.data_ptr(), stream)
     for _ in range(10): f()
@@ -26,3 +28,9 @@ for name in (sys.argv[1:] or list(variants)):
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     print("%-12s %.4f ms" % (name, e0.elapsed_time(e1) / reps))
+    if check and name == "all":
+        cs = 0
+        for t in (d_scores, d_density.view(-1)[:n * 900], d_totals, d_status):
+            v = t.contiguous().view(-1).long()
+            cs = (cs * 1000003 + int((v * (torch.arange(v.numel(), device=dev) % 65521 + 1)).sum().item())) % (1 << 61)
+        print("checksum %x" % cs)

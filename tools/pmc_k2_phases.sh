@@ -4,6 +4,7 @@
 # always placed, so the boards evolve as in the full run).  The states are wrong unless the mask is 63.
 cd "${GRAFT_REPO_ROOT:-.}" && export TMPDIR=/tmp
 out=gpurun_out/pmc_k2p; rm -rf $out; mkdir -p $out
+export GMK_HIP_LIB=prof          # the phase masks live in the profiling flavour of the library only
 for m in ${MASKS:-1 21 29 31 63}; do
   t=$(GMK_EVS_PHASE_MASK=$m timeout -k 10 120 python3 tools/evalstate_time.py | tail -1 | sed 's/.*-> //')
   GMK_EVS_PHASE_MASK=$m timeout -k 10 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $out/m_$m -o p --output-format csv -- python3 tools/evalstate_time.py > $out/run_$m.log 2>&1 || { echo "mask $m failed"; tail -5 $out/run_$m.log; exit 1; }
