@@ -57,7 +57,8 @@ constexpr int kMiscWords = 48;                   // [0] stones black | white << 
                                                  // [19..33] the rows (black | white << 16) between three zero rows on either side ([16..18], [34..36])
 constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
 static_assert(kZeroWords % 4 == 0 && kBoardWords % 4 == 0, "16-byte alignment of the per-board blocks");
-constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560;   // lane jobs, initial line words, the bits-to-bytes table and the weight table of phase D
+constexpr int kStaticTableWords = 128 + kLineWords + 512 + 1560 + 4;   // lane jobs, initial line words, the bits-to-bytes table, the weight table of phase D,
+                                                                        // and the workgroup's two hand-out counters (boards, density bursts)
 
 // Lane -> line jobs.  A job word holds what the scan and the deposits need of a line, ready to use: bits 0..4 symbols in its stream
 // segment (len + 3: one leading and two trailing pads), 5..6 dir, 7..11 cell stride, 12..19 its first cell, 20..26 line word index.
@@ -341,6 +342,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     uint32_t* s_wtab_words = s_jobs + 128 + kLineWords + 512;
     for (int i = threadIdx.x; i < kWtabWords; i += kThreads) s_wtab_words[i] = g_wtab[i];
     const v4i* s_wtab = reinterpret_cast<const v4i*>(s_wtab_words);
+    uint32_t* s_handout = s_wtab_words + kWtabWords;        // [0] boards handed out, [1] density bursts handed out
+    if (threadIdx.x < 4) s_handout[threadIdx.x] = 0;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     uint32_t* s_scores = lds + trans_words + record_words + kStaticTableWords + wave * kBoardWords;      // int32 scores, accumulated with ds_add
@@ -352,12 +355,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     __syncthreads();                                         // tables staged; from here on waves never wait for each other
     GMK_STAMP(0);
 
-    // ---- work distribution ----
-    // A wavefront takes groups of sixteen consecutive boards, evaluates them one after the other and, in the board iteration that is
-    // its turn within the workgroup, sends the group's density planes off (phase D); which groups: see the loop below.
-    // (Handing the boards out dynamically -- chunk counters per workgroup with stealing round the ring -- evened out the wavefronts'
-    // finishing times, 86 % instead of 72 % of the kernel's run time busy, and changed nothing: the SIMDs are what is busy, not
-    // the slowest wavefront; measured 0.215 ms against 0.206 ms, see DESIGN.md.)
+    // ---- work distribution: see the hand-out counters below ----
     const bool planes_out = out_density != nullptr && (phase_mask & 64) && !(phase_mask & 1024);
     int lane = lane0;
     const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
@@ -382,27 +380,32 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     };
     auto take_row = [&](int b) -> uint32_t { return lane < 16 && b < n_boards ? cur_black | (cur_white << 16) : 0u; };
 
-    for (int base = 0; base < n_groups; base += gridDim.x * kBoardsPerBlock) {
-    // the workgroup's wavefronts take ADJACENT groups (as many per workgroup as it takes to give every workgroup some: sixteen in a
-    // full batch, one in a small one): what a CU writes at any time then lies within one megabyte, its density bursts follow one
-    // another through it (0.1859 -> 0.1805 ms against handing consecutive groups to different workgroups)
-    const int per_wg = min(kBoardsPerBlock, (n_groups - base + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x));
-    const int group = (phase_mask & 4096) ? base + static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) * wave : base + static_cast<int>(blockIdx.x) * per_wg + wave;
-    if (group >= n_groups || (!(phase_mask & 4096) && wave >= per_wg)) continue;
-    const int first_board = group * kGroupBoards;
-    fetch_row(first_board);
-    asm volatile("" : "+v"(next_black), "+v"(next_white));        // (once per group: wait for them here)
-
+    // The workgroup owns one contiguous run of groups (what a CU writes at any time lies within a few hundred kilobytes) and hands its
+    // boards out one at a time from a counter in LDS: the sixteen wavefronts -- four per SIMD, and a SIMD's vector unit is what the kernel
+    // is bound by -- finish within one board of each other instead of 16 boards x (the spread of a board's work, ~ +-25 %) apart.
+    // The density bursts of its groups are handed out the same way, one per wavefront and sixteen boards, wavefront w in its w-th board.
+    // (Round 2 measured a dynamic hand-out -- chunks of four, stealing round a ring of workgroups -- as no gain and concluded the wavefronts'
+    // waits were the limit.  They are not: tools/valu_probe.hip shows a wave-instruction costs a SIMD 4 cycles whatever its type, K1's ~950
+    // per board make the vector unit ~90 % busy while all sixteen wavefronts run, and what the static hand-out lost was whole SIMDs idling
+    // behind the slowest one: 0.1544 -> 0.1402 ms.)
+    const int wg_g0 = static_cast<int>(static_cast<long long>(n_groups) * blockIdx.x / gridDim.x);
+    const int wg_groups = static_cast<int>(static_cast<long long>(n_groups) * (blockIdx.x + 1) / gridDim.x) - wg_g0;
+    const int wg_first = wg_g0 * kGroupBoards, wg_boards = min(wg_groups * kGroupBoards, n_boards - wg_first);
+    auto hand_out = [&](int which) -> int {
+        uint32_t v = 0;
+        if (lane0 == 0) v = atomicAdd(&s_handout[which], 1u);
+        return __builtin_amdgcn_readfirstlane(static_cast<int>(v));
+    };
+    int idx = hand_out(0), boards_done = 0;
+    if (idx < wg_boards) fetch_row(wg_first + idx);
+    asm volatile("" : "+v"(next_black), "+v"(next_white));        // (once: wait for them here)
 #pragma unroll 1
-    for (int bi = 0; bi < kGroupBoards; ++bi) {
-        const int board = first_board + bi;
-        const bool live = board < n_boards;
-        // the next board's planes are requested HERE, ahead of phases 0 .. 4, and waited for in ONE place, just before the iteration's
-        // stores: loads and stores share one in-order counter (vmcnt), so wherever else the wait stood it would also wait for stores
-        // issued moments before (the compiler cannot count across the loop, it waits for everything).  There, the youngest
-        // outstanding operation is a board's work old.
+    for (;;) {
+        const bool live = idx < wg_boards;
+        const int board = wg_first + idx;
         cur_black = next_black; cur_white = next_white;
-        if (bi + 1 < kGroupBoards) fetch_row(board + 1);
+        int idx_next = idx;
+        if (live) { idx_next = hand_out(0); fetch_row(wg_first + min(idx_next, wg_boards - 1)); }
         GMK_STAMP(11);
 
         if (live) {
@@ -696,18 +699,20 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         asm volatile("" : "+v"(next_black), "+v"(next_white));    // the wait for the next board's planes (a use the compiler must honour)
         GMK_STAMP(7);
 
-        // ---- phase D: the group's density planes leave, in the board iteration that is this wavefront's turn ----
-        if (planes_out && bi == wave) {
-            int lane_p = lane0, first_p = first_board;         // opaque copies: what the passes derive from them is computed here, not kept
-            asm volatile("" : "+v"(lane_p), "+s"(first_p));     // in registers from the top of the group
-            density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
-            GMK_STAMP(8);
+        // ---- phase D: density planes of the workgroup's groups: one burst in this wavefront's turn (its w-th board of every sixteen),
+        //      and whatever is left once the boards have run out ----
+        if (planes_out && (!live || (boards_done & 15) == wave)) {
+            for (;;) {
+                const int burst = hand_out(1);
+                if (burst >= wg_groups) break;
+                int lane_p = lane0, first_p = (wg_g0 + burst) * kGroupBoards;      // opaque copies: what the passes derive from them is computed here
+                asm volatile("" : "+v"(lane_p), "+s"(first_p));
+                density_planes_out(planes, n_boards, first_p, lane_p, s_wtab, out_density, s_lut, (phase_mask & 512) ? 0 : (phase_mask & 256) ? 256 : kCells);
+                GMK_STAMP(8);
+                if (live) break;
+            }
         }
-        if (!live) {
-            if (!planes_out || bi >= wave) break;
-            continue;
-        }
-
+        if (!live) break;
         // ---- phase 5: results leave LDS ----
         if (live && (phase_mask & 32)) {
             int lane_b = lane;                                  // (a copy the compiler cannot see through: the store addresses are computed here,
@@ -743,8 +748,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         }
         wave_phase_fence();
         GMK_STAMP(9);
-
-    }
+        idx = idx_next; ++boards_done;
     }
 #ifdef GMK_PROFILE
     // [0] table staging, [1] phase 0, [2] scan, [3] deposits, [4] phase 3, [5] phase 3b, [6] rescans, [7] wait for the next planes,

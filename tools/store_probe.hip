@@ -14,6 +14,7 @@
 //   bit 7   the burst in iteration 0 for every wavefront (instead of iteration == wavefront number)
 //   bit 8   density 16 B-per-lane stores non-temporal as well
 //   bit 9   board stride 3 584 B (28 x 128: every 1 KB piece starts on a cache line) instead of 3 600 B -- diagnostic only, the C-ABI fixes 3 600
+//   bit 12  score blocks as 16 dword stores per board (one word per lane into each of the four group planes)
 //   bit 11  600 idle cycles between the fourteen passes of a density burst
 //   bit 10  no board structure at all: iteration i, piece k of all wavefronts are one contiguous sweep (what fill_ does, in K1's launch shape)
 // The launch takes 158 KB of LDS per workgroup like K1, so that every CU gets exactly one workgroup.
@@ -72,6 +73,14 @@ __global__ __launch_bounds__(1024) void pattern_kernel(int32_t* __restrict__ sco
                         if (mode & 2) __builtin_nontemporal_store(v, d); else *d = v;
                     }
                 }
+            } else if (mode & 4096) {
+                // K1 round 3: the score block is [cell][group] in LDS: a lane writes one word into each group's plane, 256 contiguous bytes per instruction
+                int32_t* dst = scores + static_cast<size_t>(board) * kScoreWords + lane;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (p < 3 || lane < 33) { if (mode & 2) __builtin_nontemporal_store(board + g, dst + 64 * p + g * kCells); else dst[64 * p + g * kCells] = board + g; }
             } else if (mode & 1) {
                 store_block<(mode & 2) != 0>(scores + static_cast<size_t>(board) * stride, stride, lane, board);
             }
@@ -196,6 +205,10 @@ int main(int argc, char** argv) {
         M(1 | 2 | 4 | 128, "K1 pattern, every wavefront's burst in iteration 0"),
         M(1 | 2 | 4 | 2048, "K1 pattern, 600 cycles between the passes of a burst"),
         M(4 | 2048, "density dword burst alone, 600 cycles between passes"),
+        M(1 | 2 | 4096, "scores as 16 dword stores nt (256 B per instruction)"),
+        M(1 | 4096, "scores as 16 dword stores plain"),
+        M(1 | 2 | 4 | 4096, "round-3 K1: scores 16 dword nt + density dword burst"),
+        M(1 | 2 | 8 | 4096, "scores 16 dword nt + density 16B/lane burst"),
     };
     for (int spin : spins)
         for (const Mode& m : modes) {
