@@ -27,6 +27,32 @@ def measured_traffic(kernel, units_key, units):
 REDUCE_DEVICE = None          # torch device the cross-rank reductions run on: the GPU with RCCL, the CPU in the gloo rehearsal mode
 
 
+class LegFailed(RuntimeError):
+    """A leg of the bench failed on some rank; raised on every rank (see all_ranks_ok)."""
+
+
+def all_ranks_ok(ok, torch, dev, distributed):
+    """Every rank learns whether local work succeeded everywhere (all-reduce MIN of a flag): ranks that sit in one another's barriers
+    must take the same branch, or the ones that carried on wait for the one that left until the process group's timeout."""
+    if not distributed:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=REDUCE_DEVICE or dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    return bool(int(flag[0]))
+
+
+def local_stage(what, fn, torch, dev, distributed):
+    """Runs local (collective-free) work of a leg, then lets the ranks agree on its outcome; raises LegFailed on all of them if one failed."""
+    result, failure = None, None
+    try:
+        result = fn()
+    except Exception as exc:                                    # noqa: BLE001
+        failure = "%s: %s" % (type(exc).__name__, exc)
+    if not all_ranks_ok(failure is None, torch, dev, distributed):
+        raise LegFailed("%s failed on %s" % (what, "this rank (%s)" % failure if failure else "another rank"))
+    return result
+
+
 def measured_counter(kernel, key):
     """A derived figure of the committed rocprofv3 PMC passes (profiles/traffic.json), e.g. the share of VALU lanes that were active."""
     try:
@@ -127,9 +153,11 @@ def bench_mcts(args, G, torch, dev, rank, world, distributed):
     achieved = alg / (ms * 1e-3) / 1e9
     return {"metric": "mcts-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms, "saturated": saturated,
             "lane_utilisation": measured_counter("mcts_playouts_kernel", "valu_lane_utilisation"),
+            "lane_utilisation_source": "profiles/traffic.json (committed rocprofv3 PMC passes; not re-measured in this run)",
             "config": {"workload": "batched MCTS (K3), %d games x %d playouts per GPU, RandomPolicy c_puct=5 c_rollouts=5, 4-ply openings, fresh roots" % (n, P)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("mcts_playouts_kernel", "playouts_per_launch", n * P),
+                         "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes; not re-measured in this run)",
                          "kernel": "mcts_playouts_kernel", "kernel_ms": ms, "alg_bytes_per_launch": alg,
                          "note": "tree bytes only (select 8 B/child, expand 16 B/node, backup 16 B/level); rollouts run in LDS/registers, the kernel is latency/issue bound"}}
 
@@ -339,7 +367,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
             "network_ms_per_step": net_ms,
             "config": {"workload": "network-guided MCTS (K7), %d games x %d lock-step playouts per GPU, PolicyValueNetwork float32 with random weights, 4-ply openings" % (n, P)},
             "roofline": {"bound": "mfma", "achieved": conv_flop / (trunk_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": conv_flop / (trunk_ms * 1e-3) / 1e12 / 157.3, "traffic": measured_traffic("pvnet_trunk_kernel", "positions_per_launch", n), "kernel": "pvnet_trunk_kernel", "kernel_ms": trunk_ms,
+                         "frac": conv_flop / (trunk_ms * 1e-3) / 1e12 / 157.3, "traffic": measured_traffic("pvnet_trunk_kernel", "positions_per_launch", n), "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes; not re-measured in this run)", "kernel": "pvnet_trunk_kernel", "kernel_ms": trunk_ms,
                          "alg_flop_per_launch": conv_flop, "note": "dense f32-input MFMA peak (MI355X_MICROARCH.md); the convolution FLOPs of the 225 real pixels"},
             "pytorch_module_ms_per_step": torch_ms, "max_abs_diff_vs_pytorch_module": err,
             "note": "the step is the network's forward pass: K9 (one fused kernel for the convolutions, float32 MFMA) + three small dense layers through PyTorch-ROCm; "
@@ -359,11 +387,18 @@ def bench_selfplay(args, torch, dev, rank, world, distributed):
     if distributed:
         torch.distributed.barrier()
     t0 = time.perf_counter()
-    rec = selfplay.play_games(n, P, first_game_id=first)
-    torch.cuda.synchronize()
+    # (the local stages -- they allocate gigabytes -- end in an agreement of the ranks: see local_stage)
+    def play():
+        r = selfplay.play_games(n, P, first_game_id=first)
+        torch.cuda.synchronize()
+        return r
+    rec = local_stage("self-play", play, torch, dev, distributed)
     t1 = time.perf_counter()
-    states, values, pi = rec.to_samples(augment=False)
-    torch.cuda.synchronize()
+    def tuples():
+        r = rec.to_samples(augment=False)
+        torch.cuda.synchronize()
+        return r
+    states, values, pi = local_stage("training tuples", tuples, torch, dev, distributed)
     t2 = time.perf_counter()
     # the rehearsal mode's gloo has no device transfers: there the same exchange runs on host copies of the records
     gathered = selfplay.gather_records(rec if REDUCE_DEVICE is None else rec.cpu())
@@ -457,12 +492,18 @@ def parse_args(argv=None):
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
     ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
     ap.add_argument("--rave-playouts", type=int, default=400)
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which `--gpus N` without a launcher stops its rank processes")
+    ap.add_argument("--settle-ms", type=float, default=30.0,
+                    help="milliseconds of untimed K1 launches ahead of the W warm-up steps: the chip's clock governor needs ~20 ms of continuous "
+                         "work after an idle spell before the time per launch is steady (profiles/r03_ramp.txt); 0 = none")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help="--stub only: this rank exits with code 3 before the rendezvous (launcher test)")
+    ap.add_argument("--stub-hang-rank", type=int, default=-1, help="--stub only: this rank never reaches the rendezvous (launcher time-limit test)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test without a GPU: ranks rendezvous over gloo, the step is a no-op and the line says so (tests/test_bench_launcher.py)")
     return ap.parse_args(argv)
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s=1500.0):
     """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes of this script, one per GPU of the
     node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would set them), and wait.
     This process has not touched the GPU (no torch import yet): the ranks are children, nothing is exec'ed over a GPU process."""
@@ -477,17 +518,49 @@ def launch_ranks(n, argv):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    codes = [p.wait() for p in procs]
-    return max(abs(c) for c in codes)
+    # Fail fast and collectively: the ranks sit in barriers and reductions of one another, so the first rank that exits non-zero (or
+    # the overall time limit) ends the others -- terminate, then kill -- and its code is the launcher's.  Only these children are
+    # signalled, by pid.
+    deadline = time.monotonic() + timeout_s
+    code = 0
+    while True:
+        states = [p.poll() for p in procs]
+        failed = [c for c in states if c not in (None, 0)]
+        if failed:
+            code = abs(failed[0])
+            break
+        if all(c == 0 for c in states):
+            return 0
+        if time.monotonic() > deadline:
+            print("bench.py: ranks still running after %.0f s: stopping them" % timeout_s, file=sys.stderr)
+            code = 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    t_kill = time.monotonic() + 5.0
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.0, t_kill - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return code
 
 
 def stub_rank(args, world, rank):
     """--stub: what the launcher and the rank bookkeeping do, without a GPU: rendezvous (gloo), barrier, max over ranks, one line."""
+    if rank == args.stub_fail_rank:
+        sys.exit(3)
+    if rank == args.stub_hang_rank:
+        time.sleep(3600)
+    import datetime
     import torch
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -510,7 +583,7 @@ def stub_rank(args, world, rank):
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
@@ -518,6 +591,7 @@ def main():
     if args.stub:
         return stub_rank(args, world, rank)
 
+    import datetime
     import numpy as np
     import torch
     from gomokuai_amd import lib as G
@@ -530,14 +604,14 @@ def main():
         backend = os.environ.get("GMK_BENCH_BACKEND", "nccl")
         if backend == "nccl":                                    # RCCL: one rank per GPU
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
         else:
             # rehearsal of the N > 1 path on a box with fewer GPUs than ranks (GMK_BENCH_BACKEND=gloo): the ranks share the GPUs there are,
             # barriers and reductions go over gloo on the CPU; everything else is the code the RCCL run executes
             global REDUCE_DEVICE
             REDUCE_DEVICE = torch.device("cpu")
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=600))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -555,8 +629,7 @@ def main():
         G.eval_batch(d_planes.data_ptr(), n, d_scores.data_ptr(), d_density.data_ptr(), d_totals.data_ptr(),
                      d_status.data_ptr(), torch.cuda.current_stream().cuda_stream if stream is None else stream)
 
-    for _ in range(args.warmup):
-        step()
+    step()                                                   # the library's first call uploads its constant tables: it cannot be part of a capture
     torch.cuda.synchronize()
     # the K timed steps are captured once into a hipGraph (K kernel nodes) and replayed: no per-launch host work in the
     # timed region ("graph-launched"); --no-graph, or a failed capture, launches them one by one instead
@@ -567,12 +640,33 @@ def main():
             with torch.cuda.graph(graph):
                 for _ in range(args.steps):
                     step()
-            graph.replay()                                   # one untimed replay: the graph is uploaded here
-            torch.cuda.synchronize()
         except Exception as exc:                             # noqa: BLE001
             print("bench: hipGraph capture failed (%s); launching step by step" % exc, file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+    # Settling: after an idle spell (everything above is host work) the chip's clock governor takes ~20 ms of continuous work before
+    # the time per launch is steady -- launches 10 to 40 after idle run 15-20 % SLOWER than launches 100 on (tools/ramp_probe.py,
+    # profiles/r03_ramp.txt) -- and the timed region of K = 20 steps is 3 ms long.  So the same step runs untimed for --settle-ms
+    # of device time first (reported in the line), then the W warm-up steps, then the timed K; no gap between them is long enough
+    # (> ~2 ms) to send the governor back.
+    settle = {"ms": 0.0, "launches": 0}
+    if args.settle_ms > 0:
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        while True:
+            for _ in range(16):
+                step()
+            settle["launches"] += 16
+            s1.record()
+            s1.synchronize()
+            settle["ms"] = s0.elapsed_time(s1)
+            if settle["ms"] >= args.settle_ms or settle["launches"] >= 4096:
+                break
+    for _ in range(args.warmup):
+        step()
+    if graph is not None:
+        graph.replay()                                       # one untimed replay: the graph is uploaded here
+    torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -618,10 +712,14 @@ def main():
 
     pipeline = pipeline_error = None
     if args.selfplay_games >= world:                            # every rank needs a game (the same decision on all ranks: the leg has barriers)
+        # the headline line must not be lost to this leg: a failure is reported in its place -- by every rank alike (the leg's local stages
+        # end in an agreement of the ranks, so no rank is left in a barrier of the leg; whatever still escapes that is agreed on here)
         try:
             pipeline = bench_selfplay(args, torch, dev, rank, world, distributed)
-        except Exception as exc:                                  # the headline line must not be lost to this leg
+        except Exception as exc:                                  # noqa: BLE001
             pipeline_error = "%s: %s" % (type(exc).__name__, exc)
+        if not all_ranks_ok(pipeline_error is None, torch, dev, distributed) and pipeline_error is None:
+            pipeline, pipeline_error = None, "LegFailed: the leg failed on another rank"
 
     if rank == 0:
         achieved = ALG_BYTES_PER_EVAL * n / (kernel_ms * 1e-3) / 1e9
@@ -642,10 +740,13 @@ def main():
                                    % (n, "random-opening" if args.kind == 0 else "clustered"),
                        "boards_per_gpu": n, "parallelism": "boards sharded by rank, no collective" + ("" if os.environ.get("GMK_BENCH_BACKEND", "nccl") == "nccl" or world == 1
                                                                                                        else " (REHEARSAL: %d ranks over gloo sharing %d GPU(s))" % (world, torch.cuda.device_count())),
-                       "launch": "hipGraph replay of the K steps" if graph is not None else "K stream launches"},
+                       "launch": "hipGraph replay of the K steps" if graph is not None else "K stream launches",
+                       "settle": {"untimed_launches_before_warmup": settle["launches"], "ms": settle["ms"],
+                                  "why": "clock governor: time per launch is steady only after ~20 ms of continuous work (profiles/r03_ramp.txt); --settle-ms 0 disables"}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic("eval_positions_kernel", "boards_per_launch", n),
+                         "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes of this kernel; not re-measured in this run)",
                          "kernel": "eval_positions_kernel", "kernel_ms": kernel_ms,
                          "alg_bytes_per_launch": ALG_BYTES_PER_EVAL * n},
         }

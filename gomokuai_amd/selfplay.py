@@ -612,23 +612,35 @@ def pack_records(rec):
     return torch.cat(parts)
 
 
-def unpack_records(buf, n, has_visits, first_game_id=0, overflow=False):
-    """pack_records undone: fixed-stride GameRecords on buf's device (what to_samples() / K4 + K5 read)."""
+def unpack_records_into(buf, n, has_visits, moves, lens, winner, visits, at):
+    """pack_records undone into rows [at, at + n) of preallocated fixed-stride arrays (rows beyond a game's length must be zero already)."""
     dev = buf.device
-    lens = buf[:4 * n].view(torch.int32).clone()
-    winner = buf[4 * n:5 * n].view(torch.int8).clone()
-    total = int(lens.sum()) if n else 0
-    played = torch.arange(N, device=dev)[None, :] < lens[:, None]
-    moves = torch.zeros((n, N), dtype=torch.uint8, device=dev)
-    moves[played] = buf[5 * n:5 * n + total]
-    visits = None
-    if has_visits:
-        visits = torch.zeros((n, N, N), dtype=torch.int16, device=dev)
+    lens[at:at + n] = buf[:4 * n].view(torch.int32)
+    winner[at:at + n] = buf[4 * n:5 * n].view(torch.int8)
+    my_lens = lens[at:at + n]
+    total = int(my_lens.sum()) if n else 0
+    played = torch.arange(N, device=dev)[None, :] < my_lens[:, None]
+    moves[at:at + n][played] = buf[5 * n:5 * n + total]
+    if has_visits and visits is not None:
         flat = buf[5 * n + total:5 * n + total + total * N * 2]
         if (5 * n + total) % 2:                                  # int16 views need an even byte offset
             flat = flat.clone()
-        visits[played] = flat.view(torch.int16).reshape(total, N)
+        visits[at:at + n][played] = flat.view(torch.int16).reshape(total, N)
+
+
+def unpack_records(buf, n, has_visits, first_game_id=0, overflow=False):
+    """pack_records undone: fixed-stride GameRecords on buf's device (what to_samples() / K4 + K5 read)."""
+    dev = buf.device
+    moves = torch.zeros((n, N), dtype=torch.uint8, device=dev)
+    lens = torch.zeros((n,), dtype=torch.int32, device=dev)
+    winner = torch.zeros((n,), dtype=torch.int8, device=dev)
+    visits = torch.zeros((n, N, N), dtype=torch.int16, device=dev) if has_visits else None
+    unpack_records_into(buf, n, has_visits, moves, lens, winner, visits, 0)
     return GameRecords(moves, lens, winner, visits, first_game_id, overflow)
+
+
+class GatherError(RuntimeError):
+    """Raised on EVERY rank when any rank could not contribute to gather_records."""
 
 
 def gather_records(rec, dst=0, group=None):
@@ -643,7 +655,17 @@ def gather_records(rec, dst=0, group=None):
         return rec
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = rec.lens.device
-    mine = pack_records(rec)
+    # Packing is local work that can fail on one rank alone (memory): the ranks agree on it BEFORE the first collective, so that a failure
+    # is raised on every rank (GatherError) instead of leaving the others waiting in all_gather for a rank that has left.
+    mine, failure = None, None
+    try:
+        mine = pack_records(rec)
+    except Exception as exc:                                    # noqa: BLE001
+        failure = exc
+    ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok[0]) == 0:
+        raise GatherError("gather_records: packing failed on %s" % ("this rank: %s: %s" % (type(failure).__name__, failure) if failure is not None else "another rank"))
     # sizes first: [games, bytes, first game id, arena overflow seen, visits recorded]
     meta = torch.tensor([len(rec), int(mine.numel()), int(rec.first_game_id), int(bool(rec.overflow)), int(rec.visits is not None)], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
@@ -661,12 +683,24 @@ def gather_records(rec, dst=0, group=None):
         return None
     has_visits = all(m[4] for m in metas if m[0] > 0) and any(m[0] > 0 for m in metas)
     overflow = any(m[3] for m in metas)                          # a rank whose arenas overflowed must not be reported as clean
-    parts = [unpack_records(bufs[r], metas[r][0], bool(metas[r][4]), metas[r][2]) for r in range(world) if metas[r][0] > 0]
     first = min((m[2] for m in metas if m[0] > 0), default=rec.first_game_id)
-    if not parts:
+    n_all = sum(m[0] for m in metas)
+    if n_all == 0:
         return GameRecords(rec.moves[:0], rec.lens[:0], rec.winner[:0], None if rec.visits is None else rec.visits[:0], first, overflow)
-    return GameRecords(torch.cat([p.moves for p in parts]), torch.cat([p.lens for p in parts]), torch.cat([p.winner for p in parts]),
-                       torch.cat([p.visits for p in parts]) if has_visits else None, first, overflow)
+    # The fixed-stride form is allocated ONCE for all ranks and every rank's bytes are unpacked into their rows, the wire buffer of a rank
+    # freed as soon as it has been read: 32 768 games are 3.3 GB of visit rows, and per-rank parts plus a concatenation would hold them twice.
+    moves = torch.zeros((n_all, N), dtype=torch.uint8, device=dev)
+    lens = torch.zeros((n_all,), dtype=torch.int32, device=dev)
+    winner = torch.zeros((n_all,), dtype=torch.int8, device=dev)
+    visits = torch.zeros((n_all, N, N), dtype=torch.int16, device=dev) if has_visits else None
+    at = 0
+    for r in range(world):                                       # rank order = global game id order
+        if metas[r][0] > 0:
+            unpack_records_into(bufs[r], metas[r][0], bool(metas[r][4]), moves, lens, winner, visits, at)
+            at += metas[r][0]
+        bufs[r] = None
+    del mine
+    return GameRecords(moves, lens, winner, visits, first, overflow)
 
 
 def shard(n_total, rank, world):

@@ -40,3 +40,24 @@ def test_under_torchrun_style_environment():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_a_failing_rank_ends_the_others_quickly():
+    """Fail fast and collectively: rank 1 exits with code 3 before the rendezvous; the launcher stops the ranks that wait for it and
+    returns non-zero well inside the rendezvous timeout."""
+    import time
+    t0 = time.monotonic()
+    r = _run(["--gpus", "3", "--steps", "2", "--warmup", "0", "--stub", "--stub-fail-rank", "1"], timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert time.monotonic() - t0 < 10.0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], "no result line from a failed job"
+
+
+def test_launcher_time_limit():
+    """... and an overall time limit: rank 1 never reaches the rendezvous, rank 0 waits for it; after --launch-timeout seconds the
+    launcher stops both and reports 124."""
+    import time
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--stub", "--stub-hang-rank", "1", "--launch-timeout", "3"], timeout=60)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert time.monotonic() - t0 < 20.0

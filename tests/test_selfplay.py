@@ -120,6 +120,36 @@ def test_gather_gloo(tmp_path, world, total, dst):
         assert torch.equal(allrec[key], torch.cat([p[key] for p in parts], dim=0)), key
 
 
+def _failing_gather_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    lo, n = selfplay.shard(6, rank, world)
+    rec = _fake_records(n, lo, 7 + rank)
+    if rank == 1:
+        rec.moves = None                                   # packing this rank's records raises before the first collective
+    try:
+        selfplay.gather_records(rec, dst=0)
+        outcome = "returned"
+    except selfplay.GatherError as exc:
+        outcome = "GatherError: %s" % exc
+    open(os.path.join(out_dir, "outcome%d.txt" % rank), "w").write(outcome)
+    dist.barrier()                                         # every rank is still in step with the others
+    dist.destroy_process_group()
+
+
+def test_gather_fails_on_every_rank_when_one_cannot_pack(tmp_path):
+    """A rank that fails before all_gather must not leave the others waiting in it: the ranks agree first, all raise GatherError."""
+    import time
+    t0 = time.monotonic()
+    mp.spawn(_failing_gather_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert time.monotonic() - t0 < 45.0
+    outcomes = [open(os.path.join(tmp_path, "outcome%d.txt" % r)).read() for r in range(3)]
+    assert all(o.startswith("GatherError") for o in outcomes), outcomes
+    assert "this rank" in outcomes[1] and "another rank" in outcomes[0]
+
+
 def test_wire_form_is_compact_and_round_trips():
     """pack_records carries only what was played (moves u8[L], visits u16[L][225], winner, length per game)."""
     rec = _fake_records(3, 9, 5)
