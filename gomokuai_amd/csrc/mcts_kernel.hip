@@ -48,7 +48,7 @@ struct GameHeader {                 // 128 B per game, in HBM
     uint32_t stones;                // stones on the root board (= Policy::m_initActs)
     uint32_t last_move;             // cell of the last move, 255 if none
     uint32_t game_id;               // global game id (RNG counter word 0)
-    uint32_t status;                // bit1: arena full
+    uint32_t status;                // bit 0: the game is over, bit 1: an arena of this slot filled up (sticky over a slot's games), bit 2: illegal move requested
     uint64_t alg_bytes;             // algorithmic tree bytes of the last run
     uint32_t playouts_done;         // playouts already run from this root (RNG counter word 1 continues across launches)
     uint32_t noise;                 // 1: the root's children take their priors from root_prior[] (Default::AddNoise ran)
@@ -148,7 +148,11 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     uint32_t (*const s_path_node)[kPathCap] = reinterpret_cast<uint32_t (*)[kPathCap]>(&s_leaf[G][0]);
     uint32_t (*const s_path_visits)[kPathCap] = s_path_node + G;
     float (*const s_path_value)[kPathCap] = reinterpret_cast<float (*)[kPathCap]>(s_path_visits + G);
-    const uint32_t inv_lanes = 0xFFFFFFFFu / static_cast<uint32_t>(n_rollout_lanes) + 1u, inv_r = 0xFFFFFFFFu / static_cast<uint32_t>(R) + 1u;   // t / d = umulhi(t, inv) for the small t here
+    // t / d = umulhi(t, 2^32 / d rounded up) for the small t here; the constant does not exist for d == 1 (it would be 2^32: it wraps to 0 and
+    // every quotient with it), so a divisor of one -- RandomPolicy(c, 1), or one game with one rollout -- takes the dividend as it is
+    const uint32_t inv_lanes = 0xFFFFFFFFu / static_cast<uint32_t>(n_rollout_lanes) + 1u, inv_r = 0xFFFFFFFFu / static_cast<uint32_t>(R) + 1u;
+    auto div_lanes = [&](uint32_t t) -> uint32_t { return n_rollout_lanes == 1 ? t : __umulhi(t, inv_lanes); };
+    auto div_r = [&](uint32_t t) -> uint32_t { return R == 1 ? t : __umulhi(t, inv_r); };
 
     unsigned long long prof[4] = {0, 0, 0, 0}, t_mark = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;   // diagnostic build only
     for (int playout = 0; playout < prm.playouts; ++playout) {
@@ -282,8 +286,8 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         //      per task, block-major, so that the rollout loop below only plays (the generator is ~150 instructions a block, and
         //      a third of the lanes roll out) ----
         for (int t = lane; t < 29 * n_rollout_lanes; t += 64) {
-            const uint32_t b = __umulhi(static_cast<uint32_t>(t), inv_lanes), rl = static_cast<uint32_t>(t) - b * static_cast<uint32_t>(n_rollout_lanes);
-            const uint32_t gs = __umulhi(rl, inv_r), r = rl - gs * static_cast<uint32_t>(R);
+            const uint32_t b = div_lanes(static_cast<uint32_t>(t)), rl = static_cast<uint32_t>(t) - b * static_cast<uint32_t>(n_rollout_lanes);
+            const uint32_t gs = div_r(rl), r = rl - gs * static_cast<uint32_t>(R);
             if (static_cast<int>(gs) < games_here && s_active[gs] && s_need[gs] && 8u * b < 225u - s_ply[gs])
                 s_cells[b * static_cast<uint32_t>(n_rollout_lanes) + rl] = rollout_cells(s_rng_game[gs], s_rng_playout[gs] + static_cast<uint32_t>(playout), s_rng_stones[gs] | r,
                                                                                        b, prm.seed_lo, prm.seed_hi);
@@ -518,7 +522,8 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
                 hdr.stones = static_cast<uint32_t>(olen);
                 hdr.last_move = root_cell;
                 hdr.game_id = slots.first_game_id + static_cast<uint32_t>(next);
-                hdr.status = 0u;
+                hdr.status &= 2u;                                   // a new game: not over; "an arena of this slot filled up" stays set for the whole
+                                                                    // run (the caller reads it once, afterwards: dropped playouts must not go unreported)
                 atomicAdd(unfinished, 1);
             }
         } else {

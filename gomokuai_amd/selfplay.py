@@ -119,7 +119,8 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
-    plan = plan_games(n_games, slots, handles, opening_plies)
+    # (the device-resident loop plays whole games: a cap on the moves per game takes the lock-step path below, which honours it)
+    plan = plan_games(n_games, slots, handles, opening_plies) if max_moves >= N else None
     if plan is not None:
         handles = len(plan)
         open_moves = open_lens = None

@@ -60,7 +60,8 @@ def test_two_handles_with_different_rollout_counts(oracle):
     a = G.BatchedMCTS(6, playouts_capacity=150, c_rollouts=5)
     b = G.BatchedMCTS(6, playouts_capacity=150, c_rollouts=10)          # created second: a one-table-per-process build would now serve a with b's table
     c = G.BatchedMCTS(6, playouts_capacity=150, c_rollouts=3)
-    for t, r in ((a, 5), (b, 10), (c, 3), (a, 5)):
+    d = G.BatchedMCTS(6, playouts_capacity=150, c_rollouts=1)           # RandomPolicy(c, 1): the divisor 1 has no reciprocal constant
+    for t, r in ((a, 5), (b, 10), (c, 3), (d, 1), (a, 5)):
         t.set_roots(planes, last, first_game_id=40)
         t.run(150)
         visits, q, _, nodes, status = t.root_stats()
@@ -68,8 +69,20 @@ def test_two_handles_with_different_rollout_counts(oracle):
             ov, oq, _, osize, _ = _oracle_search(oracle, moves[g], int(lens[g]), 150, 40 + g, c_rollouts=r)
             assert (visits[g] == ov).all() and nodes[g] == osize and q[g].tobytes() == oq.tobytes(), "c_rollouts %d, game %d" % (r, g)
         assert not status.any()
-    for t in (a, b, c):
+    for t in (a, b, c, d):
         t.close()
+
+
+def test_one_game_one_rollout(oracle):
+    """The smallest search handle: one game, c_rollouts = 1 (one rollout lane in the workgroup: both fast-division constants are for 1)."""
+    moves, lens, planes, last = _openings(1, 4, first=77)
+    t = G.BatchedMCTS(1, playouts_capacity=200, c_rollouts=1)
+    t.set_roots(planes, last, first_game_id=77)
+    t.run(200)
+    visits, q, _, nodes, status = t.root_stats()
+    ov, oq, _, osize, _ = _oracle_search(oracle, moves[0], int(lens[0]), 200, 77, c_rollouts=1)
+    assert (visits[0] == ov).all() and nodes[0] == osize and q[0].tobytes() == oq.tobytes() and not status.any()
+    t.close()
 
 
 def test_results_independent_of_batching(oracle):

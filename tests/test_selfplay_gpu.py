@@ -351,3 +351,20 @@ def test_network_self_play_reports_a_full_arena():
     assert not ok.overflow
     tight = selfplay.play_network_games(4, net, 12, opening_plies=2, reuse_subtree=False, root_noise=None, max_moves=6, node_capacity=600)
     assert tight.overflow
+
+
+def test_a_full_arena_in_an_early_game_of_a_slot_is_reported():
+    """Continuous batching: the arena-full bit of a slot must survive the hand-over to the slot's next game (it was cleared with the
+    rest of the status word, so only an overflow in a slot's LAST game was seen).  Twelve games through three slots with room for ~a fifth of a
+    search's nodes: every search overflows, the records say so; with the default capacity they do not."""
+    small = selfplay.play_games(12, 60, first_game_id=5, slots=3, handles=1, node_capacity=2048)
+    assert small.overflow
+    assert (small.cpu().lens > 0).all()
+    fine = selfplay.play_games(12, 60, first_game_id=5, slots=3, handles=1)
+    assert not fine.overflow
+
+
+def test_a_move_cap_is_honoured_whatever_the_batching():
+    """max_moves truncates the games on every path (the device-resident loop plays whole games only: a capped call must not take it)."""
+    rec = selfplay.play_games(10, 40, first_game_id=3, slots=4, handles=1, max_moves=7).cpu()
+    assert int(rec.lens.max()) <= 7
