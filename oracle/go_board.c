@@ -113,3 +113,24 @@ void go_board_encoded_states(const go_board *b, uint8_t *out) {
     }
     memset(out + index * GO_N, b->cur_player == GO_BLACK, GO_N);
 }
+
+/* Test aid: replays n recorded games move by move through Board::applyMove with its victory check (Game.cpp:37-62, 88-136).
+   For game g: legal[g] = 1 iff every move was accepted and none was played after the end; end_ply[g] = number of moves after which the
+   board was over (-1: never); winner[g] = m_winner then.  Lets a full-size batch of records be checked in seconds. */
+void go_board_replay_games(const uint8_t *moves, const int32_t *lens, int stride, int n, int8_t *legal, int32_t *end_ply, int8_t *winner) {
+    for (int g = 0; g < n; ++g) {
+        go_board b;
+        go_board_reset(&b);
+        int ok = 1, ended = -1;
+        for (int i = 0; i < lens[g]; ++i) {
+            if (b.cur_player == GO_NONE) { ok = 0; break; }                 /* a move after the end */
+            int before = b.cur_player;
+            int next = go_board_apply(&b, moves[(size_t)g * stride + i], 1);
+            if (next == before) { ok = 0; break; }                          /* rejected: occupied or off the board (Game.cpp:38-39) */
+            if (next == GO_NONE && ended < 0) ended = i + 1;
+        }
+        legal[g] = (int8_t)ok;
+        end_ply[g] = ended;
+        winner[g] = b.winner;
+    }
+}

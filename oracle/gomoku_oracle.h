@@ -56,6 +56,8 @@ int  go_board_check_end(go_board *b);
 int  go_board_random_move(const go_board *b, unsigned r);
 /* game_ext.hpp:87-104 : uint8[6][15][15] feature planes */
 void go_board_encoded_states(const go_board *b, uint8_t *out);
+/* test aid: n recorded games replayed through go_board_apply (see go_board.c) */
+void go_board_replay_games(const uint8_t *moves, const int32_t *lens, int stride, int n, int8_t *legal, int32_t *end_ply, int8_t *winner);
 
 /* ---------------- Patterns + AC automaton ---------------- */
 typedef struct {

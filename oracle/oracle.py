@@ -61,6 +61,8 @@ def lib():
     L.go_board_check_end.argtypes = [P(Board)]
     L.go_board_random_move.argtypes = [P(Board), C.c_uint]
     L.go_board_encoded_states.argtypes = [P(Board), C.c_void_p]
+    L.go_board_replay_games.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.go_board_replay_games.restype = None
     L.go_encode_char.argtypes = [C.c_char]
     L.go_ac_build.argtypes = [P(AC), P(C.c_char_p), P(C.c_int), P(C.c_int), C.c_int]
     L.go_ac_build_default.argtypes = [P(AC)]
@@ -239,6 +241,19 @@ class Evaluator:
         out = np.zeros(13, dtype=np.uint8)
         self.L.go_eval_line_view(self.h, int(pos), int(direction), out.ctypes.data)
         return out
+
+
+def replay_games(moves, lens):
+    """moves u8[n][stride], lens i32[n] -> (legal bool[n], end_ply i32[n], winner i8[n]): every game through Board::applyMove with its
+    victory check (oracle/go_board.c: go_board_replay_games)."""
+    moves = np.ascontiguousarray(moves, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    n, stride = moves.shape
+    legal = np.zeros(n, dtype=np.int8)
+    end_ply = np.zeros(n, dtype=np.int32)
+    winner = np.zeros(n, dtype=np.int8)
+    lib().go_board_replay_games(moves.ctypes.data, lens.ctypes.data, stride, n, legal.ctypes.data, end_ply.ctypes.data, winner.ctypes.data)
+    return legal.astype(bool), end_ply, winner
 
 
 def replay_batch(moves, lens):

@@ -123,3 +123,23 @@ class BotDriver:
             raise RuntimeError("bot failed: " + out.stderr[-2000:])
         reply = json.loads(out.stdout.strip().splitlines()[-1])["response"]
         return core.Position(int(reply["x"]), int(reply["y"]))
+
+
+def encoded_states_of(moves):
+    """The six feature planes the reference hands the network for the position after `moves` (a list of cell ids, black first), restated
+    here from core/py_ext/src/game_ext.hpp:87-104 with nothing of this repo's code in between: [stones of the player to move, stones of
+    the opponent, empty cells, one-hot last move, one-hot move before last, all ones iff black is to move], uint8[6, 15, 15], a plane
+    indexed [y][x] with cell id = 15 y + x.  (For positions of a game that is still running: the player to move alternates from black.)"""
+    planes = np.zeros((6, 15, 15), dtype=np.uint8)
+    black_to_move = len(moves) % 2 == 0
+    stones = {True: np.zeros(225, dtype=np.uint8), False: np.zeros(225, dtype=np.uint8)}     # keyed by "is black"
+    for i, mv in enumerate(moves):
+        stones[i % 2 == 0][int(mv)] = 1
+    planes[0] = stones[black_to_move].reshape(15, 15)
+    planes[1] = stones[not black_to_move].reshape(15, 15)
+    planes[2] = (1 - stones[True] - stones[False]).reshape(15, 15)
+    for back in (0, 1):
+        if len(moves) > back:
+            planes[3 + back].reshape(-1)[int(moves[len(moves) - 1 - back])] = 1
+    planes[5][:] = 1 if black_to_move else 0
+    return planes

@@ -74,6 +74,33 @@ def test_config3_4096_games_800_playouts(oracle):
     tree.close()
 
 
+def test_config4_32768_games_through_the_self_play_loop(oracle):
+    """BASELINE configs[3] at its full game count, in the suite (only bench.py ran this size): 32 768 games through
+    selfplay.play_games (device-resident continuous batching, two search handles), at a small playout budget so that it takes seconds.
+    Size-independent properties on EVERY game: the record replays move by move on the oracle's board (Board::applyMove with its victory
+    check) -- every move legal, the game over exactly at its recorded length, the recorded winner -- and every searched ply's root visit
+    counts add up to playouts - 1 (the first playout of a fresh tree expands the root, every other one passes through a child)."""
+    import torch
+    from gomokuai_amd import selfplay
+    n, P = 32768, 24
+    rec = selfplay.play_games(n, P, first_game_id=0)
+    assert not rec.overflow and len(rec) == n
+    lens = rec.lens.cpu().numpy()
+    legal, end_ply, winner = oracle.replay_games(rec.moves.cpu().numpy(), lens)
+    assert legal.all() and (end_ply == lens).all() and (winner == rec.winner.cpu().numpy()).all()
+    assert lens.min() >= 9 and lens.max() <= 225
+    sums = rec.visits.view(n, 225, 225).to(torch.int32).sum(2)                      # [game][ply]
+    searched = torch.arange(225, device=sums.device)[None, :] < rec.lens[:, None]
+    assert bool((sums[searched] == P - 1).all()) and bool((sums[~searched] == 0).all())
+    # the move played is the first most-visited child of its search (MCTS::stepForward: std::max_element)
+    best = rec.visits.view(n, 225, 225).to(torch.int32).argmax(2)
+    assert bool((best[searched] == rec.moves.to(torch.int64)[searched]).all())
+    # and the games do not depend on how they were batched: a strided sample played alone gives the same records
+    for g in (0, 12345, 32767):
+        one = selfplay.play_games(1, P, first_game_id=g, slots=None).cpu()
+        assert int(one.lens[0]) == int(lens[g]) and (one.moves[0, :lens[g]] == rec.moves[g, :lens[g]].cpu()).all()
+
+
 def test_k3_96_games_800_playouts(oracle):
     n, P = 96, 800
     moves, lens, _ = G.synth_boards(n, 0, first_board=31337)

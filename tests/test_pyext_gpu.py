@@ -32,6 +32,32 @@ def test_eval_state_matches_oracle(oracle):
     assert m.root.position.id == int(np.argmax(ovisits))
 
 
+def test_config1_one_game_1000_playouts(oracle):
+    """BASELINE.json configs[0] as it is stated: a single 15x15 game from the empty board, pure-rollout MCTS of 1 000 playouts per move
+    (agents/mcts.py: RandomMCTSAgent -> MCTS(c_iterations=1000, RandomPolicy(c_puct=5, c_rollouts=5))), through CorePyExt: root visit counts,
+    the bits of Q and the tree size of every search equal the oracle's MCTS.cpp restatement on the same seeds, the subtree kept between
+    moves as MCTS::stepForward does and the root noise of MCTS.cpp:182 in (both sides draw it from the same counter-based stream)."""
+    O = oracle
+    core.set_seed(20241004)
+    m = core.MCTS(c_iterations=1000, policy=core.RandomPolicy(5.0, 5))
+    om = O.MCTS(1000, 5.0, 5, 20241004, 0)
+    om.set_noise(0.05, 0.25)                                        # Default::AddNoise's defaults (MonteCarlo.hpp:97), mixed in before every search (MCTS.cpp:182)
+    b, ob = core.Board(), O.new_board()
+    for ply in range(4):
+        q, pi = m.eval_state(b)
+        om.sync_with_board(ob)
+        oq, opi, ovisits = om.eval_state(ob)
+        assert np.float32(q).tobytes() == np.float32(oq).tobytes(), ply
+        assert [c.node_visits for c in m.root.children] == [int(v) for i, v in enumerate(ovisits) if ob.states[1][i]], ply
+        assert m.size == om.size and m.iterations == 1000, ply
+        assert np.abs(pi - opi).max() <= 1e-6
+        m.step_forward()
+        mv = om.step_forward()
+        assert m.root.position.id == mv, ply
+        b.apply_move(core.Position(mv))
+        O.lib().go_board_apply(C.byref(ob), mv, 1)
+
+
 def test_self_play_game_and_training_tuples():
     core.set_seed(7)
     agent = helpers.random_searcher(5.0, 5, c_iterations=60)

@@ -147,6 +147,35 @@ def test_device_tuples_match_the_reference_loop():
     assert np.abs(pi.sum(1) - 1.0).max() < 1e-3
 
 
+def test_device_planes_match_an_independent_restatement(oracle):
+    """K4's feature planes against tests/helpers.py: encoded_states_of -- a restatement of core/py_ext/src/game_ext.hpp:87-104 that shares no
+    code with the product (the fixture's states came from this repo's own Board.encoded_states) -- and that restatement against
+    the oracle's board (a third statement of the same lines), for the fixture games of the reference's dual_play and for games played here."""
+    import os
+    import torch
+    import helpers
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_tuples.npz"))
+    dev = torch.device("cuda", 0)
+    played = selfplay.play_games(5, 30, seed=99, first_game_id=11).cpu()
+    for moves, lens, winner in ((ref["moves"], ref["lens"], ref["winner"]), (played.moves.numpy(), played.lens.numpy(), played.winner.numpy())):
+        n = int(lens.shape[0])
+        rec = selfplay.GameRecords(torch.from_numpy(np.ascontiguousarray(moves)).to(dev), torch.from_numpy(np.ascontiguousarray(lens)).to(dev),
+                                   torch.from_numpy(np.ascontiguousarray(winner)).to(dev), torch.ones((n, 225, 225), dtype=torch.int16, device=dev), 0)
+        states = rec.to_samples()[0].cpu().numpy()
+        k = 0
+        for g in range(n):
+            ob = oracle.new_board()
+            for ply in range(int(lens[g])):
+                want = helpers.encoded_states_of([int(m) for m in moves[g, :ply]])
+                third = np.zeros((6, 15, 15), dtype=np.uint8)
+                oracle.lib().go_board_encoded_states(C.byref(ob), third.ctypes.data)
+                assert (want == third).all(), (g, ply)
+                assert (states[k] == want).all(), (g, ply)
+                oracle.lib().go_board_apply(C.byref(ob), int(moves[g, ply]), 1)
+                k += 1
+        assert k == states.shape[0]
+
+
 def test_device_samples_match_host_and_augmentation():
     """K4 + K5 on the device == the host construction of the tuples (GameRecords.samples, itself held to the reference loop's
     fixtures in tests/test_selfplay.py), and the eight-fold copies == the order network/data_helper.py:36-55 prescribes (restated
