@@ -264,6 +264,64 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
             "note": "a serial chain per game (one wavefront each): bound by LDS / HBM latency, not by bandwidth; no roofline fraction is claimed"}
 
 
+def bench_supervisor_pipeline(args, G, torch, dev, rank, world, distributed, bare_playouts_per_s):
+    """The supervisor's self-play loop (network/data_helper.py:56-83 with config.py:9-12's "traditional_mcts" on both sides) resident on
+    the device: --sup-games games per GPU through --trad-games slots (continuous batching: gmk_trad_selfplay_run), every move one K6
+    search of --trad-playouts playouts.  Weak scaling (games per GPU fixed); the time is the slowest rank's."""
+    import time
+    from gomokuai_amd import selfplay
+    n, slots, P = args.sup_games, args.trad_games, args.trad_playouts
+    def play():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = selfplay.play_supervisor_games(n, P, first_game_id=rank * n, opening_plies=2, slots=slots, node_capacity=args.trad_nodes)
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+    if distributed:
+        torch.distributed.barrier()
+    rec, seconds = local_stage("supervisor self-play", play, torch, dev, distributed)
+    moves = int(rec.lens.sum()) - 2 * n                          # searched plies (the two opening plies are given)
+    if distributed:
+        t = torch.tensor([seconds], dtype=torch.float64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        seconds = float(t[0])
+        c = torch.tensor([moves, int(rec.overflow)], dtype=torch.int64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
+        moves, overflow = int(c[0]), bool(int(c[1]))
+    else:
+        overflow = bool(rec.overflow)
+    rate = moves * P / seconds
+    # ... and the same loop while every slot is busy (eight games queued per slot, stopped after 40 moves per slot): what the loop itself
+    # -- step kernel, slot hand-over, four bytes to the host per move -- takes from the bare search rate, without the tail of a finite batch
+    # (game lengths run from 9 to 225 moves: at the end of a batch few slots still play, and a search costs a game its full latency)
+    steady_steps = 40
+    def steady():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = selfplay.play_supervisor_games(8 * slots, P, first_game_id=(world + rank) * n, opening_plies=2, slots=slots, node_capacity=args.trad_nodes, max_steps=steady_steps)
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+    rec2, seconds2 = local_stage("supervisor self-play (busy slots)", steady, torch, dev, distributed)
+    moves2 = int(rec2.lens.sum()) - int(torch.clamp(rec2.lens, max=2).sum())
+    if distributed:
+        t = torch.tensor([seconds2], dtype=torch.float64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        seconds2 = float(t[0])
+        c = torch.tensor([moves2], dtype=torch.int64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
+        moves2 = int(c[0])
+    busy_rate = moves2 * P / seconds2
+    return {"metric": "supervisor self-play playouts/s", "value": rate, "unit": "playouts/s", "seconds": seconds, "games": n * world, "searched_moves": moves,
+            "games_per_s": n * world / seconds, "arena_overflow": overflow,
+            "busy_slots": {"value": busy_rate, "unit": "playouts/s", "steps": steady_steps, "searched_moves": moves2, "seconds": seconds2,
+                           "share_of_bare_search_rate": busy_rate / bare_playouts_per_s if bare_playouts_per_s else None,
+                           "note": "includes the setup of %d queued games (records, openings) and the first search's evaluator syncs" % (8 * slots)},
+            "share_of_bare_search_rate": rate / bare_playouts_per_s if bare_playouts_per_s else None,
+            "config": {"workload": "supervisor self-play (K6 searches + device-resident game loop, gmk_trad_selfplay_run), %d games per GPU through %d slots, "
+                                   "%d playouts per move, 2-ply openings, fresh root every move" % (n, slots, P),
+                       "host_traffic_per_move": "4 bytes (slots still playing)"}}
+
+
 def rave_positions(G, np, n, first):
     """K8 workload: the 4-ply random openings of the K3 measurement."""
     moves, lens, _, _ = mcts_openings(G, np, n, first)
@@ -490,6 +548,7 @@ def parse_args(argv=None):
     ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
+    ap.add_argument("--sup-games", type=int, default=3584, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots); 0 = skip")
     ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
     ap.add_argument("--rave-playouts", type=int, default=400)
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which `--gpus N` without a launcher stops its rank processes")
@@ -702,6 +761,15 @@ def main():
     if args.trad_games > 0:
         trad = bench_trad(args, G, torch, dev, rank, world, distributed)
 
+    sup_pipeline = sup_error = None
+    if args.sup_games > 0 and args.trad_games > 0:
+        try:
+            sup_pipeline = bench_supervisor_pipeline(args, G, torch, dev, rank, world, distributed, trad["value"] if trad else None)
+        except Exception as exc:                                  # noqa: BLE001
+            sup_error = "%s: %s" % (type(exc).__name__, exc)
+        if not all_ranks_ok(sup_error is None, torch, dev, distributed) and sup_error is None:
+            sup_pipeline, sup_error = None, "LegFailed: the leg failed on another rank"
+
     rave = None
     if args.rave_games > 0:
         rave = bench_rave(args, G, torch, dev, rank, world, distributed)
@@ -758,6 +826,8 @@ def main():
             out["incremental"] = incremental
         if trad is not None:
             out["supervisor"] = trad
+        if sup_pipeline is not None or sup_error is not None:
+            out["supervisor_pipeline"] = sup_pipeline if sup_pipeline is not None else {"error": sup_error}
         if rave is not None:
             out["poolrave"] = rave
         if az is not None:

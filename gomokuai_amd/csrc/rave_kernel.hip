@@ -66,8 +66,9 @@ void rave_playouts_kernel(RaveParams prm) {
     __shared__ uint2 s_cells[kWaves][30];                       // per game and playout: the rollout's cell draws, eight plies per entry
     __shared__ int s_ply[kWaves], s_winner[kWaves];             // per game and playout: stones at the leaf (-1: no rollout), the rollout's winner
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool exists = blockIdx.x * kWaves + wave < prm.n_games;
-    const int game = exists ? blockIdx.x * kWaves + wave : prm.n_games - 1;     // a surplus wave shadows the last game read-only and only keeps the barriers
+    const bool in_range = blockIdx.x * kWaves + wave < prm.n_games;
+    const int game = in_range ? blockIdx.x * kWaves + wave : prm.n_games - 1;   // a surplus wave shadows the last game read-only and only keeps the barriers
+    const bool exists = in_range && !(prm.hdr[game].status & gmk::tree::kStatusIdleSlot);     // ... and so does a slot whose games have run out (continuous batching)
 
     uint32_t* lines = s_mem[wave];
     uint32_t* root_lines = lines + kLinePad;

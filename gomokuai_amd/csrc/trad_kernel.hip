@@ -22,6 +22,7 @@
 #include <random>
 #include <vector>
 
+#include "board_device.h"
 #include "evalstate_device.h"
 #include "philox.h"
 #include "root_noise.h"
@@ -202,6 +203,7 @@ void trad_playouts_kernel(TradParams prm) {
     }
     __syncthreads();                                            // tables staged; the games of a block never wait for each other again
     if (game >= prm.n_games) return;
+    if (prm.hdr[game].status & kStatusIdleSlot) return;         // continuous batching: a slot whose games have run out (trad_advance_kernel)
 
     Game g;
     g.c = Ctx{base, base + kStateWords, reinterpret_cast<const char*>(lds), reinterpret_cast<const uint4*>(lds + prm.trans_words), lane};
@@ -521,6 +523,55 @@ void trad_playouts_kernel(TradParams prm) {
 // (children consecutive, the root at 0).  A copied node carries its OLD child range and OLD first-child record until the
 // scan reaches it, copies its children and rewrites both.  One wavefront per game.
 
+// The subtree of node src_root of arena a becomes the tree of arena b, level by level (see above); one wavefront.
+__device__ void copy_subtree(const TradArena& a, const TradArena& b, size_t base, uint32_t src_root, int lane, TradHeader& hdr) {
+    if (lane == 0) {
+        b.stat[base] = a.stat[base + src_root];
+        b.info[base] = make_uint2(kNoParent | (a.info[base + src_root].x & 0xFF000000u), a.info[base + src_root].y);
+        b.link[base] = a.link[base + src_root];
+        b.front[base] = a.front[base + src_root];
+        b.ord[base] = 0;
+        if (a.amaf) b.amaf[base] = a.amaf[base + src_root];
+    }
+    __syncthreads();
+    uint32_t next = 1;
+    for (uint32_t i0 = 0, chunk = 0; i0 < next; i0 += chunk) {
+        chunk = min(64u, next - i0);                            // nodes appended while this chunk is handled come after it
+        const uint32_t old_link = static_cast<uint32_t>(lane) < chunk ? b.link[base + i0 + lane] : 0u;
+        unsigned long long todo = __ballot((old_link >> 24) != 0u);
+        while (todo) {
+            const int j = __ffsll(static_cast<long long>(todo)) - 1;
+            todo &= todo - 1ull;
+            const uint32_t ol = __shfl(old_link, j), of = ol & 0xFFFFFFu, nk = ol >> 24, node = i0 + static_cast<uint32_t>(j);
+            for (uint32_t k = lane; k < nk; k += 64) {
+                const uint2 inf = a.info[base + of + k];
+                b.stat[base + next + k] = a.stat[base + of + k];
+                b.info[base + next + k] = make_uint2(node | (inf.x & 0xFF000000u), inf.y);
+                b.link[base + next + k] = a.link[base + of + k];
+                b.front[base + next + k] = a.front[base + of + k];
+                b.ord[base + next + k] = a.ord[base + of + k];
+                if (a.amaf) b.amaf[base + next + k] = a.amaf[base + of + k];
+            }
+            if (lane == 0) {
+                const uint32_t new_link = next | (nk << 24);
+                b.link[base + node] = new_link;
+                const uint2 fr = b.front[base + node];              // still the OLD id of the first child in the current order
+                b.front[base + node] = make_uint2((next + ((fr.x & 0xFFFFFFu) - of)) | (fr.x & 0xFF000000u), fr.y);
+                if (node != 0u) {                                   // am I my parent's first child?  then its record of me carries my child range
+                    const uint32_t p = b.info[base + node].x & 0xFFFFFFu;
+                    const uint2 pf = b.front[base + p];
+                    if ((pf.x & 0xFFFFFFu) == node) b.front[base + p] = make_uint2(pf.x, new_link);
+                }
+            }
+            next += nk;
+            __syncthreads();
+        }
+        __syncthreads();                                        // children written above are scanned below
+    }
+    if (lane == 0) hdr.n_nodes = next;
+}
+
+
 __global__ __launch_bounds__(64)
 void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n_games, const int16_t* forced, uint8_t* moves, int32_t* lens) {
     const int game = blockIdx.x, lane = threadIdx.x;
@@ -580,50 +631,114 @@ void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n
         }
         return;
     }
-    if (lane == 0) {
-        b.stat[base] = a.stat[base + src_root];
-        b.info[base] = make_uint2(kNoParent | (a.info[base + src_root].x & 0xFF000000u), a.info[base + src_root].y);
-        b.link[base] = a.link[base + src_root];
-        b.front[base] = a.front[base + src_root];
-        b.ord[base] = 0;
-        if (a.amaf) b.amaf[base] = a.amaf[base + src_root];
+    copy_subtree(a, b, base, src_root, lane, hdr);
+}
+
+// The step of the device-resident self-play loop (gmk_trad_selfplay_run): what play_supervisor_games does on the host after every search --
+// MCTS::stepForward()'s choice (MCTS.cpp:129-134), the root visit counts into the game's record, Board::applyMove with its victory check
+// (Game.cpp:37-49, 88-136) -- and the hand-over of a finished game's slot (tree arena, evaluator, wavefront) to the next unstarted game
+// (network/data_helper.py:56-83 plays its games one after the other per worker; here a slot does).  One wavefront per slot.
+__global__ __launch_bounds__(64)
+void trad_advance_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n_slots, uint8_t* moves, int32_t* lens, TradSelfPlay sp, int reuse) {
+    __shared__ uint32_t s_rows[16];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= n_slots) return;
+    const int game = sp.slot_game[slot];
+    if (game < 0) return;                                       // idle slot
+    TradHeader& hdr = hdrs[slot];
+    const size_t base = static_cast<size_t>(slot) * cap;
+    uint8_t* mv = moves + static_cast<size_t>(slot) * 225;
+    const int len = lens[slot];
+    if (lane == 0 && (hdr.status & 1u)) atomicOr(sp.overflow, 1);
+    // the child to keep: the most visited one, first in the current order (as trad_step_kernel / trad_root_stats_kernel)
+    const bool searched = hdr.fresh != 1u;                      // (a position that was never searched has no root node yet)
+    const uint32_t lk = searched ? a.link[base] : 0u, first = lk & 0xFFFFFFu, n = lk >> 24;
+    uint32_t best_visits = 0, best_ord = 0xFFFFFFFFu, best_id = 0;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t id = first + i, o = a.ord[base + id], v = a.stat[base + id].x + 1u;
+        if (v > best_visits || (v == best_visits && o < best_ord)) { best_visits = v; best_ord = o; best_id = id; }
     }
-    __syncthreads();
-    uint32_t next = 1;
-    for (uint32_t i0 = 0, chunk = 0; i0 < next; i0 += chunk) {
-        chunk = min(64u, next - i0);                            // nodes appended while this chunk is handled come after it
-        const uint32_t old_link = static_cast<uint32_t>(lane) < chunk ? b.link[base + i0 + lane] : 0u;
-        unsigned long long todo = __ballot((old_link >> 24) != 0u);
-        while (todo) {
-            const int j = __ffsll(static_cast<long long>(todo)) - 1;
-            todo &= todo - 1ull;
-            const uint32_t ol = __shfl(old_link, j), of = ol & 0xFFFFFFu, nk = ol >> 24, node = i0 + static_cast<uint32_t>(j);
-            for (uint32_t k = lane; k < nk; k += 64) {
-                const uint2 inf = a.info[base + of + k];
-                b.stat[base + next + k] = a.stat[base + of + k];
-                b.info[base + next + k] = make_uint2(node | (inf.x & 0xFF000000u), inf.y);
-                b.link[base + next + k] = a.link[base + of + k];
-                b.front[base + next + k] = a.front[base + of + k];
-                b.ord[base + next + k] = a.ord[base + of + k];
-                if (a.amaf) b.amaf[base + next + k] = a.amaf[base + of + k];
-            }
-            if (lane == 0) {
-                const uint32_t new_link = next | (nk << 24);
-                b.link[base + node] = new_link;
-                const uint2 fr = b.front[base + node];              // still the OLD id of the first child in the current order
-                b.front[base + node] = make_uint2((next + ((fr.x & 0xFFFFFFu) - of)) | (fr.x & 0xFF000000u), fr.y);
-                if (node != 0u) {                                   // am I my parent's first child?  then its record of me carries my child range
-                    const uint32_t p = b.info[base + node].x & 0xFFFFFFu;
-                    const uint2 pf = b.front[base + p];
-                    if ((pf.x & 0xFFFFFFu) == node) b.front[base + p] = make_uint2(pf.x, new_link);
-                }
-            }
-            next += nk;
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        const uint32_t ov = __shfl_down(best_visits, sft), oo = __shfl_down(best_ord, sft), oi = __shfl_down(best_id, sft);
+        if (ov > best_visits || (ov == best_visits && ov != 0u && oo < best_ord)) { best_visits = ov; best_ord = oo; best_id = oi; }
+    }
+    best_visits = __shfl(best_visits, 0);
+    best_id = __shfl(best_id, 0);
+    bool over = best_visits == 0u || len >= 225;                // no child: nothing the policy wants to play: the game ends where it stands
+    int winner = 0;
+    if (!over) {
+        const uint32_t cell = a.info[base + best_id].x >> 24;
+        if (sp.rec_visits) {                                    // the root's visit counts by cell, the searched ply's row of the game's record
+            uint16_t* rv = sp.rec_visits + (static_cast<size_t>(game) * 225 + static_cast<size_t>(len)) * 225;
+            for (int i = lane; i < 225; i += 64) rv[i] = 0;
             __syncthreads();
+            for (uint32_t i = lane; i < n; i += 64) rv[a.info[base + first + i].x >> 24] = static_cast<uint16_t>(min(a.stat[base + first + i].x, 65535u));
         }
-        __syncthreads();                                        // children written above are scanned below
+        // the board after the move (move i is black's when i is even), five or more through it wins, a full board is a tie
+        if (lane < 16) s_rows[lane] = 0u;
+        __syncthreads();
+        for (int i = lane; i < len; i += 64) atomicOr(&s_rows[mv[i] / 15u], 1u << (mv[i] % 15u + ((i & 1) ? 16u : 0u)));
+        const int shift = (len & 1) ? 16 : 0;
+        if (lane == 0) atomicOr(&s_rows[cell / 15u], 1u << (cell % 15u + shift));
+        __syncthreads();
+        const bool five = gmk::five_through<1>(s_rows, static_cast<int>(cell % 15u), static_cast<int>(cell / 15u), shift);
+        if (lane == 0) {
+            mv[len] = static_cast<uint8_t>(cell);
+            lens[slot] = len + 1;
+            sp.rec_moves[static_cast<size_t>(game) * 225 + len] = static_cast<uint8_t>(cell);
+            sp.rec_lens[game] = len + 1;
+        }
+        over = five || len + 1 == 225;
+        winner = five ? (shift ? -1 : 1) : 0;
+        if (!over) {
+            if (lane == 0) {
+                atomicAdd(sp.unfinished, 1);
+                if (!reuse) { hdr.fresh = 1; hdr.playouts_done = 0; }          // a new root at the next search (gmk_trad_set_positions)
+                else { hdr.fresh = 2; hdr.root_black ^= 1u; }                  // the subtree is kept (gmk_trad_step)
+            }
+            if (reuse) copy_subtree(a, b, base, best_id, lane, hdr);
+            return;
+        }
     }
-    if (lane == 0) hdr.n_nodes = next;
+    // the game is over: its winner; the slot waits for trad_refill_kernel
+    if (lane == 0) {
+        sp.rec_winner[game] = static_cast<int8_t>(winner);
+        sp.slot_game[slot] = -2;
+    }
+}
+
+// Finished games hand their slots to the next unstarted games, in ascending slot order (the order play_supervisor_games' host loop uses:
+// which slot a game lands in decides which evaluator history it inherits, so the order is part of the result); the opening of the new
+// game is the slot's new position.  Slots left without a game go idle.  One wavefront for all slots.
+__global__ __launch_bounds__(64)
+void trad_refill_kernel(TradHeader* hdrs, int n_slots, uint8_t* moves, int32_t* lens, TradSelfPlay sp) {
+    const int lane = threadIdx.x;
+    int next0 = *sp.next_game;
+    for (int s0 = 0; s0 < n_slots; s0 += 64) {
+        const int slot = s0 + lane;
+        const bool finished = slot < n_slots && sp.slot_game[slot] == -2;
+        const unsigned long long mask = __ballot(finished);
+        if (finished) {
+            const int next = next0 + static_cast<int>(__popcll(mask & ((1ull << lane) - 1ull)));
+            TradHeader& hdr = hdrs[slot];
+            if (next < sp.n_total) {
+                uint8_t* mv = moves + static_cast<size_t>(slot) * 225;
+                const int olen = sp.open_lens ? sp.open_lens[next] : 0;
+                for (int i = 0; i < olen; ++i) mv[i] = sp.open_moves[static_cast<size_t>(next) * sp.open_stride + i];     // (the game's record holds its opening already)
+                lens[slot] = olen;
+                sp.slot_game[slot] = next;
+                sp.game_ids[slot] = static_cast<uint32_t>(next);
+                hdr.fresh = 1; hdr.playouts_done = 0;
+                hdr.status &= ~(1u | 8u);
+                atomicAdd(sp.unfinished, 1);
+            } else {
+                sp.slot_game[slot] = -1;
+                hdr.status |= kStatusIdleSlot;
+            }
+        }
+        next0 = min(sp.n_total, next0 + static_cast<int>(__popcll(mask)));
+    }
+    if (lane == 0) *sp.next_game = next0;
 }
 
 // Default::AddNoise (MonteCarlo.hpp:97-108): the root children's priors, by cell, as the host computed them
@@ -736,7 +851,7 @@ extern "C" int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves, const
     if (all) {
         GMK_HIP_CHECK(hipMemcpy(t->d_moves, h_moves, n * 225, hipMemcpyHostToDevice));
         GMK_HIP_CHECK(hipMemcpy(t->d_lens, h_lens, n * 4, hipMemcpyHostToDevice));
-        for (TradHeader& h : hdr) { h.fresh = 1; h.playouts_done = 0; }
+        for (TradHeader& h : hdr) { h.fresh = 1; h.playouts_done = 0; h.status &= ~kStatusIdleSlot; }
     } else {                                                    // a negative length: that game keeps its position and its tree
         std::vector<uint8_t> moves(n * 225);
         std::vector<int32_t> lens(n);
@@ -746,7 +861,7 @@ extern "C" int gmk_trad_set_positions(gmk_trad* t, const uint8_t* h_moves, const
             if (h_lens[g] >= 0) {
                 std::memcpy(&moves[g * 225], h_moves + g * 225, 225);
                 lens[g] = h_lens[g];
-                hdr[g].fresh = 1; hdr[g].playouts_done = 0;
+                hdr[g].fresh = 1; hdr[g].playouts_done = 0; hdr[g].status &= ~kStatusIdleSlot;
             }
         GMK_HIP_CHECK(hipMemcpy(t->d_moves, moves.data(), n * 225, hipMemcpyHostToDevice));
         GMK_HIP_CHECK(hipMemcpy(t->d_lens, lens.data(), n * 4, hipMemcpyHostToDevice));
@@ -902,4 +1017,124 @@ extern "C" int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t*
         if (h_record) std::memcpy(h_record + static_cast<size_t>(g) * 228, s + oRecord, 228);
     }
     return GMK_OK;
+}
+
+// The self-play loop of network/data_helper.py:56-83 for the pattern-guided searchers, resident on the device: n_total games through the
+// handle's slots, every move = Default::AddNoise (if asked for) + one search of `playouts` playouts for every slot that has a game +
+// trad_advance_kernel; the host sees four bytes per move (slots that still play) and, with root noise, the slots' game numbers.
+extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uint32_t first_game_id, int playouts, double c_puct, uint64_t seed,
+                                     int reuse_subtree, float noise_alpha, float noise_epsilon,
+                                     const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens,
+                                     uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int max_steps, int32_t* h_overflow, int32_t* h_steps, void* stream) {
+    if (!t || n_total <= 0 || playouts < 0 || max_steps < 0 || !d_moves || !d_lens || !d_winner || (h_open_moves && (!h_open_lens || open_stride <= 0))) {
+        gmk::set_error("gmk_trad_selfplay_run: bad arguments");
+        return GMK_ERR_ARG;
+    }
+    const int n_slots = t->n_games;
+    const size_t ns = static_cast<size_t>(n_slots), nt = static_cast<size_t>(n_total);
+    std::vector<int32_t> open_lens(nt, 0);
+    if (h_open_moves)
+        for (size_t g = 0; g < nt; ++g) {
+            if (h_open_lens[g] < 0 || h_open_lens[g] > 224 || h_open_lens[g] > open_stride) { gmk::set_error("gmk_trad_selfplay_run: opening of game %zu has %d moves", g, h_open_lens[g]); return GMK_ERR_ARG; }
+            open_lens[g] = h_open_lens[g];
+            for (int i = 0; i < open_lens[g]; ++i)
+                if (h_open_moves[g * open_stride + i] >= 225) { gmk::set_error("gmk_trad_selfplay_run: opening of game %zu holds cell %d", g, h_open_moves[g * open_stride + i]); return GMK_ERR_ARG; }
+        }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    // the first min(n_slots, n_total) games start in the slots, from their openings; the rest wait for a slot
+    const int started = std::min(n_slots, n_total);
+    std::vector<uint8_t> slot_moves(ns * 225, 0), first_moves(nt * 225, 0);
+    std::vector<int32_t> slot_lens(ns, 0), state(ns + 3, -1);
+    std::vector<uint32_t> ids(ns, 0);
+    for (size_t g = 0; g < nt; ++g)
+        for (int i = 0; i < open_lens[g]; ++i) {
+            first_moves[g * 225 + i] = h_open_moves[g * open_stride + i];
+            if (g < ns) slot_moves[g * 225 + i] = h_open_moves[g * open_stride + i];
+        }
+    for (int g = 0; g < started; ++g) { slot_lens[static_cast<size_t>(g)] = open_lens[static_cast<size_t>(g)]; state[static_cast<size_t>(g)] = g; ids[static_cast<size_t>(g)] = static_cast<uint32_t>(g); }
+    state[ns] = started;                                        // next_game
+    state[ns + 1] = 0;                                          // unfinished
+    state[ns + 2] = 0;                                          // overflow
+    int rc = gmk_trad_set_game_ids(t, ids.data());
+    if (rc == GMK_OK) rc = gmk_trad_set_positions(t, slot_moves.data(), slot_lens.data());
+    if (rc != GMK_OK) return rc;
+    if (n_slots > n_total) {                                    // slots without a game: idle from the start
+        std::vector<TradHeader> hdr(ns);
+        GMK_HIP_CHECK(hipMemcpy(hdr.data(), t->d_hdr, ns * sizeof(TradHeader), hipMemcpyDeviceToHost));
+        for (size_t g = nt; g < ns; ++g) hdr[g].status |= kStatusIdleSlot;
+        GMK_HIP_CHECK(hipMemcpy(t->d_hdr, hdr.data(), ns * sizeof(TradHeader), hipMemcpyHostToDevice));
+    }
+    int32_t* d_state = nullptr;
+    uint8_t* d_open_moves = nullptr;
+    int32_t* d_open_lens = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_state); (void)hipFree(d_open_moves); (void)hipFree(d_open_lens); };
+#define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("gmk_trad_selfplay_run: %s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
+    GMK_TRY(hipMalloc(&d_state, state.size() * 4));
+    GMK_TRY(hipMemcpy(d_state, state.data(), state.size() * 4, hipMemcpyHostToDevice));
+    GMK_TRY(hipMalloc(&d_open_lens, nt * 4));
+    GMK_TRY(hipMemcpy(d_open_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
+    if (h_open_moves) {
+        GMK_TRY(hipMalloc(&d_open_moves, nt * static_cast<size_t>(open_stride)));
+        GMK_TRY(hipMemcpy(d_open_moves, h_open_moves, nt * static_cast<size_t>(open_stride), hipMemcpyHostToDevice));
+    }
+    GMK_TRY(hipMemcpy(d_moves, first_moves.data(), nt * 225, hipMemcpyHostToDevice));
+    GMK_TRY(hipMemcpy(d_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
+    GMK_TRY(hipMemset(d_winner, 0, nt));
+    if (reuse_subtree && !t->second_arena) {                     // the arenas flip at every step (as gmk_trad_step)
+        const size_t nodes = ns * static_cast<size_t>(t->cap);
+        const bool ok = hipMalloc(&t->d_stat2, nodes * 8) == hipSuccess && hipMalloc(&t->d_info2, nodes * 8) == hipSuccess &&
+                        hipMalloc(&t->d_link2, nodes * 4) == hipSuccess && hipMalloc(&t->d_front2, nodes * 8) == hipSuccess &&
+                        hipMalloc(&t->d_ord2, nodes) == hipSuccess && hipMalloc(&t->d_forced, ns * 2) == hipSuccess;
+        if (!ok) {
+            (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_link2); (void)hipFree(t->d_front2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_forced);
+            t->d_stat2 = t->d_info2 = t->d_front2 = nullptr; t->d_link2 = nullptr; t->d_ord2 = nullptr; t->d_forced = nullptr;
+            (void)hipGetLastError();
+            gmk::set_error("gmk_trad_selfplay_run: hipMalloc of the second arena (%zu nodes) failed", nodes);
+            cleanup();
+            return GMK_ERR_HIP;
+        }
+        t->second_arena = true;
+    }
+    TradSelfPlay sp;
+    sp.slot_game = d_state; sp.next_game = d_state + ns; sp.unfinished = d_state + ns + 1; sp.overflow = d_state + ns + 2;
+    sp.n_total = n_total; sp.open_moves = d_open_moves; sp.open_lens = d_open_lens; sp.open_stride = open_stride;
+    sp.game_ids = t->d_game_ids;
+    sp.rec_moves = d_moves; sp.rec_lens = d_lens; sp.rec_visits = d_visits; sp.rec_winner = d_winner;
+    int32_t steps = 0;
+    std::vector<int32_t> slot_game(ns);
+    const long long step_limit = max_steps > 0 ? max_steps : 226ll * (n_total / n_slots + 2);
+    for (long long step = 0; step < step_limit; ++step) {
+        if (noise_alpha > 0.0f) {                               // Default::AddNoise at the start of every search (MCTS.cpp:182), keyed by the GAME a slot plays
+            GMK_TRY(hipMemcpy(slot_game.data(), d_state, ns * 4, hipMemcpyDeviceToHost));
+            for (size_t g = 0; g < ns; ++g) t->game_ids[g] = slot_game[g] >= 0 ? static_cast<uint32_t>(slot_game[g]) : 0u;
+            rc = gmk_trad_add_root_noise(t, noise_alpha, noise_epsilon, seed, first_game_id);
+            if (rc != GMK_OK) break;
+        }
+        rc = poolrave ? gmk_trad_run_poolrave(t, playouts, c_puct, seed, first_game_id, s) : gmk_trad_run(t, playouts, c_puct, s);
+        if (rc != GMK_OK) break;
+        if (reuse_subtree && t->d_amaf && !t->d_amaf2) GMK_TRY(hipMalloc(&t->d_amaf2, ns * static_cast<size_t>(t->cap) * 8));
+        GMK_TRY(hipMemsetAsync(sp.unfinished, 0, 4, s));
+        hipLaunchKernelGGL(trad_advance_kernel, dim3(n_slots), dim3(64), 0, s, t->arena(), t->arena2(), t->d_hdr, t->cap, n_slots, t->d_moves, t->d_lens, sp, reuse_subtree ? 1 : 0);
+        hipLaunchKernelGGL(trad_refill_kernel, dim3(1), dim3(64), 0, s, t->d_hdr, n_slots, t->d_moves, t->d_lens, sp);
+        GMK_TRY(hipGetLastError());
+        ++steps;
+        int32_t unfinished = 0;
+        GMK_TRY(hipMemcpyAsync(&unfinished, sp.unfinished, 4, hipMemcpyDeviceToHost, s));
+        GMK_TRY(hipStreamSynchronize(s));
+        if (reuse_subtree) {
+            std::swap(t->d_stat, t->d_stat2); std::swap(t->d_info, t->d_info2); std::swap(t->d_link, t->d_link2);
+            std::swap(t->d_front, t->d_front2); std::swap(t->d_ord, t->d_ord2); std::swap(t->d_amaf, t->d_amaf2);
+        }
+        if (unfinished == 0) break;
+    }
+    int32_t overflow = 0;
+    if (rc == GMK_OK) GMK_TRY(hipMemcpy(&overflow, sp.overflow, 4, hipMemcpyDeviceToHost));
+#undef GMK_TRY
+    cleanup();
+    if (h_overflow) *h_overflow = overflow;
+    if (h_steps) *h_steps = steps;
+    // the handle is left with idle slots: position it again (gmk_trad_set_positions) before any other use
+    t->positioned = false;
+    return rc;
 }

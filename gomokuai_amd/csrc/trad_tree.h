@@ -14,8 +14,10 @@ namespace tree {
 
 constexpr uint32_t kNoParent = 0xFFFFFFu;
 
+constexpr uint32_t kStatusIdleSlot = 16u;        // continuous batching (gmk_trad_selfplay_run): the slot's games have run out, the searches skip it
+
 struct TradHeader {                              // 64 B per game in HBM
-    uint32_t n_nodes, init_acts, status, fresh;  // status: bit 0 node capacity reached, bit 1 evaluator error, bit 2 board-only revert met, bit 3 illegal step
+    uint32_t n_nodes, init_acts, status, fresh;  // status: bit 0 node capacity reached, bit 1 evaluator error, bit 2 board-only revert met, bit 3 illegal step, bit 4 idle slot
                                                  // fresh: 1 = new root + evaluator sync, 2 = the tree was re-rooted (kept): evaluator sync only
     uint32_t playouts_done, root_black, pad0, pad1;
     unsigned long long evaluator_updates, pad2;
@@ -30,6 +32,24 @@ struct TradArena {
     uint2* front;                                // [n_games][cap] the child that is first in the CURRENT order: {id | cell << 24, its link word}
     uint8_t* ord;                                // [n_games][cap] the node's position in its parent's current child order
     uint2* amaf;                                 // [n_games][cap] {amaf_visits, amaf_value bits} (AMAFNode, MonteCarlo.hpp:113-122); null for K6
+};
+
+// What the device-resident self-play loop (gmk_trad_selfplay_run) hands its step kernel: the game a slot plays and the hand-over of a
+// finished game's slot to the next unstarted game, the openings, and the records by GAME (not by slot).
+struct TradSelfPlay {
+    int32_t* slot_game;                          // [n_slots] the game (0 .. n_total-1) a slot plays, -1: none
+    int32_t* next_game;                          // the next unstarted game
+    int n_total;
+    const uint8_t* open_moves;                   // [n_total][open_stride], may be null
+    const int32_t* open_lens;                    // [n_total]
+    int open_stride;
+    uint32_t* game_ids;                          // [n_slots] = slot_game as the searches and the root noise key their streams
+    uint8_t* rec_moves;                          // [n_total][225]
+    int32_t* rec_lens;                           // [n_total]
+    uint16_t* rec_visits;                        // [n_total][225][225] or null: root visit counts of every searched ply
+    int8_t* rec_winner;                          // [n_total]
+    int32_t* unfinished;                         // slots that still have a game after this step
+    int32_t* overflow;                           // set when a search stopped at its node capacity
 };
 
 // ---- wave-wide reductions without LDS round trips ----

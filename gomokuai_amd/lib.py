@@ -38,7 +38,7 @@ EXPORTS = [
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_selfplay_run", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
     "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_root_stats",
-    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
+    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_trad_selfplay_run", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
 ]
 
 
@@ -121,6 +121,8 @@ def load():
     L.gmk_trad_root_stats.argtypes = [vp] * 10
     L.gmk_trad_read_evaluators.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.gmk_trad_run_poolrave.argtypes = [vp, C.c_int, C.c_double, C.c_uint64, C.c_uint32, vp]
+    L.gmk_trad_selfplay_run.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_uint64, C.c_int, C.c_float, C.c_float,
+                                        vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     L.gmk_trad_root_amaf.argtypes = [vp, vp, vp]
     L.gmk_pvnet_create.argtypes = [vp] * 10 + [C.POINTER(vp)]
     L.gmk_pvnet_destroy.argtypes = [vp]
@@ -438,6 +440,29 @@ class TraditionalMCTS:
     def add_root_noise(self, alpha=0.05, epsilon=0.25, seed=DEFAULT_SEED, first_game_id=0):
         _check(load().gmk_trad_add_root_noise(self.h, alpha, epsilon, seed, first_game_id))
 
+    _POOLRAVE = 0
+
+    def selfplay_run(self, n_total, first_game_id, playouts, d_moves, d_visits, d_lens, d_winner, open_moves=None, open_lens=None,
+                     reuse_subtree=False, root_noise=None, seed=DEFAULT_SEED, stream=None, max_steps=0):
+        """gmk_trad_selfplay_run: the handle's games are slots that play n_total whole games between them, the loop resident on the
+        device (search, MCTS::stepForward's move, end-of-game check and slot hand-over are kernels).  open_moves uint8[n_total, stride] /
+        open_lens int32[n_total] (host) or None; the outputs are device pointers (ints), indexed by game.
+        Returns (search launches, whether a search stopped at its node capacity)."""
+        steps, overflow = C.c_int32(), C.c_int32()
+        om = ol = None
+        stride = 0
+        if open_moves is not None:
+            om = np.ascontiguousarray(open_moves, dtype=np.uint8)
+            ol = np.ascontiguousarray(open_lens, dtype=np.int32)
+            assert om.ndim == 2 and om.shape[0] == n_total and ol.shape == (n_total,)
+            stride = om.shape[1]
+        alpha, eps = root_noise if root_noise is not None else (0.0, 0.0)
+        _check(load().gmk_trad_selfplay_run(self.h, self._POOLRAVE, int(n_total), int(first_game_id), int(playouts), self.c_puct, int(seed),
+                                            int(bool(reuse_subtree)), float(alpha), float(eps),
+                                            None if om is None else om.ctypes.data, stride, None if ol is None else ol.ctypes.data,
+                                            d_moves, d_visits, d_lens, d_winner, int(max_steps), C.byref(overflow), C.byref(steps), stream))
+        return steps.value, bool(overflow.value)
+
     def root_stats(self):
         out = {"visits": np.zeros((self.n, N), np.uint32), "values": np.zeros((self.n, N), np.float32), "priors": np.zeros((self.n, N), np.float32),
                "best": np.zeros(self.n, np.int32), "root_visits": np.zeros(self.n, np.uint32), "root_value": np.zeros(self.n, np.float32),
@@ -458,6 +483,8 @@ class TraditionalMCTS:
 class PoolRAVEMCTS(TraditionalMCTS):
     """n_games searches of MCTS(policy=PoolRAVEPolicy(c_puct)) side by side on the GPU (K8): the tree, step, noise and root
     statistics of TraditionalMCTS, playouts with one random rollout each and RAVE::BackPropogate<true>."""
+
+    _POOLRAVE = 1
 
     def __init__(self, n_games, node_capacity=1 << 20, c_puct=2.0, seed=DEFAULT_SEED, first_game_id=0):
         super().__init__(n_games, node_capacity, c_puct)

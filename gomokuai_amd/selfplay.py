@@ -258,8 +258,39 @@ class _HostGames:
         return last
 
 
+def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps=0):
+    """play_supervisor_games with the loop resident on the device (gmk_trad_selfplay_run): the searches, MCTS::stepForward's move, the
+    end-of-game check and the hand-over of a finished game's slot are kernels; the host reads four bytes per move.  Same games, same
+    records as the host-driven loops below (tests/test_selfplay_gpu.py holds them to each other)."""
+    G.init(torch.cuda.current_device() if device is None else device.index)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    open_moves = open_lens = None
+    if opening_plies > 0:
+        m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+        open_moves, open_lens = m, np.minimum(l, opening_plies).astype(np.int32)
+    cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * 226 + 1, (1 << 24) - 1)
+    if policy == "poolrave":
+        tree = G.PoolRAVEMCTS(n_slots, node_capacity=cap, c_puct=c_puct, seed=seed, first_game_id=first_game_id)
+    elif policy == "traditional":
+        tree = G.TraditionalMCTS(n_slots, node_capacity=cap, c_puct=c_puct)
+    else:
+        raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
+    d_moves = torch.zeros((n_games, N), dtype=torch.uint8, device=dev)
+    d_lens = torch.zeros(n_games, dtype=torch.int32, device=dev)
+    d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
+    d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    try:
+        _, overflow = tree.selfplay_run(n_games, first_game_id, playouts, d_moves.data_ptr(), d_visits.data_ptr(), d_lens.data_ptr(), d_winner.data_ptr(),
+                                        open_moves, open_lens, reuse_subtree, root_noise, seed, stream, max_steps)
+    finally:
+        tree.close()
+    return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, overflow)
+
+
 def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional", slots=None):
+                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional", slots=None, device_loop=True, max_steps=0):
     """n_games complete games of the reference's self-play SUPERVISOR against itself (config.py:9-12: "traditional_mcts",
     MCTS(TraditionalPolicy) on both sides), all games side by side on the current GPU: every move = one K6 search of
     `playouts` playouts per unfinished game (the games' evaluators are kept and synchronised like the policy objects of
@@ -271,7 +302,17 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
     slots: at most that many games are in flight; a game that ends hands its slot -- tree arena, evaluator,
     wavefront -- to the next unstarted game, so the GPU stays full instead of waiting for the longest game of the batch (a search
     costs the same time however many of its games are still alive: one wavefront per game, latency bound).
+    device_loop (default): the loop runs on the device (gmk_trad_selfplay_run; whole games only, so a max_moves cap takes the host loop);
+    device_loop=False: the host drives it ply by ply with numpy boards (root_stats down, positions up every ply) -- the same games.
+    max_steps > 0 (device loop only): stop after that many moves per slot, whatever is unfinished (throughput measurements with every slot busy).
     Returns the same GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
+    if policy not in ("traditional", "poolrave"):
+        raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
+    if device_loop and max_moves >= N:
+        return _play_supervisor_on_device(n_games, n_games if slots is None else max(1, min(int(slots), n_games)), playouts, c_puct, seed, first_game_id,
+                                          opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps)
+    if max_steps:
+        raise ValueError("play_supervisor_games: max_steps is a switch of the device-resident loop")
     if slots is not None and slots < n_games:
         return _play_supervisor_slots(n_games, int(slots), playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy,
                                       reuse_subtree, root_noise)

@@ -233,6 +233,21 @@ int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float*
 int gmk_trad_step(gmk_trad* t, const int16_t* h_moves);
 /* Default::AddNoise on every root with children (the reference does this at the start of every search, MCTS.cpp:182) */
 int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id);
+/* The self-play loop of the pattern-guided searchers, resident on the device (replaces the host loop of network/data_helper.py:56-83
+ * around agents/mcts.py:17-21 for config.py:9-12's supervisor): n_total games (global ids first_game_id ..) are played through the
+ * handle's n_games SLOTS with continuous batching -- every move = Default::AddNoise (noise_alpha > 0; MCTS.cpp:182) + one search of
+ * `playouts` playouts (poolrave = 0: TraditionalPolicy as gmk_trad_run, 1: PoolRAVEPolicy as gmk_trad_run_poolrave) + a step kernel
+ * that plays MCTS::stepForward()'s choice, checks the end of the game (Game.cpp:88-136) and hands a finished game's slot to the next
+ * unstarted game (reuse_subtree = 1 keeps the chosen child's subtree as gmk_trad_step does, 0 starts every search from a new root as
+ * gmk_trad_set_positions does).  Records by GAME, on the device: d_moves uint8[n_total][225], d_lens int32[n_total], d_winner
+ * int8[n_total], d_visits uint16[n_total][225][225] (may be NULL).  h_open_moves / h_open_lens: the games' openings, or NULL.
+ * max_steps > 0 ends the loop after that many moves per slot (games still running keep the moves they have, winner 0): what a
+ * throughput measurement with every slot busy needs; 0 = play every game to its end.
+ * *h_overflow != 0: some search stopped at its node capacity.  Afterwards the handle must be positioned again before other use. */
+int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uint32_t first_game_id, int playouts, double c_puct, uint64_t seed,
+                          int reuse_subtree, float noise_alpha, float noise_epsilon,
+                          const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens,
+                          uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int max_steps, int32_t* h_overflow, int32_t* h_steps, void* stream);
 /* the games' evaluator states, laid out as gmk_evalstate_read */
 int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density, uint32_t* h_pattern_dist,
                              uint32_t* h_compound_dist, int32_t* h_meta, uint8_t* h_record);

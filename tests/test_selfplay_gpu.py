@@ -397,3 +397,21 @@ def test_a_move_cap_is_honoured_whatever_the_batching():
     """max_moves truncates the games on every path (the device-resident loop plays whole games only: a capped call must not take it)."""
     rec = selfplay.play_games(10, 40, first_game_id=3, slots=4, handles=1, max_moves=7).cpu()
     assert int(rec.lens.max()) <= 7
+
+
+@pytest.mark.parametrize("policy,c_puct", [("traditional", 5.0), ("poolrave", 2.0)])
+@pytest.mark.parametrize("reuse,noise", [(False, None), (True, None), (True, (0.05, 0.25))])
+def test_device_resident_supervisor_loop_plays_the_host_loops_games(policy, c_puct, reuse, noise):
+    """gmk_trad_selfplay_run (search, MCTS::stepForward's move, end-of-game check and slot hand-over as kernels, the records written by game
+    id on the device) against the host-driven loops it replaces (numpy boards, root_stats down and positions up every ply): the same moves,
+    lengths, winners and per-ply root visit counts, all games at once and through a few slots (continuous batching: a finished game's slot
+    goes to the next unstarted game in slot order, as the host loop does it)."""
+    kw = dict(c_puct=c_puct, policy=policy, opening_plies=2, first_game_id=21, seed=99, reuse_subtree=reuse, root_noise=noise)
+    for slots in (None, 3):
+        host = selfplay.play_supervisor_games(10, 70, slots=slots, device_loop=False, **kw).cpu()
+        dev = selfplay.play_supervisor_games(10, 70, slots=slots, **kw)
+        assert not dev.overflow and not host.overflow
+        dev = dev.cpu()
+        assert (dev.lens == host.lens).all() and (dev.winner == host.winner).all(), (policy, reuse, noise, slots)
+        assert (dev.moves == host.moves).all() and (dev.visits == host.visits).all(), (policy, reuse, noise, slots)
+        assert int(dev.lens.min()) >= 9
