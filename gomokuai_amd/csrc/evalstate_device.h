@@ -193,27 +193,35 @@ __device__ inline void update_patterns(const Ctx& c, int move, int slot, int del
 __device__ inline void queue_compound(const Ctx& c, int cell, int pb /* player is black */, int delta) {
     const uint32_t* pd = c.st + oPdist + pdist_index(cell, 0);
     const int g_own = group2(pb, pb);
-    // locate(): state machine S0,L2,LD3,To33,To43,To44 = 0..5 over the directions; first present of L3, D3, L2 per direction
-    int state = 0, l3 = 0, triple = 0, n_comp = 0;
-    uint32_t comps = 0;                                         // 4 bits per component: dir | (0 L3, 1 D3, 2 L2) << 2
-    const uint32_t f_l3 = pd[5] >> (8 * g_own), f_d3 = pd[4] >> (8 * g_own), f_l2 = pd[3] >> (8 * g_own);
-    for (int d = 0; d < 4; ++d) {
-        // a 2-bit flag field counts 0, 1, 2-or-more as 00, 01, 11 (10 does not occur and counts as nothing, Pattern.cpp:457-462)
-        auto count_of = [](uint32_t f) { return (f & 1u) ? static_cast<int>((f >> 1) & 1u) + 1 : 0; };
-        const int k3 = count_of(f_l3 >> (2 * d)), kd = count_of(f_d3 >> (2 * d)), k2 = count_of(f_l2 >> (2 * d));
-        const int t = k3 ? 0 : kd ? 1 : k2 ? 2 : -1;
-        if (t < 0) continue;
-        const int count = t == 0 ? k3 : t == 1 ? kd : k2, cond = t == 2 ? 1 : 2;
-        if (t == 0) ++l3;
-        for (int r = 0; r < count; ++r) {
-            if (n_comp < 8) { comps |= static_cast<uint32_t>(d | (t << 2)) << (4 * n_comp); ++n_comp; }
-            if (state == 0) state += cond;
-            else if (state <= 2) state += cond + 1;
-            else { triple = 1; state += (state == 5) ? 0 : cond - 1; }
+    // locate() walks the directions in order through the state machine S0, L2, LD3, To33, To43, To44 (Pattern.cpp:440-486); per direction
+    // the component is the first present of LiveThree, DeadThree, LiveTwo, taken once or twice (a 2-bit flag field counts 0, 1, 2-or-more
+    // as 00, 01, 11; 10 does not occur and counts as nothing, Pattern.cpp:457-462).  Its outcome does not depend on the order: with n
+    // components of which s are threes (weight 2, a LiveTwo 1) the state ends at 3 + min(2, s) for n >= 2 -- the first two transitions add
+    // w1 + w2 + 1, every further one w - 1, capped at 5 -- and "triple" is n >= 3.  So: masks over the four 2-bit fields, no loops
+    // (the wavefront pays this code's full length for a handful of lanes).
+    const uint32_t f_l3 = (pd[5] >> (8 * g_own)) & 0xFFu, f_d3 = (pd[4] >> (8 * g_own)) & 0xFFu, f_l2 = (pd[3] >> (8 * g_own)) & 0xFFu;
+    const uint32_t sel3 = f_l3 & 0x55u, seld = f_d3 & 0x55u & ~sel3, sel2 = f_l2 & 0x55u & ~(sel3 | seld);       // the direction's component: bit 2 d
+    const uint32_t strong = sel3 | seld, any_dir = strong | sel2;
+    const uint32_t twice_strong = ((f_l3 >> 1) & sel3) | ((f_d3 >> 1) & seld), twice = twice_strong | ((f_l2 >> 1) & sel2);
+    const int n_comp = __popc(any_dir) + __popc(twice);
+    const int l3 = sel3 != 0u, triple = n_comp >= 3;
+    if (n_comp < 2) { c.st[oMeta + 3] |= 2u; return; }                                 // the reference indexes out of bounds here
+    const int ctype = min(__popc(strong) + __popc(twice_strong), 2);
+    // the components in direction order, one nibble each (dir | (0 L3, 1 D3, 2 L2) << 2), a component taken twice twice in a row
+    uint32_t comps = 0;
+    {
+        int at = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t bit = 1u << (2 * d);
+            const uint32_t code = static_cast<uint32_t>(d) | ((sel3 & bit) ? 0u : (seld & bit) ? 4u : 8u);
+            const uint32_t once = (any_dir >> (2 * d)) & 1u, again = (twice >> (2 * d)) & 1u;
+            comps |= (code * once) << (4 * at);
+            at += static_cast<int>(once);
+            comps |= (code * again) << (4 * at);
+            at += static_cast<int>(again);
         }
     }
-    const int ctype = state - 3;
-    if (ctype < 0 || ctype > 2) { c.st[oMeta + 3] |= 2u; return; }                     // the reference indexes out of bounds here
     const int count0 = __popc((c.st[oCdist + cell * 3 + ctype] >> (8 * g_own)) & 0xFFu);
     const int todo = delta == 1 ? n_comp : min(n_comp, count0);                        // update(-1) stops at "2 * count + delta == -1", i.e. at count 0
     if (todo == 0) return;
