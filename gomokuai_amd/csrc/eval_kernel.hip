@@ -174,7 +174,6 @@ __host__ __device__ constexpr int block_weight(int dy, int dx) {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-struct __attribute__((packed, aligned(4))) Int4Unaligned { int32_t x, y, z, w; };      // a 16-byte store to a 4-byte aligned address
 
 // ---- phase D: one plane kind of one M tile of a group of sixteen boards leaves for HBM ----
 // Here the BOARDS are on the accumulator rows (A = stones, B = weights): lane (n, h) holds cell 32 M + n of sixteen board-colour
@@ -210,45 +209,6 @@ __device__ __forceinline__ void density_tile_pass(const uint32_t (&own_rows)[8],
     }
     // accumulator i = board-colour column 8 (i / 4) + 4 h + (i % 4) at cell 32 M + n; columns 2 b, 2 b + 1 are board b
     const int n_live = n_boards - first_board;      // >= 16 except in the last group
-#ifdef GMK_K1_D16
-    // Sixteen bytes per lane: the four accumulators of a register quad are four planes (two boards x two colours) at ONE cell; the four
-    // lanes of a lane quad hold four consecutive cells.  A 4 x 4 transpose inside the lane quad (two rounds of DPP exchanges, with the
-    // lane one and two away) leaves lane t of a quad with plane t at the quad's four cells: one 16-byte store per register quad,
-    // eight pieces of 128 contiguous bytes per instruction, 57 store instructions per group instead of 225.
-    const int t = n & 3;
-    const bool t0 = (t & 1) != 0, t1 = (t & 2) != 0;
-    auto swap_with = [](int v, bool by_two) -> int {
-        return by_two ? __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true)       // quad_perm [2, 3, 0, 1]
-                      : __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
-    };
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int a[4];
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-            const int b = 4 * q + j / 2;            // + 2 h
-            const uint32_t wd = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(8 * b + 16 * h, static_cast<int>(occ)));
-            const int neg = __builtin_amdgcn_sbfe(static_cast<int>(wd), n, 1);      // occupied cells hold -v - 1 = ~v (Pattern.cpp:253-265)
-            a[j] = acc[4 * q + j] ^ neg;
-            a[j + 1] = acc[4 * q + j + 1] ^ neg;
-        }
-        {   // exchange with the lane one away: (a0, a1) and (a2, a3) become 2 x 2 transposed
-            const int r01 = swap_with(t0 ? a[0] : a[1], false), r23 = swap_with(t0 ? a[2] : a[3], false);
-            if (t0) { a[0] = r01; a[2] = r23; } else { a[1] = r01; a[3] = r23; }
-        }
-        {   // ... and with the lane two away: (a0, a2) and (a1, a3)
-            const int r02 = swap_with(t1 ? a[0] : a[2], true), r13 = swap_with(t1 ? a[1] : a[3], true);
-            if (t1) { a[0] = r02; a[1] = r13; } else { a[2] = r02; a[3] = r13; }
-        }
-        // lane t now holds plane t of the register quad (board 4 q + 2 h + t / 2; t even: black, the second colour block) at cells 32 M + 4 (n / 4) ..
-        const int board_in_group = 4 * q + 2 * h + (t >> 1);
-        if (board_in_group < n_live && plane_stride > 0) {
-            int32_t* dst = out_density + static_cast<size_t>(first_board + board_in_group) * 4 * plane_stride + ((t & 1) ? 0 : 2 * plane_stride)
-                           + KIND * plane_stride + 32 * M + (n & ~3);
-            *reinterpret_cast<Int4Unaligned*>(dst) = Int4Unaligned{a[0], a[1], a[2], a[3]};
-        }
-    }
-#else
     int32_t* out = out_density + static_cast<size_t>(first_board) * 4 * plane_stride + KIND * plane_stride + 32 * M + n + h * (2 * 4 * plane_stride);
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
@@ -260,7 +220,6 @@ __device__ __forceinline__ void density_tile_pass(const uint32_t (&own_rows)[8],
             out[b * 4 * plane_stride + 0 * 2 * plane_stride] = acc[i + 1] ^ neg;             // column 2 b + 1: white, the first
         }
     }
-#endif
 }
 
 // All fourteen passes of a group, back to back: the group's density planes are one contiguous block of 16 x 3 600 bytes, and written
