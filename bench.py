@@ -266,8 +266,9 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
 
 def bench_supervisor_pipeline(args, G, torch, dev, rank, world, distributed, bare_playouts_per_s):
     """The supervisor's self-play loop (network/data_helper.py:56-83 with config.py:9-12's "traditional_mcts" on both sides) resident on
-    the device: --sup-games games per GPU through --trad-games slots (continuous batching: gmk_trad_selfplay_run), every move one K6
-    search of --trad-playouts playouts.  Weak scaling (games per GPU fixed); the time is the slowest rank's."""
+    the device: --sup-games games per GPU through --trad-games slots (gmk_trad_selfplay_run, persistent: ONE launch in which every slot's
+    wavefront plays game after game at its own pace), every move one K6 search of --trad-playouts playouts.  Weak scaling (games per GPU
+    fixed); the time is the slowest rank's.  Beside it the lock-step form of the loop (search by search for all slots) with every slot busy."""
     import time
     from gomokuai_amd import selfplay
     n, slots, P = args.sup_games, args.trad_games, args.trad_playouts
@@ -291,9 +292,9 @@ def bench_supervisor_pipeline(args, G, torch, dev, rank, world, distributed, bar
     else:
         overflow = bool(rec.overflow)
     rate = moves * P / seconds
-    # ... and the same loop while every slot is busy (eight games queued per slot, stopped after 40 moves per slot): what the loop itself
-    # -- step kernel, slot hand-over, four bytes to the host per move -- takes from the bare search rate, without the tail of a finite batch
-    # (game lengths run from 9 to 225 moves: at the end of a batch few slots still play, and a search costs a game its full latency)
+    # ... and the lock-step form of the loop (one search launch per move for all slots, then the step kernels; what kept subtrees, root noise
+    # and PoolRAVE use) while every slot is busy (eight games queued per slot, stopped after 40 moves per slot): what that loop's step
+    # kernels, slot hand-over and four bytes to the host per move take from the bare search rate
     steady_steps = 40
     def steady():
         torch.cuda.synchronize()
@@ -317,9 +318,9 @@ def bench_supervisor_pipeline(args, G, torch, dev, rank, world, distributed, bar
                            "share_of_bare_search_rate": busy_rate / bare_playouts_per_s if bare_playouts_per_s else None,
                            "note": "includes the setup of %d queued games (records, openings) and the first search's evaluator syncs" % (8 * slots)},
             "share_of_bare_search_rate": rate / bare_playouts_per_s if bare_playouts_per_s else None,
-            "config": {"workload": "supervisor self-play (K6 searches + device-resident game loop, gmk_trad_selfplay_run), %d games per GPU through %d slots, "
+            "config": {"workload": "supervisor self-play (K6, persistent device-resident game loop: gmk_trad_selfplay_run in ONE launch), %d games per GPU through %d slots, "
                                    "%d playouts per move, 2-ply openings, fresh root every move" % (n, slots, P),
-                       "host_traffic_per_move": "4 bytes (slots still playing)"}}
+                       "host_traffic": "none while the games run (records by game id in HBM); busy_slots: the lock-step form of the loop, 4 bytes per move"}}
 
 
 def rave_positions(G, np, n, first):

@@ -48,14 +48,16 @@ struct TradParams {
     uint2* front;                                // [n_games][cap] the child that is first in the CURRENT order: {id | cell << 24, its link word}
     uint8_t* ord;                                // [n_games][cap] the node's position in its parent's current child order
     TradHeader* hdr;
-    const uint8_t* moves;                        // [n_games][225] position to search from (read when hdr.fresh)
-    const int32_t* lens;
+    uint8_t* moves;                              // [n_games][225] position to search from (read when hdr.fresh; the persistent self-play loop appends to it)
+    int32_t* lens;
     const uint32_t* g_trans;
     const uint32_t* g_records;
     int trans_words, record_words;
     int n_games, cap, playouts;
     int profile;                                 // diagnostic runs only
     double c_puct;
+    int selfplay;                                // != 0: every wavefront plays whole games, search after search, until the games have run out (sp)
+    TradSelfPlay sp;
 };
 
 // lane i of a 16-lane row reads lane i + N of the same row (DPP row_shl; 0 beyond the row)
@@ -222,7 +224,16 @@ void trad_playouts_kernel(TradParams prm) {
     const uint8_t* record = reinterpret_cast<const uint8_t*>(g.c.st + oRecord);
     uint32_t n_nodes = hdr->n_nodes, status = hdr->status;
     int root_black = hdr->root_black;
-    const uint32_t fresh_mode = hdr->fresh;
+    uint32_t fresh_mode = hdr->fresh;
+    // The persistent self-play loop (gmk_trad_selfplay_run, mode 1): this wavefront plays whole games at its own pace -- one turn of the loop
+    // below = Policy::prepare + one search + MCTS::stepForward()'s move + the end-of-game check, a finished game's slot takes the next
+    // unstarted game from a global counter (its evaluator starts from the empty board, so a game's record does not depend on the slot it
+    // landed in) -- instead of every slot waiting at every move for the slowest search of the batch.  Otherwise: one turn.
+    int sp_game = prm.selfplay ? prm.sp.slot_game[game] : -1, cur_len = prm.lens[game];
+    uint8_t* const slot_moves = prm.moves + static_cast<size_t>(game) * 225;
+    unsigned long long playouts_run = hdr->playouts_done;
+    unsigned long long prof_sel = 0, prof_sim = 0, prof_back = 0, prof_t0 = 0, prof_all = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;
+    for (;;) {
     const bool fresh = fresh_mode == 1u;
 
     // The evaluator's work of one step is a script: take `n_revert` moves back, then apply script[0 .. n_apply) (bytes in LDS).
@@ -231,10 +242,10 @@ void trad_playouts_kernel(TradParams prm) {
     uint8_t* script = g.record_copy;
     int n_revert = 0, n_apply = 0;
     bool rebuild = false;
-    const int n_position = fresh_mode != 0u ? prm.lens[game] : 0;
+    const int n_position = fresh_mode != 0u ? cur_len : 0;
     if (fresh_mode != 0u) {
         // syncWithBoard: back to the first move that differs (or to the position's length), then the rest of the position
-        const uint8_t* mv = prm.moves + static_cast<size_t>(game) * 225;
+        const uint8_t* mv = slot_moves;
         const int have = meta[0], common = min(have, n_position);
         int i0 = common;
         for (int i = lane; i < common; i += 64) if (record[i] != mv[i]) i0 = min(i0, i);
@@ -273,7 +284,6 @@ void trad_playouts_kernel(TradParams prm) {
         return L;
     };
 
-    unsigned long long prof_sel = 0, prof_sim = 0, prof_back = 0, prof_t0 = 0, prof_all = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int it = fresh_mode != 0u ? -1 : 0; it < prm.playouts && !(status & 1u); ++it) {
         if (prm.profile) prof_t0 = __builtin_amdgcn_s_memtime();
         int depth = 0;
@@ -334,7 +344,7 @@ void trad_playouts_kernel(TradParams prm) {
             if (fresh) {
                 if (lane == 0) {
                     g.stat[0] = make_uint2(0u, 0u);
-                    g.info[0] = make_uint2(kNoParent | ((n_position ? prm.moves[static_cast<size_t>(game) * 225 + n_position - 1] : 255u) << 24), __float_as_uint(1.0f));
+                    g.info[0] = make_uint2(kNoParent | ((n_position ? slot_moves[n_position - 1] : 255u) << 24), __float_as_uint(1.0f));
                     g.link[0] = 0u;
                     g.path_link[0] = 0u;
                 }
@@ -500,13 +510,87 @@ void trad_playouts_kernel(TradParams prm) {
 
     wave_phase_fence();
     if (meta[3]) status |= 2u;
+    playouts_run = (fresh ? 0ull : playouts_run) + static_cast<unsigned long long>(prm.playouts);
+    if (!prm.selfplay || sp_game < 0) break;
+
+    // ---- the move: MCTS::stepForward()'s choice (the most visited child, first in the current order), the root's visit counts into the
+    //      game's record, Board::applyMove with its victory check (Game.cpp:37-49, 88-136); as trad_advance_kernel, inside the wavefront ----
+    {
+        const TradSelfPlay& sp = prm.sp;
+        if (lane == 0 && (status & 1u)) atomicOr(sp.overflow, 1);
+        const uint32_t lk = g.link[0], first = lk & 0xFFFFFFu, n = lk >> 24;
+        uint32_t best_visits = 0, best_ord = 0xFFFFFFFFu, best_id = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t id = first + i, o = g.ord[id], v = g.stat[id].x + 1u;
+            if (v > best_visits || (v == best_visits && o < best_ord)) { best_visits = v; best_ord = o; best_id = id; }
+        }
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const uint32_t ov = __shfl_down(best_visits, sft), oo = __shfl_down(best_ord, sft), oi = __shfl_down(best_id, sft);
+            if (ov > best_visits || (ov == best_visits && ov != 0u && oo < best_ord)) { best_visits = ov; best_ord = oo; best_id = oi; }
+        }
+        best_visits = __shfl(best_visits, 0);
+        best_id = __shfl(best_id, 0);
+        bool over = best_visits == 0u || cur_len >= 225;        // no child: nothing the policy wants to play: the game ends where it stands
+        int winner = 0;
+        if (!over) {
+            const uint32_t cell = g.info[best_id].x >> 24;
+            if (sp.rec_visits) {
+                uint16_t* rv = sp.rec_visits + (static_cast<size_t>(sp_game) * 225 + static_cast<size_t>(cur_len)) * 225;
+                for (int i = lane; i < 225; i += 64) rv[i] = 0;
+                wave_phase_fence();
+                for (uint32_t i = lane; i < n; i += 64) rv[g.info[first + i].x >> 24] = static_cast<uint16_t>(min(g.stat[first + i].x, 65535u));
+            }
+            uint32_t* rows = g.path_node;                       // (the path is rebuilt by the next search: sixteen words of it hold the board's rows here)
+            if (lane < 16) rows[lane] = 0u;
+            wave_phase_fence();
+            for (int i = lane; i < cur_len; i += 64) atomicOr(&rows[slot_moves[i] / 15u], 1u << (slot_moves[i] % 15u + ((i & 1) ? 16u : 0u)));
+            const int shift = (cur_len & 1) ? 16 : 0;
+            if (lane == 0) atomicOr(&rows[cell / 15u], 1u << (cell % 15u + shift));
+            wave_phase_fence();
+            const bool five = gmk::five_through<1>(rows, static_cast<int>(cell % 15u), static_cast<int>(cell / 15u), shift);
+            if (lane == 0) {
+                slot_moves[cur_len] = static_cast<uint8_t>(cell);
+                sp.rec_moves[static_cast<size_t>(sp_game) * 225 + cur_len] = static_cast<uint8_t>(cell);
+                sp.rec_lens[sp_game] = cur_len + 1;
+            }
+            over = five || cur_len + 1 == 225;
+            winner = five ? (shift ? -1 : 1) : 0;
+            ++cur_len;
+        }
+        if (over) {
+            int next = 0;
+            if (lane == 0) {
+                sp.rec_winner[sp_game] = static_cast<int8_t>(winner);
+                next = atomicAdd(sp.next_game, 1);
+            }
+            next = __shfl(next, 0);
+            if (next >= sp.n_total) {                           // the games have run out: the slot is done
+                if (lane == 0) sp.slot_game[game] = -1;
+                sp_game = -1;
+                status |= kStatusIdleSlot;
+                break;
+            }
+            sp_game = next;
+            cur_len = sp.open_lens ? sp.open_lens[next] : 0;
+            for (int i = lane; i < cur_len; i += 64) slot_moves[i] = sp.open_moves[static_cast<size_t>(next) * sp.open_stride + i];
+            if (lane == 0) { sp.slot_game[game] = next; sp.game_ids[game] = static_cast<uint32_t>(next); }
+            reset_state(g.c);                                   // a new game on a fresh evaluator (Evaluator::reset)
+            status &= ~(1u | 8u);
+        }
+        // the slot's move list is read again by the next turn's syncWithBoard, by other lanes than the one that wrote it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        fresh_mode = 1u;
+    }
+    }
     if (lane == 0) {
+        if (prm.selfplay) prm.lens[game] = cur_len;
         hdr->n_nodes = n_nodes;
         hdr->init_acts = static_cast<uint32_t>(g.init);
         hdr->status = status;
-        hdr->fresh = 0;
+        hdr->fresh = prm.selfplay ? 1u : 0u;
         hdr->root_black = static_cast<uint32_t>(root_black);
-        hdr->playouts_done = (fresh ? 0u : hdr->playouts_done) + static_cast<uint32_t>(prm.playouts);
+        hdr->playouts_done = static_cast<uint32_t>(playouts_run);
         hdr->evaluator_updates += g.updates;
         if (prm.profile) {
             hdr->prof[0] = static_cast<uint32_t>(prof_sel >> 10); hdr->prof[1] = static_cast<uint32_t>(prof_sim >> 10);
@@ -888,6 +972,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     prm.moves = t->d_moves; prm.lens = t->d_lens;
     prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
+    prm.selfplay = 0; prm.sp = TradSelfPlay{};
     static const bool profile = gmk::profile_env("GMK_TRAD_PROFILE") != nullptr;
     prm.profile = profile ? 1 : 0;
     const int grid = (t->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
@@ -1025,7 +1110,11 @@ extern "C" int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t*
 extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uint32_t first_game_id, int playouts, double c_puct, uint64_t seed,
                                      int reuse_subtree, float noise_alpha, float noise_epsilon,
                                      const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens,
-                                     uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int max_steps, int32_t* h_overflow, int32_t* h_steps, void* stream) {
+                                     uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int persistent, int max_steps, int32_t* h_overflow, int32_t* h_steps, void* stream) {
+    if (persistent && (poolrave || reuse_subtree || noise_alpha > 0.0f || max_steps > 0)) {
+        gmk::set_error("gmk_trad_selfplay_run: the persistent loop plays TraditionalPolicy games from a new root every move, without root noise, to their end");
+        return GMK_ERR_ARG;
+    }
     if (!t || n_total <= 0 || playouts < 0 || max_steps < 0 || !d_moves || !d_lens || !d_winner || (h_open_moves && (!h_open_lens || open_stride <= 0))) {
         gmk::set_error("gmk_trad_selfplay_run: bad arguments");
         return GMK_ERR_ARG;
@@ -1102,9 +1191,30 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
     sp.game_ids = t->d_game_ids;
     sp.rec_moves = d_moves; sp.rec_lens = d_lens; sp.rec_visits = d_visits; sp.rec_winner = d_winner;
     int32_t steps = 0;
+    if (persistent) {
+        // ONE launch: every wavefront plays game after game at its own pace (trad_playouts_kernel, prm.selfplay)
+        gmk::DeviceState& st = gmk::device_state();
+        if (t->policy == 2) { gmk::set_error("gmk_trad_selfplay_run: this handle searches with PoolRAVEPolicy"); cleanup(); return GMK_ERR_STATE; }
+        t->policy = 1;
+        const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4) * 4;
+        if (!t->attr_set) {
+            GMK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            t->attr_set = true;
+        }
+        TradParams prm;
+        prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.front = t->d_front; prm.ord = t->d_ord; prm.hdr = t->d_hdr;
+        prm.moves = t->d_moves; prm.lens = t->d_lens;
+        prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
+        prm.n_games = n_slots; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
+        prm.profile = 0; prm.selfplay = 1; prm.sp = sp;
+        hipLaunchKernelGGL(trad_playouts_kernel, dim3((n_slots + kGamesPerBlock - 1) / kGamesPerBlock), dim3(kThreads), lds, s, prm);
+        GMK_TRY(hipGetLastError());
+        GMK_TRY(hipStreamSynchronize(s));
+        steps = 1;
+    }
     std::vector<int32_t> slot_game(ns);
     const long long step_limit = max_steps > 0 ? max_steps : 226ll * (n_total / n_slots + 2);
-    for (long long step = 0; step < step_limit; ++step) {
+    for (long long step = 0; step < step_limit && !persistent; ++step) {
         if (noise_alpha > 0.0f) {                               // Default::AddNoise at the start of every search (MCTS.cpp:182), keyed by the GAME a slot plays
             GMK_TRY(hipMemcpy(slot_game.data(), d_state, ns * 4, hipMemcpyDeviceToHost));
             for (size_t g = 0; g < ns; ++g) t->game_ids[g] = slot_game[g] >= 0 ? static_cast<uint32_t>(slot_game[g]) : 0u;

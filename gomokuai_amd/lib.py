@@ -122,7 +122,7 @@ def load():
     L.gmk_trad_read_evaluators.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.gmk_trad_run_poolrave.argtypes = [vp, C.c_int, C.c_double, C.c_uint64, C.c_uint32, vp]
     L.gmk_trad_selfplay_run.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_double, C.c_uint64, C.c_int, C.c_float, C.c_float,
-                                        vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
+                                        vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     L.gmk_trad_root_amaf.argtypes = [vp, vp, vp]
     L.gmk_pvnet_create.argtypes = [vp] * 10 + [C.POINTER(vp)]
     L.gmk_pvnet_destroy.argtypes = [vp]
@@ -443,7 +443,7 @@ class TraditionalMCTS:
     _POOLRAVE = 0
 
     def selfplay_run(self, n_total, first_game_id, playouts, d_moves, d_visits, d_lens, d_winner, open_moves=None, open_lens=None,
-                     reuse_subtree=False, root_noise=None, seed=DEFAULT_SEED, stream=None, max_steps=0):
+                     reuse_subtree=False, root_noise=None, seed=DEFAULT_SEED, stream=None, max_steps=0, persistent=False):
         """gmk_trad_selfplay_run: the handle's games are slots that play n_total whole games between them, the loop resident on the
         device (search, MCTS::stepForward's move, end-of-game check and slot hand-over are kernels).  open_moves uint8[n_total, stride] /
         open_lens int32[n_total] (host) or None; the outputs are device pointers (ints), indexed by game.
@@ -460,7 +460,7 @@ class TraditionalMCTS:
         _check(load().gmk_trad_selfplay_run(self.h, self._POOLRAVE, int(n_total), int(first_game_id), int(playouts), self.c_puct, int(seed),
                                             int(bool(reuse_subtree)), float(alpha), float(eps),
                                             None if om is None else om.ctypes.data, stride, None if ol is None else ol.ctypes.data,
-                                            d_moves, d_visits, d_lens, d_winner, int(max_steps), C.byref(overflow), C.byref(steps), stream))
+                                            d_moves, d_visits, d_lens, d_winner, int(bool(persistent)), int(max_steps), C.byref(overflow), C.byref(steps), stream))
         return steps.value, bool(overflow.value)
 
     def root_stats(self):

@@ -258,7 +258,8 @@ class _HostGames:
         return last
 
 
-def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps=0):
+def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps=0,
+                               persistent=False):
     """play_supervisor_games with the loop resident on the device (gmk_trad_selfplay_run): the searches, MCTS::stepForward's move, the
     end-of-game check and the hand-over of a finished game's slot are kernels; the host reads four bytes per move.  Same games, same
     records as the host-driven loops below (tests/test_selfplay_gpu.py holds them to each other)."""
@@ -283,7 +284,7 @@ def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_g
     torch.cuda.current_stream(dev).synchronize()
     try:
         _, overflow = tree.selfplay_run(n_games, first_game_id, playouts, d_moves.data_ptr(), d_visits.data_ptr(), d_lens.data_ptr(), d_winner.data_ptr(),
-                                        open_moves, open_lens, reuse_subtree, root_noise, seed, stream, max_steps)
+                                        open_moves, open_lens, reuse_subtree, root_noise, seed, stream, max_steps, persistent)
     finally:
         tree.close()
     return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, overflow)
@@ -309,8 +310,16 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
     if policy not in ("traditional", "poolrave"):
         raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
     if device_loop and max_moves >= N:
-        return _play_supervisor_on_device(n_games, n_games if slots is None else max(1, min(int(slots), n_games)), playouts, c_puct, seed, first_game_id,
-                                          opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps)
+        n_slots = n_games if slots is None else max(1, min(int(slots), n_games))
+        # "persistent": one launch, every slot plays game after game at its own pace (TraditionalPolicy, new root every move, no noise, whole
+        # games); each game on a fresh evaluator, so the records equal the all-at-once loop's whatever the slots.  Chosen by itself when games
+        # outnumber slots and the configuration allows it; device_loop="lockstep" keeps the search-by-search loop (a slot's evaluator carries over).
+        can_persist = policy == "traditional" and not reuse_subtree and root_noise is None and not max_steps
+        if device_loop == "persistent" and not can_persist:
+            raise ValueError("play_supervisor_games: the persistent loop plays TraditionalPolicy games from a new root every move, without root noise, to their end")
+        persistent = can_persist and (device_loop == "persistent" or (device_loop is True and n_slots < n_games))
+        return _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id,
+                                          opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps, persistent)
     if max_steps:
         raise ValueError("play_supervisor_games: max_steps is a switch of the device-resident loop")
     if slots is not None and slots < n_games:

@@ -241,13 +241,18 @@ int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t se
  * unstarted game (reuse_subtree = 1 keeps the chosen child's subtree as gmk_trad_step does, 0 starts every search from a new root as
  * gmk_trad_set_positions does).  Records by GAME, on the device: d_moves uint8[n_total][225], d_lens int32[n_total], d_winner
  * int8[n_total], d_visits uint16[n_total][225][225] (may be NULL).  h_open_moves / h_open_lens: the games' openings, or NULL.
+ * persistent = 1 (TraditionalPolicy, a new root every move, no root noise, whole games): ONE launch in which every slot's wavefront
+ * plays game after game at its own pace -- a search no longer waits for the slowest one of the batch -- taking the next unstarted game
+ * from a counter when its game ends; a game then starts on a fresh evaluator (Evaluator::reset), so its record does not depend on the
+ * slot it landed in and equals the one the all-games-at-once loop plays.  persistent = 0: the lock-step loop described above (a slot's
+ * evaluator carries over from game to game, as the reference's policy object does within a worker).
  * max_steps > 0 ends the loop after that many moves per slot (games still running keep the moves they have, winner 0): what a
  * throughput measurement with every slot busy needs; 0 = play every game to its end.
  * *h_overflow != 0: some search stopped at its node capacity.  Afterwards the handle must be positioned again before other use. */
 int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uint32_t first_game_id, int playouts, double c_puct, uint64_t seed,
                           int reuse_subtree, float noise_alpha, float noise_epsilon,
                           const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens,
-                          uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int max_steps, int32_t* h_overflow, int32_t* h_steps, void* stream);
+                          uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int persistent, int max_steps, int32_t* h_overflow, int32_t* h_steps, void* stream);
 /* the games' evaluator states, laid out as gmk_evalstate_read */
 int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t* h_density, uint32_t* h_pattern_dist,
                              uint32_t* h_compound_dist, int32_t* h_meta, uint8_t* h_record);

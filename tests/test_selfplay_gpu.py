@@ -409,9 +409,28 @@ def test_device_resident_supervisor_loop_plays_the_host_loops_games(policy, c_pu
     kw = dict(c_puct=c_puct, policy=policy, opening_plies=2, first_game_id=21, seed=99, reuse_subtree=reuse, root_noise=noise)
     for slots in (None, 3):
         host = selfplay.play_supervisor_games(10, 70, slots=slots, device_loop=False, **kw).cpu()
-        dev = selfplay.play_supervisor_games(10, 70, slots=slots, **kw)
+        dev = selfplay.play_supervisor_games(10, 70, slots=slots, device_loop="lockstep", **kw)
         assert not dev.overflow and not host.overflow
         dev = dev.cpu()
         assert (dev.lens == host.lens).all() and (dev.winner == host.winner).all(), (policy, reuse, noise, slots)
         assert (dev.moves == host.moves).all() and (dev.visits == host.visits).all(), (policy, reuse, noise, slots)
         assert int(dev.lens.min()) >= 9
+
+
+def test_persistent_supervisor_loop_plays_the_games_of_the_all_at_once_loop(oracle):
+    """gmk_trad_selfplay_run with persistent = 1: one launch, every slot's wavefront plays game after game at its own pace and takes the
+    next unstarted game from a counter; a game starts on a fresh evaluator, so -- whatever slot it lands in, whatever the order the slots
+    finish in -- its record is the one the host-driven loop plays with all games side by side: moves, lengths, winners, per-ply root visit
+    counts; twice the same; every game legal and finished on the oracle's board."""
+    kw = dict(c_puct=5.0, policy="traditional", opening_plies=2, first_game_id=61, seed=7)
+    host = selfplay.play_supervisor_games(23, 60, device_loop=False, **kw).cpu()
+    for slots in (5, 23, 40):
+        a = selfplay.play_supervisor_games(23, 60, slots=slots, device_loop="persistent", **kw)
+        assert not a.overflow
+        a = a.cpu()
+        assert (a.lens == host.lens).all() and (a.winner == host.winner).all(), slots
+        assert (a.moves == host.moves).all() and (a.visits == host.visits).all(), slots
+    legal, end_ply, winner = oracle.replay_games(a.moves.numpy(), a.lens.numpy())
+    assert legal.all() and (end_ply == a.lens.numpy()).all() and (winner == a.winner.numpy()).all()
+    with pytest.raises(ValueError):
+        selfplay.play_supervisor_games(4, 10, device_loop="persistent", reuse_subtree=True)
