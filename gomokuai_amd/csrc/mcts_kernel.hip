@@ -57,6 +57,20 @@ struct GameHeader {                 // 128 B per game, in HBM
 };
 static_assert(sizeof(GameHeader) == 128, "GameHeader layout");
 
+// Continuous batching for whole-game self-play (gmk_selfplay_run): the handle's games are SLOTS; slot g plays game slot_game[g] of
+// n_total, its records go to that game's rows, and when the game ends the slot takes the next game nobody has started (a counter in
+// device memory): its opening position becomes the slot's root, its global id the slot's random-number key.  So the search
+// launches stay full until fewer games than slots remain, instead of waiting for the longest game of a fixed batch.
+struct SlotRefill {
+    int32_t* slot_game;             // [n_slots] game played by each slot, -1 = none (null: slot g plays game g and is not refilled)
+    int32_t* next_game;             // [1] first game not started yet
+    int n_total;
+    const uint8_t* open_moves;      // [n_total][open_stride] opening moves (black first), may be null
+    const int32_t* open_lens;       // [n_total] (<= 8: an opening cannot be a finished game)
+    int open_stride;
+    uint32_t first_game_id;
+};
+
 struct SearchParams {
     double c_puct;
     uint32_t seed_lo, seed_hi;
@@ -68,7 +82,23 @@ struct SearchParams {
     int profile;                    // GMK_MCTS_PROFILE=1: per-phase shader-clock sums into GameHeader::pad (diagnostic runs only)
     const float* value_table;       // float(double(sum) / double(c_rollouts)) at index sum + c_rollouts (Random.h:30-33): owned by the HANDLE, since
                                     // handles with different c_rollouts run side by side (supervisor against candidate)
+    // The persistent self-play loop (gmk_selfplay_run without kept subtrees and root noise): the kernel is a loop of TURNS -- the search of its
+    // games' current roots, then for each of them the step mcts_advance_kernel does (the move, the record, the end-of-game check, a new root, a
+    // finished game's slot taking the next unstarted game) -- until none of the wavefront's slots has a game left: ONE launch, no wavefront
+    // waits for another's search.  The records below are the step's outputs; a game's record does not depend on where or when it was played
+    // (its random streams are keyed by its global id), so this loop and the lock-step one write the same bytes.
+    int persistent;
+    uint8_t* rec_moves;
+    uint16_t* rec_visits;
+    int32_t* rec_lens;
+    int8_t* rec_winner;
+    int32_t* unfinished;            // (written, never read, in this mode)
+    SlotRefill slots;
 };
+
+__device__ void advance_one(int g, int lane, GameHeader* headers, uint2* stats, uint32_t* link, uint32_t* parent, uint2* stats2, uint32_t* link2,
+                            uint32_t* parent2, size_t cap, uint8_t* rec_moves, uint16_t* rec_visits, int32_t* rec_lens, int8_t* rec_winner,
+                            int32_t* unfinished, int reuse, const int16_t* forced, const SlotRefill& slots);
 
 __constant__ float c_prior[226];          // 1.0f / float(n) evaluated on the host (MonteCarlo.hpp:50-55)
 
@@ -93,7 +123,7 @@ __device__ __forceinline__ int row_scan(int v) {                        // inclu
     return v;
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))      // two wavefronts per SIMD: at most 256 registers
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
                           uint32_t* __restrict__ parent, const float* __restrict__ root_prior, SearchParams prm) {
     // dynamic LDS, sized by the games G and rollouts R of the block (lds_words() below): the rollout positions as line words
@@ -123,6 +153,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     const int rounds = (G + 3) >> 2;
     const size_t cap = static_cast<size_t>(prm.node_capacity);
 
+    for (;;) {                                                  // one turn = one search of the wavefront's games (the only turn unless prm.persistent)
     if (lane < kMaxGamesPerBlock) {
         const bool ok = lane < games_here;
         s_nodes[lane] = ok ? headers[game0 + lane].n_nodes : 0;
@@ -402,6 +433,30 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         if (s_active[lane]) headers[game0 + lane].playouts_done += static_cast<uint32_t>(prm.playouts);
         if (prm.profile) for (int k = 0; k < 4; ++k) headers[game0 + lane].pad[k] = static_cast<uint32_t>(prof[k] >> 10);
     }
+    if (!prm.persistent) break;
+    // the step of every game of this wavefront (headers and trees were written by other lanes than the ones that read them now, and the
+    // next turn reads what the step writes: an agent-scope release / acquire pair either side)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+        // (opaque copies: what the step derives from the kernel's arguments is computed here, not hoisted out of the turn loop and carried
+        // through the playouts in registers -- the search runs two wavefronts per SIMD on 256 registers and has none to spare)
+        GameHeader* h_ = headers; uint2* st_ = stats; uint32_t* lk_ = link; uint32_t* pa_ = parent;
+        int first_ = game0, lane_ = lane;
+        asm volatile("" : "+s"(h_), "+s"(st_), "+s"(lk_), "+s"(pa_), "+s"(first_), "+v"(lane_));
+#pragma unroll 1
+        for (int g = 0; g < games_here; ++g)
+            advance_one(first_ + g, lane_, h_, st_, lk_, pa_, nullptr, nullptr, nullptr, cap, prm.rec_moves, prm.rec_visits, prm.rec_lens, prm.rec_winner,
+                        prm.unfinished, 0, nullptr, prm.slots);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bool any = false;
+    for (int g = 0; g < games_here; ++g) any |= !(headers[game0 + g].status & 1u);
+    if (!any) break;
+    }
 }
 
 // fresh single-node trees (MCTS::reset, MCTS.cpp:149-156)
@@ -415,33 +470,14 @@ __global__ void mcts_init_roots_kernel(const GameHeader* __restrict__ headers, u
     parent[base] = kNone;
 }
 
-// Continuous batching for whole-game self-play (gmk_selfplay_run): the handle's games are SLOTS; slot g plays game slot_game[g] of
-// n_total, its records go to that game's rows, and when the game ends the slot takes the next game nobody has started (a counter in
-// device memory): its opening position becomes the slot's root, its global id the slot's random-number key.  So the search
-// launches stay full until fewer games than slots remain, instead of waiting for the longest game of a fixed batch.
-struct SlotRefill {
-    int32_t* slot_game;             // [n_slots] game played by each slot, -1 = none (null: slot g plays game g and is not refilled)
-    int32_t* next_game;             // [1] first game not started yet
-    int n_total;
-    const uint8_t* open_moves;      // [n_total][open_stride] opening moves (black first), may be null
-    const int32_t* open_lens;       // [n_total] (<= 8: an opening cannot be a finished game)
-    int open_stride;
-    uint32_t first_game_id;
-};
-
 // One self-play move per unfinished game: MCTS::stepForward() (MCTS.cpp:129-134) + Board::applyMove with the
 // victory check (Game.cpp:37-47, 88-136) on the root position, the (move, visit counts) record of
 // agents/utils.py:29-41, and the new root.  One wavefront per game.
-__global__ __launch_bounds__(64)
-void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
-                         uint32_t* __restrict__ parent, uint2* __restrict__ stats2, uint32_t* __restrict__ link2,
-                         uint32_t* __restrict__ parent2, size_t cap, int n_games,
-                         uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
-                         int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse,
-                         const int16_t* __restrict__ forced /* null, or per game: the move to step to (MCTS::stepForward(move)), -1 = the most visited child */,
-                         SlotRefill slots) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    if (g >= n_games) return;
+__device__ void advance_one(int g, int lane, GameHeader* headers, uint2* stats, uint32_t* link, uint32_t* parent, uint2* stats2, uint32_t* link2,
+                            uint32_t* parent2, size_t cap, uint8_t* rec_moves, uint16_t* rec_visits, int32_t* rec_lens, int8_t* rec_winner,
+                            int32_t* unfinished, int reuse,
+                            const int16_t* forced /* null, or per game: the move to step to (MCTS::stepForward(move)), -1 = the most visited child */,
+                            const SlotRefill& slots) {
     GameHeader& hdr = headers[g];
     const int rec = slots.slot_game ? slots.slot_game[g] : g;      // the records' row of this slot's game
     if (rec < 0) return;                                            // a slot that never got a game
@@ -577,6 +613,17 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
     if (lane == 0) { hdr.root = 0; hdr.n_nodes = next; }
 }
 
+__global__ __launch_bounds__(64)
+void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
+                         uint32_t* __restrict__ parent, uint2* __restrict__ stats2, uint32_t* __restrict__ link2,
+                         uint32_t* __restrict__ parent2, size_t cap, int n_games,
+                         uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
+                         int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse,
+                         const int16_t* __restrict__ forced, SlotRefill slots) {
+    if (static_cast<int>(blockIdx.x) >= n_games) return;
+    advance_one(blockIdx.x, threadIdx.x, headers, stats, link, parent, stats2, link2, parent2, cap, rec_moves, rec_visits, rec_lens, rec_winner, unfinished, reuse, forced, slots);
+}
+
 __global__ void mcts_root_flags_kernel(GameHeader* __restrict__ headers, const uint32_t* __restrict__ link, size_t cap, int n_games) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_games) return;
@@ -625,6 +672,7 @@ struct gmk_mcts {
     float* d_root_prior = nullptr;     // [n_games][225] by child index, used while GameHeader::noise is set
     float* d_value = nullptr;          // [2 * c_rollouts + 1] rollout sum -> state value
     SlotRefill slots{};                // continuous batching (gmk_selfplay_run); all null otherwise
+    struct { uint8_t* moves; uint16_t* visits; int32_t* lens; int8_t* winner; int32_t* unfinished; } persistent_rec{};     // set while gmk_selfplay_run's ONE launch is issued
     int32_t* d_slot_state = nullptr;   // [n_games + 1] slot_game, next_game
     uint8_t* d_open_moves = nullptr;
     int32_t* d_open_lens = nullptr;
@@ -741,6 +789,12 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     const int grid = (m->n_games + m->games_per_block - 1) / m->games_per_block;
     prm.profile = gmk::profile_env("GMK_MCTS_PROFILE") ? 1 : 0;
     prm.value_table = m->d_value;
+    prm.persistent = 0; prm.rec_moves = nullptr; prm.rec_visits = nullptr; prm.rec_lens = nullptr; prm.rec_winner = nullptr; prm.unfinished = nullptr; prm.slots = SlotRefill{};
+    if (m->persistent_rec.moves) {                              // gmk_selfplay_run's persistent form: this launch plays the games to their end
+        prm.persistent = 1;
+        prm.rec_moves = m->persistent_rec.moves; prm.rec_visits = m->persistent_rec.visits; prm.rec_lens = m->persistent_rec.lens; prm.rec_winner = m->persistent_rec.winner;
+        prm.unfinished = m->persistent_rec.unfinished; prm.slots = m->slots;
+    }
     m->last_stream = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
                        m->d_root_prior, prm);
@@ -848,7 +902,17 @@ extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id
     GMK_HIP_CHECK(hipMalloc(&d_unfinished, 4));
     int32_t steps = 0;
     rc = GMK_OK;
-    for (long long step = 0; step < 226ll * (n_total / n_slots + 2); ++step) {
+    // Without kept subtrees and root noise the whole run is ONE launch (SearchParams::persistent): every wavefront plays its slots' games
+    // turn by turn at its own pace; the records are the same bytes either way (a game's random streams are keyed by its global id).
+    const bool persistent = !reuse_subtree && !(noise_alpha > 0.0f);
+    if (persistent) {
+        m->persistent_rec = {d_moves, d_visits, d_lens, d_winner, d_unfinished};
+        rc = gmk_mcts_run(m, playouts, s);
+        m->persistent_rec = {};
+        if (rc == GMK_OK && hipStreamSynchronize(s) != hipSuccess) { gmk::set_error("gmk_selfplay_run: the persistent launch failed"); rc = GMK_ERR_HIP; }
+        steps = 1;
+    }
+    for (long long step = 0; step < 226ll * (n_total / n_slots + 2) && !persistent; ++step) {
         if (noise_alpha > 0.0f && reuse_subtree) rc = gmk_mcts_add_root_noise(m, noise_alpha, noise_epsilon, s);      // Default::AddNoise at the start of every search (MCTS.cpp:182)
         if (rc == GMK_OK) rc = gmk_mcts_run(m, playouts, s);
         if (rc == GMK_OK) rc = gmk_mcts_step(m, nullptr, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, s);
