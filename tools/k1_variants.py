@@ -13,12 +13,13 @@ def build(specs):
     from gomokuai_amd import build as B
     B.build_lib()
     os.makedirs(VAR, exist_ok=True)
-    others = [os.path.join(B.CSRC, os.path.splitext(s)[0] + ".o") for s in B.LIB_SOURCES if s != "eval_kernel.hip"]
+    source = os.environ.get("GMK_VARIANT_SOURCE", "eval_kernel.hip")       # (the same harness for another kernel file's -D switches)
+    others = [os.path.join(B.CSRC, os.path.splitext(s)[0] + ".o") for s in B.LIB_SOURCES if s != source]
     procs = []
     for spec in specs:
         name, _, flags = spec.partition("=")
-        obj = os.path.join(VAR, "eval_kernel_%s.o" % name)
-        cmd = [B.HIPCC] + B.FLAGS + ["-D" + f for f in flags.split(",") if f] + ["-x", "hip", "-c", os.path.join(B.CSRC, "eval_kernel.hip"), "-o", obj]
+        obj = os.path.join(VAR, "%s_%s.o" % (os.path.splitext(source)[0], name))
+        cmd = [B.HIPCC] + B.FLAGS + ["-D" + f for f in flags.split(",") if f] + ["-x", "hip", "-c", os.path.join(B.CSRC, source), "-o", obj]
         procs.append((name, obj, subprocess.Popen(cmd)))
     for name, obj, p in procs:
         if p.wait() != 0:
