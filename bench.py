@@ -257,7 +257,30 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         ms = float(t[0])
     tree.close()
-    return {"metric": "supervisor-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms,
+    saturated = None
+    if args.trad_saturated_games > n:
+        # 1 792 games are exactly the wavefronts the chip holds (7 per CU: the evaluator states fill the LDS), so that launch lasts as long as
+        # its slowest game; with four times the games the workgroups that finish early are replaced: the search rate without that wait
+        ns = args.trad_saturated_games
+        big = G.TraditionalMCTS(ns, node_capacity=args.trad_nodes, c_puct=5.0)
+        big.set_positions(trad_positions(G, ns, rank * ns))
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        big.run(P, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_s = e0.elapsed_time(e1)
+        if distributed:
+            t = torch.tensor([ms_s], dtype=torch.float64, device=REDUCE_DEVICE or dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ms_s = float(t[0])
+        big.close()
+        saturated = {"value": ns * world * P / (ms_s * 1e-3), "unit": "playouts/s", "ms_per_search": ms_s, "games_per_gpu": ns,
+                     "note": "four workgroups queued per CU: a finished game's wavefront slot is refilled by the dispatcher"}
+    return {"metric": "supervisor-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_search": ms, "saturated": saturated,
             "config": {"workload": "pattern-guided MCTS (K6, TraditionalPolicy c_puct=5), %d games x %d playouts per GPU, 12-ply clustered openings, fresh roots" % (n, P),
                        "nodes_per_game_mean": float(st["n_nodes"].mean()), "evaluator_updates_per_playout": float((st["evaluator_updates"].astype(np.float64) - updates_before).mean()) / P,
                        "games_stopped_at_node_capacity": int((st["status"] & 1).sum())},
@@ -549,6 +572,7 @@ def parse_args(argv=None):
     ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
+    ap.add_argument("--trad-saturated-games", type=int, default=7168, help="games per GPU for the saturated-batch K6 figure beside the 1 792-game one; 0 = skip")
     ap.add_argument("--sup-games", type=int, default=3584, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots); 0 = skip")
     ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
     ap.add_argument("--rave-playouts", type=int, default=400)

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-.}" && export TMPDIR=/tmp
 tag=${1:-r01x}
 out=gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
-BENCH="bench.py --steps 50 --warmup 5 --no-cpu-baseline --mcts-reps 1 --az-games 0 --mcts-saturated-games 0 --selfplay-games 0 --sup-games 0"   # K7 is the network (MIOpen kernels): not profiled here
+BENCH="bench.py --steps 50 --warmup 5 --no-cpu-baseline --mcts-reps 1 --az-games 0 --mcts-saturated-games 0 --selfplay-games 0 --sup-games 0 --trad-saturated-games 0"   # K7 is the network (MIOpen kernels): not profiled here
 echo "[profile] kernel trace"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace -o t --output-format csv -- python3 $BENCH > $out/trace.log 2>&1 || { echo "trace failed"; tail -5 $out/trace.log; exit 1; }
 i=0
@@ -13,7 +13,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
            "SQ_INSTS_BRANCH SQ_INSTS_SMEM GRBM_GUI_ACTIVE" "SQ_THREAD_CYCLES_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8"; do
   i=$((i+1))
   echo "[profile] pmc pass $i: $grp"
-  timeout -k 10 400 rocprofv3 --pmc $grp -d $out/pmc_$i -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --mcts-reps 1 --no-cpu-baseline --az-games 0 --mcts-saturated-games 0 --selfplay-games 0 --sup-games 0 --settle-ms 0 > $out/pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/pmc_$i.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --pmc $grp -d $out/pmc_$i -o p --output-format csv -- python3 bench.py --steps 5 --warmup 2 --mcts-reps 1 --no-cpu-baseline --az-games 0 --mcts-saturated-games 0 --selfplay-games 0 --sup-games 0 --trad-saturated-games 0 --settle-ms 0 > $out/pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/pmc_$i.log; exit 1; }
 done
 find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 # K9 (the fused network trunk) on its own: kernel stats and the matrix-core counters
