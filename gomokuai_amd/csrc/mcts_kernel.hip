@@ -231,9 +231,20 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     // interleaves (inside `if (i < n_child)` they ran one behind the other); a slot without a child scores explore / 1
                     double score[15];
                     if (__ballot(noisy) == 0ull) {
+                        // explore / (n + 1) depends on the child's visit count only, and nearly all children of a node have few visits: lane
+                        // l16 of the game's quarter computes the quotient for n = l16 ONCE, a child with n < 16 fetches it from that lane (two
+                        // ds_bpermute), the few others divide as before -- the same division on the same operands either way, bit for bit
+                        const double by_visits = explore / static_cast<double>(l16 + 1);
+                        const int quarter_base = (lane & 48) << 2;          // byte address of the quarter's lane 0 for ds_bpermute
+                        const int lo = __double2loint(by_visits), hi = __double2hiint(by_visits);
 #pragma unroll
-                        for (int j = 0; j < 15; ++j)
-                            score[j] = static_cast<double>(__uint_as_float(st[j].y)) + explore / static_cast<double>(st[j].x + 1u);
+                        for (int j = 0; j < 15; ++j) {
+                            const uint32_t n_j = st[j].x;
+                            const int from = quarter_base + 4 * static_cast<int>(min(n_j, 15u));
+                            double bonus = __hiloint2double(__builtin_amdgcn_ds_bpermute(from, hi), __builtin_amdgcn_ds_bpermute(from, lo));
+                            if (n_j >= 16u) bonus = explore / static_cast<double>(n_j + 1u);
+                            score[j] = static_cast<double>(__uint_as_float(st[j].y)) + bonus;
+                        }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 15; ++j) {
