@@ -734,7 +734,24 @@ def main():
     # of device time first (reported in the line), then the W warm-up steps, then the timed K; no gap between them is long enough
     # (> ~2 ms) to send the governor back.
     settle = {"ms": 0.0, "launches": 0}
+    cold_ms = None
     if args.settle_ms > 0:
+        # (for the record, the same measurement WITHOUT settling first: W warm-up steps from idle, then K timed steps)
+        for _ in range(args.warmup):
+            step()
+        if graph is not None:
+            graph.replay()
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                step()
+        c1.record()
+        torch.cuda.synchronize()
+        cold_ms = c0.elapsed_time(c1) / args.steps
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record()
         while True:
@@ -841,7 +858,11 @@ def main():
                          "traffic": measured_traffic("eval_positions_kernel", "boards_per_launch", n),
                          "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes of this kernel; not re-measured in this run)",
                          "kernel": "eval_positions_kernel", "kernel_ms": kernel_ms,
-                         "alg_bytes_per_launch": ALG_BYTES_PER_EVAL * n},
+                         "alg_bytes_per_launch": ALG_BYTES_PER_EVAL * n,
+                         "without_settling": None if cold_ms is None else {
+                             "kernel_ms": cold_ms, "frac": ALG_BYTES_PER_EVAL * n / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "this rank, the same W warm-up + K timed steps straight after the idle spell of the set-up, before config.settle: "
+                                     "the K steps then fall into the clock governor's dip (profiles/r03_ramp.txt)"}},
         }
         if mcts is not None:
             out["secondary"] = mcts
