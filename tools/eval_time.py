@@ -9,6 +9,15 @@ from gomokuai_amd import lib as G
 torch.cuda.set_device(0); G.init(0)
 n = int(os.environ.get("GMK_EVAL_BOARDS", "65536"))
 _, _, planes = G.synth_boards(n, int(os.environ.get("GMK_EVAL_KIND", "0")))
+if os.environ.get("GMK_EVAL_STRATIFY"):
+    # diagnostic: the boards dealt to the 256 workgroup ranges like cards, in order of their stone count: every workgroup gets the same mix
+    # (what is left of the kernel's time against the natural order is what uneven workgroup sums cost)
+    stones = np.unpackbits(planes.view(np.uint8).reshape(n, -1), axis=1).sum(1)
+    order = np.argsort(stones, kind="stable")
+    w = 256
+    dealt = np.empty(n, dtype=np.int64)
+    dealt[(np.arange(n) % w) * (n // w) + np.arange(n) // w] = order
+    planes = planes[dealt]
 dev = torch.device("cuda", 0)
 d_planes = torch.from_numpy(planes.view(np.int16).reshape(n, 32)).to(dev)
 d_scores = torch.empty((n, 900), dtype=torch.int32, device=dev)
