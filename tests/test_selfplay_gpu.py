@@ -434,3 +434,14 @@ def test_persistent_supervisor_loop_plays_the_games_of_the_all_at_once_loop(orac
     assert legal.all() and (end_ply == a.lens.numpy()).all() and (winner == a.winner.numpy()).all()
     with pytest.raises(ValueError):
         selfplay.play_supervisor_games(4, 10, device_loop="persistent", reuse_subtree=True)
+
+
+def test_supervisor_loop_stops_after_max_steps():
+    """max_steps (the throughput measurements' switch, lock-step form of the device loop): after that many moves per slot the loop ends, games
+    still running keep the moves they have (winner 0), and those moves are the first moves of the whole games."""
+    whole = selfplay.play_supervisor_games(6, 50, opening_plies=2, first_game_id=9, device_loop="lockstep").cpu()
+    cut = selfplay.play_supervisor_games(6, 50, opening_plies=2, first_game_id=9, device_loop="lockstep", max_steps=3).cpu()
+    assert (cut.lens == 5).all() and (cut.winner == 0).all()
+    assert (cut.moves[:, :5] == whole.moves[:, :5]).all() and (cut.visits[:, :5] == whole.visits[:, :5]).all()
+    with pytest.raises(ValueError):
+        selfplay.play_supervisor_games(2, 10, device_loop=False, max_steps=3)
