@@ -573,7 +573,7 @@ def parse_args(argv=None):
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
     ap.add_argument("--trad-saturated-games", type=int, default=7168, help="games per GPU for the saturated-batch K6 figure beside the 1 792-game one; 0 = skip")
-    ap.add_argument("--sup-games", type=int, default=3584, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots); 0 = skip")
+    ap.add_argument("--sup-games", type=int, default=7168, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots); 0 = skip")
     ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
     ap.add_argument("--rave-playouts", type=int, default=400)
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which `--gpus N` without a launcher stops its rank processes")
