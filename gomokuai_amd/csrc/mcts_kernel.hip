@@ -7,11 +7,12 @@
 // that visit counts and Q are bit-identical to the CPU restatement under the shared Philox stream.
 //
 // Mapping onto CDNA4
-//   * one 64-lane wavefront (= one workgroup) owns G = 64 / c_rollouts games (12 for the default 5) for
-//     the whole search: all `playouts` iterations run inside ONE launch, no host round trips;
+//   * one 64-lane wavefront (= one workgroup) owns G <= 4 games (gmk_mcts_create: as many as keep two wavefronts per SIMD busy; two for
+//     BASELINE configs[2]'s 4 096 games) for the whole search: all `playouts` iterations run inside ONE launch, no host round trips; in the
+//     persistent self-play form (SearchParams::persistent) the launch also steps the games and plays them to their end, turn by turn;
 //   * tree phases (select / expand / backup) give each game a quarter-wave (16 lanes = one DPP row): the
-//     <= 225 children of a node are scored 16 at a time with f64 PUCB and reduced with row shuffles, four
-//     games proceed concurrently per wave so that their dependent HBM loads overlap;
+//     <= 225 children of a node are scored 16 at a time with f64 PUCB (the bonus explore / (n + 1) from a per-level table for n < 16) and
+//     reduced with row shuffles, four games proceed concurrently per wave so that their dependent HBM loads overlap;
 //   * the simulate phase gives every ROLLOUT a lane: lane = (game, rollout); each lane plays its random
 //     game on a private bit-board kept in LDS (column layout [row][lane]: conflict-free), draws come from
 //     Philox4x32-10 keyed by (seed; game, playout, root stones << 8 | rollout, ply >> 3), eight 16-bit draws per block;
