@@ -56,8 +56,8 @@ __device__ __forceinline__ void place_stone(uint32_t* lines, uint32_t cell, uint
     const uint32_t y = cell / 15u, x = cell - 15u * y;
     atomicOr(&lines[y], 1u << (x + shift));
     atomicOr(&lines[kColBase + x], 1u << (y + shift));
-    atomicOr(&lines[kDiagBase + x - y + 14], 1u << (min(x, y) + shift));
-    atomicOr(&lines[kAntiBase + x + y], 1u << (min(14u - x, y) + shift));
+    atomicOr(&lines[kDiagBase + x - y + 14], 1u << (x + shift));
+    atomicOr(&lines[kAntiBase + x + y], 1u << (x + shift));
 }
 
 __global__ __launch_bounds__(64 * kWaves, 4)
