@@ -213,16 +213,18 @@ void rave_playouts_kernel(RaveParams prm) {
         if (lane == 0) s_ply[wave] = rollout ? ply : -1;
         if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
         __syncthreads();
-        // ---- Default::RandomRollout for the games of the workgroup, one lane each; a finished game stays in its `lines` ----
+        // ---- Default::RandomRollout for the games of the workgroup, four lanes each; a finished game stays in its `lines` ----
         if (wave == roll_wave) {
             int no_tie_before = 224;                            // the first ply at which one of the boards can fill up (wave-uniform)
             for (int g = 0; g < kWaves; ++g)
                 if (s_ply[g] >= 0) no_tie_before = min(no_tie_before, 224 - s_ply[g]);
             no_tie_before = __builtin_amdgcn_readfirstlane(no_tie_before);
-            if (lane < kWaves) {
-                const int stones = s_ply[lane];
-                if (stones >= 0)
-                    s_winner[lane] = random_rollout_blocks(s_mem[lane], 1u, (stones & 1) ? -1 : 1, stones, no_tie_before, [&](uint32_t b) { return s_cells[lane][b]; });
+            if (lane < 4 * kWaves) {                            // four lanes per rollout, one line direction each (random_rollout_quads)
+                const int g = lane >> 2, stones = s_ply[g];
+                if (stones >= 0) {
+                    const int winner = random_rollout_quads(s_mem[g], 1u, (stones & 1) ? -1 : 1, stones, no_tie_before, [&](uint32_t b) { return s_cells[g][b]; });
+                    if ((lane & 3) == 0) s_winner[g] = winner;
+                }
             }
         }
         __syncthreads();
