@@ -116,6 +116,18 @@ __device__ __forceinline__ void row_best(double& best, int& best_i) {   // rotat
     best_i = take ? oi : best_i;
 }
 
+// the better of the two DPP rows of a half-wavefront, in all of its lanes: v_permlane16_swap hands every lane the even row's and the odd
+// row's value of its pair of rows (gfx950)
+__device__ __forceinline__ void rows_best(double& best, int& best_i) {
+    auto swap = [](unsigned v) { return __builtin_amdgcn_permlane16_swap(v, v, false, false); };
+    const auto lo = swap(static_cast<unsigned>(__double2loint(best))), hi = swap(static_cast<unsigned>(__double2hiint(best))), ix = swap(static_cast<unsigned>(best_i));
+    const double even = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0])), odd = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+    const int even_i = static_cast<int>(ix[0]), odd_i = static_cast<int>(ix[1]);
+    const bool take_odd = odd > even || (odd == even && odd_i < even_i);
+    best = take_odd ? odd : even;
+    best_i = take_odd ? odd_i : even_i;
+}
+
 __device__ __forceinline__ int row_scan(int v) {                        // inclusive prefix sum over the row (row_shr, zero fill)
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
@@ -190,10 +202,13 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     for (int playout = 0; playout < prm.playouts; ++playout) {
         if (lane < kMaxGamesPerBlock) s_sum[lane] = 0;
 
-        // ---- select: quarter-wave per game, descend to a leaf (MCTS.cpp:160-163) ----
-        for (int round = 0; round < rounds; ++round) {
-            const int gs = round * 4 + quarter;
-            if (gs < games_here && s_active[gs]) {
+        // ---- select: descend to a leaf (MCTS.cpp:160-163), a quarter-wave per game -- or half a wavefront per game when the wavefront has two
+        //      games at most (W = 32: eight children a lane instead of fifteen; the board rows and the bonus table are kept by both of the
+        //      half's DPP rows, the same values twice.  All 64 lanes for a wavefront's only game: 3 % on a one-game search, not kept) ----
+        auto descend = [&](auto width_tag, const int gs) {
+            constexpr int W = decltype(width_tag)::value, kPerLane = (225 + W - 1) / W;
+            const int lw = lane & (W - 1);
+            {
                 const size_t base = static_cast<size_t>(game0 + gs) * cap;
                 uint32_t row = s_root_rows[gs][l16];                 // lane y holds row y of the board
                 const uint32_t root = s_root[gs];
@@ -220,17 +235,17 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     // all of this lane's children (i = l16, l16 + 16, ...: at most 15) are fetched before any is scored, so
                     // the loads overlap instead of queueing behind each other's f64 divide; their link words come with them:
                     // the chosen child's is then at hand and the next level starts without a dependent load of its own
-                    uint2 st[15];
-                    uint32_t lk[15];
+                    uint2 st[kPerLane];
+                    uint32_t lk[kPerLane];
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) {
-                        const int i = l16 + 16 * j;
+                    for (int j = 0; j < kPerLane; ++j) {
+                        const int i = lw + W * j;
                         st[j] = (i < n_child) ? stats[base + first + i] : make_uint2(0u, 0u);
                         lk[j] = (i < n_child) ? link[base + first + i] : 0u;
                     }
                     // the scores of all fifteen first, without a branch: fifteen independent f64 divide chains that the scheduler
                     // interleaves (inside `if (i < n_child)` they ran one behind the other); a slot without a child scores explore / 1
-                    double score[15];
+                    double score[kPerLane];
                     if (__ballot(noisy) == 0ull) {
                         // explore / (n + 1) depends on the child's visit count only, and nearly all children of a node have few visits: lane
                         // l16 of the game's quarter computes the quotient for n = l16 ONCE, a child with n < 16 fetches it from that lane (two
@@ -239,7 +254,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         const int quarter_base = (lane & 48) << 2;          // byte address of the quarter's lane 0 for ds_bpermute
                         const int lo = __double2loint(by_visits), hi = __double2hiint(by_visits);
 #pragma unroll
-                        for (int j = 0; j < 15; ++j) {
+                        for (int j = 0; j < kPerLane; ++j) {
                             const uint32_t n_j = st[j].x;
                             const int from = quarter_base + 4 * static_cast<int>(min(n_j, 15u));
                             double bonus = __hiloint2double(__builtin_amdgcn_ds_bpermute(from, hi), __builtin_amdgcn_ds_bpermute(from, lo));
@@ -248,16 +263,16 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         }
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 15; ++j) {
-                            const int i = l16 + 16 * j;
+                        for (int j = 0; j < kPerLane; ++j) {
+                            const int i = lw + W * j;
                             double bonus = explore;
                             if (noisy && i < n_child) bonus = prm.c_puct * static_cast<double>(root_prior[static_cast<size_t>(game0 + gs) * 225 + i]) * root_n;
                             score[j] = static_cast<double>(__uint_as_float(st[j].y)) + bonus / static_cast<double>(st[j].x + 1u);
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) {
-                        const int i = l16 + 16 * j;
+                    for (int j = 0; j < kPerLane; ++j) {
+                        const int i = lw + W * j;
                         const bool take = i < n_child && score[j] > best;
                         best = take ? score[j] : best;
                         best_i = take ? i : best_i;
@@ -268,12 +283,13 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                     // first maximum wins (strict > in ascending order): (score, -index) is a total order, so rotating the
                     // row of 16 lanes by 8, 4, 2, 1 leaves the same winner in every lane - DPP moves, no LDS permute
                     row_best<8>(best, best_i); row_best<4>(best, best_i); row_best<2>(best, best_i); row_best<1>(best, best_i);
+                    if constexpr (W == 32) rows_best(best, best_i);           // ... and the better of the half's two rows
                     bytes += static_cast<unsigned long long>(n_child) * 8ull;
                     cur = first + static_cast<uint32_t>(best_i);
-                    // the statistics of the chosen child sit in the lane that scored it (children i = l16 mod 16)
-                    cur_stats.x = __shfl(best_st.x, best_i & 15, 16);
-                    cur_stats.y = __shfl(best_st.y, best_i & 15, 16);
-                    cur_link = __shfl(best_link, best_i & 15, 16);
+                    // the statistics of the chosen child sit in the lane that scored it (children i = lane mod W)
+                    cur_stats.x = __shfl(best_st.x, best_i & (W - 1), W);
+                    cur_stats.y = __shfl(best_st.y, best_i & (W - 1), W);
+                    cur_link = __shfl(best_link, best_i & (W - 1), W);
                     // its cell = the best_i-th empty cell of the current position in ascending order (children are created
                     // that way, MonteCarlo.hpp:71-80): no dependent load of link[]
                     {
@@ -307,7 +323,15 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                         atomicOr(&s_leaf[gs][kAntiBase + x + y], 1u << (x + cb));
                     }
                 }
-                if (l16 == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; s_depth[gs] = depth; s_leaf_link[gs] = cur_link; }
+                if (lw == 0) { s_cur[gs] = cur; s_ply[gs] = ply; s_last[gs] = last; s_bytes[gs] += bytes; s_depth[gs] = depth; s_leaf_link[gs] = cur_link; }
+            }
+        };
+        if (G <= 2) {
+            if ((lane >> 5) < games_here && s_active[lane >> 5]) descend(std::integral_constant<int, 32>{}, lane >> 5);
+        } else {
+            for (int round = 0; round < rounds; ++round) {
+                const int gs = round * 4 + quarter;
+                if (gs < games_here && s_active[gs]) descend(std::integral_constant<int, 16>{}, gs);
             }
         }
         __syncthreads();
