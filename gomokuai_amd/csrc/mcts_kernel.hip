@@ -360,46 +360,39 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                                                                                        b, prm.seed_lo, prm.seed_hi);
         }
         __syncthreads();
-        // the rollouts: four lanes each (random_rollout_quads) while the wavefront has the lanes for it, one lane each otherwise
+        // the rollouts: four lanes each (random_rollout_quads) while the wavefront has the lanes for it, else two (random_rollout_pairs), else one
         {
             int no_tie_before = 224;                                 // the first ply at which a board of this wavefront can fill up
             for (int g = 0; g < games_here; ++g)
                 if (s_active[g] && s_need[g]) no_tie_before = min(no_tie_before, 224 - static_cast<int>(s_ply[g]));
             no_tie_before = __builtin_amdgcn_readfirstlane(no_tie_before);
-            const bool quads = 4 * n_rollout_lanes <= 64;
-            const int rl = quads ? lane >> 2 : lane, part = quads ? lane & 3 : 0;       // the rollout this lane works on, and its share of it
+            const int share = 4 * n_rollout_lanes <= 64 ? 2 : 2 * n_rollout_lanes <= 64 ? 1 : 0;       // log2 of the lanes per rollout
+            const int rl = lane >> share, part = lane & ((1 << share) - 1), parts = 1 << share;      // the rollout this lane works on, and its share of it
             const int gs = static_cast<int>(div_r(static_cast<uint32_t>(rl)));
             if (rl < n_rollout_lanes && gs < games_here && s_active[gs] && s_need[gs]) {
                 // the leaf's line words into the rollout's position, 23 reads in flight at a time (one by one each copy is a
-                // round trip: the compiler cannot tell that the two regions are apart); a quad's lanes copy a quarter each
+                // round trip: the compiler cannot tell that the two regions are apart); the lanes of a rollout copy a share each
                 static_assert(kLineWords == 4 * 23, "copy batches");
+                for (int w0 = 23 * part; w0 < kLineWords; w0 += 23 * parts) {
+                    uint32_t t[23];
+    #pragma unroll
+                    for (int i = 0; i < 23; ++i) t[i] = s_leaf[gs][w0 + i];
+    #pragma unroll
+                    for (int i = 0; i < 23; ++i) s_lane_lines[(w0 + i) * n_rollout_lanes + rl] = t[i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t ply = s_ply[gs];
                 const int init_player = (ply & 1u) ? -1 : 1;         // black moves on even stone counts
                 const uint2* my_cells = s_cells + rl;
                 auto fetch = [&](uint32_t b) { return my_cells[b * static_cast<uint32_t>(n_rollout_lanes)]; };
-                if (quads) {
-                    uint32_t t[23];
-    #pragma unroll
-                    for (int i = 0; i < 23; ++i) t[i] = s_leaf[gs][part * 23 + i];
-    #pragma unroll
-                    for (int i = 0; i < 23; ++i) s_lane_lines[(part * 23 + i) * n_rollout_lanes + rl] = t[i];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int winner = random_rollout_quads(&s_lane_lines[rl], static_cast<uint32_t>(n_rollout_lanes), init_player, static_cast<int>(ply), no_tie_before, fetch);
-                    if (part == 0) atomicAdd(&s_sum[gs], init_player * winner);          // CalcScore(init_player, winner)
-                } else {
-    #pragma unroll
-                    for (int w0 = 0; w0 < kLineWords; w0 += 23) {
-                        uint32_t t[23];
-    #pragma unroll
-                        for (int i = 0; i < 23; ++i) t[i] = s_leaf[gs][w0 + i];
-    #pragma unroll
-                        for (int i = 0; i < 23; ++i) s_lane_lines[(w0 + i) * n_rollout_lanes + rl] = t[i];
-                    }
-                    const int winner = random_rollout_blocks(&s_lane_lines[rl], static_cast<uint32_t>(n_rollout_lanes), init_player, static_cast<int>(ply), no_tie_before, fetch);
-                    atomicAdd(&s_sum[gs], init_player * winner);         // CalcScore(init_player, winner)
-                }
+                uint32_t* const position = &s_lane_lines[rl];
+                const uint32_t stride = static_cast<uint32_t>(n_rollout_lanes);
+                const int winner = share == 2 ? random_rollout_quads(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch)
+                                 : share == 1 ? random_rollout_pairs(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch)
+                                              : random_rollout_blocks(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch);
+                if (part == 0) atomicAdd(&s_sum[gs], init_player * winner);              // CalcScore(init_player, winner)
             }
         }
         __syncthreads();

@@ -122,8 +122,10 @@ __device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], 
 // (the probe rule needs it), so the move's cell is known to all four without an exchange.
 template <class Fetch>
 __device__ inline int random_rollout_quads(uint32_t* lines /* [word * stride], in LDS */, uint32_t stride, int to_move, int stones, int no_tie_before, Fetch fetch) {
-    const uint32_t sb = 4u * stride;
-    const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lines));
+    uint32_t sb = 4u * stride;
+    uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lines));
+    asm volatile("" : "+v"(sb), "+v"(base));                       // opaque: what derives from them is computed here, per call (hoisted out of the caller's
+                                                                   // loop it would live in registers the caller does not have, i.e. in scratch)
     const uint32_t d = threadIdx.x & 3u;
     // this lane's line of a move at (x, y): word c0 + ax * x + ay * y, stone bit = y for the column, x otherwise
     int line0 = static_cast<int>(base + (d == 0u ? 0u : d == 1u ? kColBase : d == 2u ? kDiagBase + 14u : kAntiBase) * sb);
@@ -165,6 +167,71 @@ __device__ inline int random_rollout_quads(uint32_t* lines /* [word * stride], i
                 uint32_t fives = h4 & (h >> 4);
                 fives |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(fives), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
                 fives |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(fives), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+                if (fives != 0u) won = 2u | static_cast<uint32_t>(j & 1);
+                live = fives == 0u && (!kTie || static_cast<int>(8u * b) + j != last_ply);
+            }
+            if ((j & 3) == 3 && __ballot(live) == 0ull) return true;
+        }
+        return false;
+    };
+    for (uint32_t b = 0;; ++b) {
+        const uint2 ahead = fetch(b + 1u);
+        const bool over = static_cast<int>(8u * b) + 7 < no_tie_before ? play_block(std::false_type{}, b, ahead) : play_block(std::true_type{}, b, ahead);
+        if (over) return won ? ((won & 1u) ? -to_move : to_move) : 0;
+        cur = ahead;
+    }
+}
+
+// ... and on TWO lanes (an aligned pair, both called with the same arguments), for wavefronts whose rollouts leave no room for quads: the even
+// lane keeps the row and the column through the move's cell, the odd lane the diagonal and the anti-diagonal; two addresses, two reads, two
+// writes and one run test (both words' mover halves side by side) per lane and ply, one DPP instruction for the pair's verdict: ~31
+// instructions a ply.
+template <class Fetch>
+__device__ inline int random_rollout_pairs(uint32_t* lines /* [word * stride], in LDS */, uint32_t stride, int to_move, int stones, int no_tie_before, Fetch fetch) {
+    uint32_t sb = 4u * stride;
+    uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lines));
+    asm volatile("" : "+v"(sb), "+v"(base));                       // opaque, as in random_rollout_quads
+    const bool odd = (threadIdx.x & 1u) != 0u;
+    // this lane's two lines of a move at (x, y): first = row | diagonal (stone bit x), second = column (bit y) | anti-diagonal (bit x)
+    int first0 = static_cast<int>(base + (odd ? (kDiagBase + 14u) * sb : 0u)), second0 = static_cast<int>(base + (odd ? kAntiBase : kColBase) * sb);
+    int first_x = odd ? static_cast<int>(sb) : 0, first_y = odd ? -static_cast<int>(sb) : static_cast<int>(sb), second_y = odd ? static_cast<int>(sb) : 0;
+    asm volatile("" : "+v"(first0), "+v"(second0), "+v"(first_x), "+v"(first_y), "+v"(second_y));
+    const uint32_t stone_even = to_move > 0 ? 1u : 0x10000u, stone_odd = stone_even ^ 0x10001u;
+    const uint32_t halves_even = to_move > 0 ? 0x05040100u : 0x07060302u, halves_odd = halves_even ^ 0x02020202u;
+    const int last_ply = 224 - stones;
+    uint32_t won = 0;
+    bool live = true;
+    uint2 cur = fetch(0u);
+    uint32_t rw_ahead = *lds_at(base + __umul24(cur.x & 15u, sb));
+    auto play_block = [&](auto tie_tag, uint32_t b, const uint2 ahead) -> bool {
+        constexpr bool kTie = decltype(tie_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (live) {                                             // pair-uniform
+                const uint32_t cw = j < 4 ? cur.x : cur.y, cw_next = j + 1 < 4 ? cur.x : j + 1 < 8 ? cur.y : ahead.x;
+                uint32_t y = (cw >> (8 * (j & 3))) & 15u, x = (cw >> (8 * (j & 3) + 4)) & 15u;
+                const uint32_t y_next = (cw_next >> (8 * ((j + 1) & 3))) & 15u;
+                uint32_t rw = rw_ahead;
+                uint32_t open = ~(rw | (rw >> 16)) & 0x7FFFu & (0x7FFFu << x);
+                while (!open) {                                     // linear probe with wrap (Board::getRandomMove, Game.cpp:64-73)
+                    y = (y == 14u) ? 0u : y + 1u;
+                    rw = *lds_at(base + __umul24(y, sb));
+                    open = ~(rw | (rw >> 16)) & 0x7FFFu;
+                }
+                x = static_cast<uint32_t>(__ffs(open)) - 1u;
+                const uint32_t first_at = static_cast<uint32_t>(__mul24(static_cast<int>(x), first_x) + __mul24(static_cast<int>(y), first_y) + first0);
+                const uint32_t second_at = static_cast<uint32_t>(static_cast<int>(__umul24(x, sb)) + __mul24(static_cast<int>(y), second_y) + second0);
+                const uint32_t stone = (j & 1) ? stone_odd : stone_even, halves = (j & 1) ? halves_odd : halves_even;
+                const uint32_t first_old = *lds_at(first_at), second_old = *lds_at(second_at);
+                const uint32_t next_row = *lds_at(base + __umul24(y_next, sb));
+                const uint32_t put = stone << x;
+                const uint32_t first_new = first_old | put, second_new = second_old | (odd ? put : stone << y);
+                *lds_at(first_at) = first_new; *lds_at(second_at) = second_new;
+                rw_ahead = y_next == y ? (rw | put) : next_row;
+                const uint32_t both = __builtin_amdgcn_perm(second_new, first_new, halves);          // the mover's halves; bits 15 and 31 are gaps
+                const uint32_t b2 = both & (both >> 1), b4 = b2 & (b2 >> 2);
+                uint32_t fives = b4 & (both >> 4);
+                fives |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(fives), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]: the pair's other lane
                 if (fives != 0u) won = 2u | static_cast<uint32_t>(j & 1);
                 live = fives == 0u && (!kTie || static_cast<int>(8u * b) + j != last_ply);
             }
