@@ -48,9 +48,10 @@ extern "C" int gmk_init(int device) {
     st.emit_words = static_cast<int>(t.emit_lists.size());
     st.n_records = t.n_records;
     GMK_HIP_CHECK(hipMalloc(&st.d_trans, t.dev_trans.size() * sizeof(uint32_t)));
-    GMK_HIP_CHECK(hipMalloc(&st.d_records, t.dev_records.size() * sizeof(uint32_t)));
+    GMK_HIP_CHECK(hipMalloc(&st.d_records, (t.dev_records.size() + gmk::kPrefixWords) * sizeof(uint32_t)));      // the records, then dev_prefix4
     GMK_HIP_CHECK(hipMemcpy(st.d_trans, t.dev_trans.data(), t.dev_trans.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     GMK_HIP_CHECK(hipMemcpy(st.d_records, t.dev_records.data(), t.dev_records.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(st.d_records + t.dev_records.size(), t.dev_prefix4.data(), gmk::kPrefixWords * sizeof(uint32_t), hipMemcpyHostToDevice));
     st.ready = true;
     return GMK_OK;
 }

@@ -19,7 +19,7 @@ struct DeviceState {
     int device = -1;
     int cu_count = 0;
     uint32_t* d_trans = nullptr;        // n_states*4 words, device form (DeviceTables::dev_trans)
-    uint32_t* d_records = nullptr;      // 4 words per emission record (DeviceTables::dev_records)
+    uint32_t* d_records = nullptr;      // 4 words per emission record (DeviceTables::dev_records), then kPrefixWords words of DeviceTables::dev_prefix4
     int n_states = 0, n_patterns = 0, emit_words = 0, n_records = 0;
 };
 DeviceState& device_state();

@@ -51,6 +51,7 @@ struct Ctx {
     uint32_t* scratch;           // results[2][4][kResultCap][2] + count[2][4]
     const char* trans;           // device transition words (pattern_tables.h)
     const uint4* rec;            // emission records
+    const char* prefix;          // DeviceTables::dev_prefix4 (in LDS, behind the records)
     int lane;
     unsigned long long* prof = nullptr;      // profiling aid (GMK_EVS_PROFILE): cycles per phase of update_move, summed by lane 0
     int phases = 0x3F;                       // profiling aid (GMK_EVS_PHASE_MASK, K2 only): bit p runs phase p of update_move (match, compounds -, patterns -,
@@ -107,8 +108,9 @@ __device__ __forceinline__ uint64_t window_symbols(const uint32_t* lines, int ce
 // centre -> result set 1).  Only transitions at window indices 6..12 can report a match that covers the centre, and the
 // automaton forgets where it started after 7 symbols (checked for all 556 states x 4^7 strings when the tables are
 // built, PatternAutomaton::flatten), so every such transition gets its own lane: lane = (window * 4 + direction) * 7 +
-// (k - 6) starts at the root at index max(0, k - 7) and is at the right state after at most 7 lookups.  A chain of 8
-// dependent LDS reads instead of 13; the order of the results does not matter (every update they feed commutes).
+// (k - 6) starts at the root at index max(0, k - 7) and is at the right state after at most 7 lookups -- of which the first four
+// (from the root, their reports unused) are ONE lookup in dev_prefix4.  A chain of 5 dependent LDS reads instead of 13; the order of
+// the results does not matter (every update they feed commutes).
 __device__ inline void match_patterns_both(const Ctx& c, int move, uint32_t new_sym) {
     if (c.lane < 8) c.scratch[oResultCount + c.lane] = 0u;
     wave_phase_fence();
@@ -117,14 +119,16 @@ __device__ inline void match_patterns_both(const Ctx& c, int move, uint32_t new_
         uint64_t syms = window_symbols(c.st + oLines, move, dir);
         if (w) syms = (syms & ~(3ull << 12)) | (static_cast<uint64_t>(new_sym) << 12);
         const int start = k > 7 ? k - 7 : 0;
-        uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0, tw7 = 0;        // symbol * 4 in bits 2..3, as in eval_kernel.hip
+        const uint32_t stream = static_cast<uint32_t>(syms >> (2 * start));
+        uint32_t tw = *reinterpret_cast<const uint16_t*>(c.prefix + 2u * (stream & 0xFFu)), tw_before = 0;   // the first four symbols: one lookup (dev_prefix4)
+        uint32_t cur = (stream >> 8) << 2;                        // symbol * 4 in bits 2..3, as in eval_kernel.hip
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {                             // eight lookups for everybody; the lane of index 6 stops after seven
-            if (i == 7) tw7 = tw;
+        for (int i = 0; i < 4; ++i) {                             // four more for everybody; the lane of index 6 stops after three
+            if (i == 3) tw_before = tw;
             tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
             cur >>= 2;
         }
-        if (k == 6) tw = tw7;
+        if (k == 6) tw = tw_before;
         const uint32_t rid = gmk::dev_trans_record(tw);
         if (rid) {
             uint32_t* out = c.scratch + (w * 4 + dir) * kResultCap * 2;
@@ -266,14 +270,16 @@ __device__ inline void apply_compound_items(const Ctx& c, int delta) {
             const int want = ct == 0 ? 5 : ct == 1 ? 4 : 3;
             const uint64_t syms = window_symbols(c.st + oLines, cell, cdir);
             const int start = k > 7 ? k - 7 : 0;
-            uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0, tw7 = 0;
+            const uint32_t stream = static_cast<uint32_t>(syms >> (2 * start));
+            uint32_t tw = *reinterpret_cast<const uint16_t*>(c.prefix + 2u * (stream & 0xFFu)), tw_before = 0;   // as in match_patterns_both
+            uint32_t cur = (stream >> 8) << 2;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {                         // eight lookups for everybody; the lane of index 6 stops after seven
-                if (i == 7) tw7 = tw;
+            for (int i = 0; i < 4; ++i) {
+                if (i == 3) tw_before = tw;
                 tw = *reinterpret_cast<const uint32_t*>(c.trans + (gmk::dev_trans_row(tw) | (cur & 12u)));
                 cur >>= 2;
             }
-            if (k == 6) tw = tw7;
+            if (k == 6) tw = tw_before;
             if ((gmk::dev_trans_kinds(tw) >> ct) & 1u) {
                 const uint4 r = c.rec[gmk::dev_trans_record(tw)];
                 const uint32_t w0s[2] = {r.x, r.z};

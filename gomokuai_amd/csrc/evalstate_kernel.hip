@@ -20,7 +20,7 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
                              const uint32_t* __restrict__ g_trans, const uint32_t* __restrict__ g_records, int trans_words, int record_words,
                              unsigned long long* prof /* profiling aid, normally null: 8 counters per game */, int phases /* profiling aid: 0x3F */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // layout: [games: kGamesPerBlock * (kStateWords + kScratchWords rounded)] [trans] [records]
+    // layout: [games: kGamesPerBlock * (kStateWords + kScratchWords rounded)] [trans] [records, then the four-symbol prefix table: record_words counts both]
     constexpr int kPerGame = (kStateWords + kScratchWords + 16 + 3) & ~3;     // + 8 profiling counters
     uint32_t* s_trans = lds + kGamesPerBlock * kPerGame;
     for (int i = threadIdx.x; i < trans_words + record_words; i += kThreads) s_trans[i] = i < trans_words ? g_trans[i] : g_records[i - trans_words];
@@ -44,7 +44,8 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
     }
     __syncthreads();
     if (game >= n_games) return;
-    Ctx c{st, st + kStateWords, reinterpret_cast<const char*>(s_trans), reinterpret_cast<const uint4*>(s_trans + trans_words), lane,
+    Ctx c{st, st + kStateWords, reinterpret_cast<const char*>(s_trans), reinterpret_cast<const uint4*>(s_trans + trans_words),
+          reinterpret_cast<const char*>(s_trans + trans_words + record_words - gmk::kPrefixWords), lane,
           prof ? reinterpret_cast<unsigned long long*>(st + kStateWords + kScratchWords) : nullptr, phases};
     if (prof && lane < 16) st[kStateWords + kScratchWords + lane] = 0u;
     // the script 64 steps at a time, one step per lane, handed out with v_readlane: a load per step would put a trip to memory in
@@ -107,7 +108,7 @@ extern "C" int gmk_evalstate_update(gmk_evalstate* e, const int16_t* d_moves, in
     if (!e || !d_moves || moves_per_game < 0) { gmk::set_error("gmk_evalstate_update: bad arguments"); return GMK_ERR_ARG; }
     if (moves_per_game == 0) return GMK_OK;
     constexpr int kPerGame = (kStateWords + kScratchWords + 16 + 3) & ~3;
-    const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4) * 4;
+    const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4 + gmk::kPrefixWords) * 4;
     if (!e->attr_set) {
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(evalstate_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         e->attr_set = true;
@@ -121,7 +122,7 @@ extern "C" int gmk_evalstate_update(gmk_evalstate* e, const int16_t* d_moves, in
         GMK_HIP_CHECK(hipMemset(d_prof, 0, static_cast<size_t>(e->n_games) * 8 * sizeof(unsigned long long)));
     }
     hipLaunchKernelGGL(evalstate_update_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), e->d_states, d_moves,
-                       moves_per_game, e->n_games, st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4, d_prof, phases);
+                       moves_per_game, e->n_games, st.d_trans, st.d_records, st.n_states * 4, st.n_records * 4 + gmk::kPrefixWords, d_prof, phases);
     GMK_HIP_CHECK(hipGetLastError());
     if (profile) {                                              // cycles per phase of Updater::updateMove, mean over games
         std::vector<unsigned long long> h(static_cast<size_t>(e->n_games) * 8);

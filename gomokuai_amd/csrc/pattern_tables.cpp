@@ -346,6 +346,12 @@ void PatternAutomaton::flatten() {
         dev_.dev_trans[i] = (next * 16u) | (kinds << 14) | (rec << 17);
     }
     dev_.n_records = static_cast<int>(dev_.dev_records.size() / 4);
+    dev_.dev_prefix4.assign(256, 0);
+    for (uint32_t idx = 0; idx < 256; ++idx) {
+        uint32_t row = 0;                                          // byte offset of the root's row
+        for (int i = 0; i < 4; ++i) row = dev_trans_row(dev_.dev_trans[row / 4 + ((idx >> (2 * i)) & 3u)]);
+        dev_.dev_prefix4[idx] = static_cast<uint16_t>(row);
+    }
 
     // How many symbols until the automaton has forgotten where it started: the image of the full state set under every
     // string of that length is a single state.  The incremental evaluator's window matcher (evalstate_device.h) starts

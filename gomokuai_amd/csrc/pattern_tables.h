@@ -43,6 +43,7 @@ struct Emission { uint16_t pattern; uint8_t back; };
 GMK_TABLE_FN uint32_t dev_trans_row(uint32_t tw) { return tw & 0x3FFFu; }
 GMK_TABLE_FN uint32_t dev_trans_kinds(uint32_t tw) { return (tw >> 14) & 7u; }
 GMK_TABLE_FN uint32_t dev_trans_record(uint32_t tw) { return tw >> 17; }
+constexpr int kPrefixWords = 128;       // DeviceTables::dev_prefix4: 256 entries of 16 bits
 
 struct DeviceTables {
     // trans[state*4 + sym] : bits 0..9 next state, bits 10..19 index into emit_lists (0 = nothing)
@@ -66,6 +67,11 @@ struct DeviceTables {
     //   w1: as pattern_info w1
     std::vector<uint32_t> dev_records;
     int n_records = 0;
+    // dev_prefix4[s0 | s1 << 2 | s2 << 4 | s3 << 6]: byte offset of the row of the state the ROOT reaches over the symbols s0 s1 s2 s3 (the
+    //   value dev_trans_row gives after four lookups).  The incremental evaluator's window matcher starts every lane at the root and only
+    //   uses what its LAST transition reports, so the first four of its dependent lookups are one lookup here (evalstate_device.h).
+    //   Uploaded behind the records (kPrefixWords 32-bit words).
+    std::vector<uint16_t> dev_prefix4;
     int sync_symbols = 0;                // after this many symbols the state no longer depends on the start state (7 for the production table)
     int n_states = 0;
     int n_patterns = 0;

@@ -192,7 +192,7 @@ struct Game {
 __global__ __launch_bounds__(kThreads)
 void trad_playouts_kernel(TradParams prm) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // layout: [trans][records][games: kGamesPerBlock * kPerGame]
+    // layout: [trans][records, then the four-symbol prefix table: record_words counts both][games: kGamesPerBlock * kPerGame]
     for (int i = threadIdx.x; i < prm.trans_words + prm.record_words; i += kThreads)
         lds[i] = i < prm.trans_words ? prm.g_trans[i] : prm.g_records[i - prm.trans_words];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -208,7 +208,8 @@ void trad_playouts_kernel(TradParams prm) {
     if (prm.hdr[game].status & kStatusIdleSlot) return;         // continuous batching: a slot whose games have run out (trad_advance_kernel)
 
     Game g;
-    g.c = Ctx{base, base + kStateWords, reinterpret_cast<const char*>(lds), reinterpret_cast<const uint4*>(lds + prm.trans_words), lane};
+    g.c = Ctx{base, base + kStateWords, reinterpret_cast<const char*>(lds), reinterpret_cast<const uint4*>(lds + prm.trans_words),
+              reinterpret_cast<const char*>(lds + prm.trans_words + prm.record_words - gmk::kPrefixWords), lane};
     g.path_node = base + kStateWords + kScratchWords;
     g.path_link = g.path_node + kPathCap;
     g.record_copy = reinterpret_cast<uint8_t*>(g.path_link + kPathCap);
@@ -961,7 +962,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     if (!t->positioned) { gmk::set_error("gmk_trad_run: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
     if (t->policy == 2) { gmk::set_error("gmk_trad_run: this handle searches with gmk_trad_run_poolrave (its evaluators are not kept in step)"); return GMK_ERR_STATE; }
     t->policy = 1;
-    const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4) * 4;
+    const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4 + gmk::kPrefixWords) * 4;
     if (lds > 160u * 1024u) { gmk::set_error("gmk_trad_run: tables do not fit in LDS (%zu bytes)", lds); return GMK_ERR_CAPACITY; }
     if (!t->attr_set) {
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -970,7 +971,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     TradParams prm;
     prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.front = t->d_front; prm.ord = t->d_ord; prm.hdr = t->d_hdr;
     prm.moves = t->d_moves; prm.lens = t->d_lens;
-    prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
+    prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4 + gmk::kPrefixWords;
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
     prm.selfplay = 0; prm.sp = TradSelfPlay{};
     static const bool profile = gmk::profile_env("GMK_TRAD_PROFILE") != nullptr;
@@ -1196,7 +1197,7 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
         gmk::DeviceState& st = gmk::device_state();
         if (t->policy == 2) { gmk::set_error("gmk_trad_selfplay_run: this handle searches with PoolRAVEPolicy"); cleanup(); return GMK_ERR_STATE; }
         t->policy = 1;
-        const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4) * 4;
+        const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4 + gmk::kPrefixWords) * 4;
         if (!t->attr_set) {
             GMK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             t->attr_set = true;
@@ -1204,7 +1205,7 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
         TradParams prm;
         prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.front = t->d_front; prm.ord = t->d_ord; prm.hdr = t->d_hdr;
         prm.moves = t->d_moves; prm.lens = t->d_lens;
-        prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4;
+        prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4 + gmk::kPrefixWords;
         prm.n_games = n_slots; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
         prm.profile = 0; prm.selfplay = 1; prm.sp = sp;
         hipLaunchKernelGGL(trad_playouts_kernel, dim3((n_slots + kGamesPerBlock - 1) / kGamesPerBlock), dim3(kThreads), lds, s, prm);

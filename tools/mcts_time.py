@@ -2,7 +2,7 @@ import time, numpy as np, sys, os
 sys.path.insert(0,'.')
 from gomokuai_amd import lib as G
 import torch
-n=4096; P=800
+n=int(os.environ.get('N','4096')); P=800
 moves,lens,_=G.synth_boards(n,0)
 lens=np.minimum(lens,4).astype(np.int32)
 planes=G.moves_to_planes(moves,lens)
