@@ -12,6 +12,7 @@
 //     az_expand_kernel      children with the returned priors, value backed up to the root
 // all on one HIP stream (the three steps can be captured in a hipGraph and replayed per playout).
 // Mapping: one wavefront per game, lanes over the (<= 225) children; the tree is an SoA arena per game in HBM.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <random>
@@ -28,12 +29,13 @@ using gmk::five_through;
 
 constexpr int kCells = 225;
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+constexpr uint32_t kStatusOver = 1u;
 
 struct AzHeader {                                // 256 B per game, in HBM
     uint32_t rows[16];                           // root position: black | white << 16 per row
     uint32_t leaf_rows[16];                      // position of the pending leaf
     uint32_t n_nodes, stones, last_move, last_move2;           // cells 0..224, 255 = none
-    uint32_t status;                             // bit 1: node arena full
+    uint32_t status;                             // bit 0: the game is over (az_advance_kernel), bit 1: node arena full, bit 2: a forced step was not a move of the game
     uint32_t leaf, leaf_pending;                 // node waiting for the network's answer (leaf_pending = 1)
     uint32_t leaf_stones;
     uint32_t pad[24];
@@ -48,6 +50,8 @@ struct AzTree {
     uint32_t* parent;                            // [n_games][cap]
     int cap, n_games;
     double c_puct;
+    const int32_t* row_of;                       // [n_games] the row of the leaf batch a game writes to and is answered from: the games still
+                                                 // played, in slot order (az_compact_kernel); finished games have none
 };
 
 // Default::BackPropogate (MonteCarlo.hpp:90-95): one lane walks the parent chain
@@ -66,6 +70,8 @@ void az_select_kernel(AzTree t, float* __restrict__ out_states) {
     const int game = blockIdx.x, lane = threadIdx.x;
     if (game >= t.n_games) return;
     AzHeader* hdr = t.hdr + game;
+    if (hdr->status & kStatusOver) return;                       // the game is over (az_advance_kernel): nothing to search, leaf_pending stays 0
+    const size_t row = static_cast<size_t>(t.row_of[game]);
     const size_t arena = static_cast<size_t>(game) * t.cap;
     uint2* stat = t.stat + arena;
     const uint2* kids = t.kids + arena;
@@ -123,14 +129,14 @@ void az_select_kernel(AzTree t, float* __restrict__ out_states) {
             hdr->leaf_pending = 0;
         }
         if (out_states)
-            for (int i = lane; i < 6 * kCells; i += 64) out_states[static_cast<size_t>(game) * 6 * kCells + i] = 0.0f;
+            for (int i = lane; i < 6 * kCells; i += 64) out_states[row * 6 * kCells + i] = 0.0f;
         return;
     }
     if (lane == 0) { hdr->leaf = node; hdr->leaf_pending = 1; hdr->leaf_stones = static_cast<uint32_t>(stones); }
     if (lane < 16) hdr->leaf_rows[lane] = s_rows[lane];
     // ---- Board.encoded_states (game_ext.hpp:87-104): own stones, opponent's, empties, last move, the one before, colour to move ----
     const int cur_white = stones & 1;
-    float* out = out_states + static_cast<size_t>(game) * 6 * kCells;
+    float* out = out_states + row * 6 * kCells;
     for (int i = lane; i < kCells; i += 64) {
         const uint32_t row = s_rows[i / 15] >> (i % 15);
         const bool black = row & 1u, white = (row >> 16) & 1u;
@@ -149,11 +155,12 @@ void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* _
     if (game >= t.n_games) return;
     AzHeader* hdr = t.hdr + game;
     if (!hdr->leaf_pending) return;
+    const size_t row = static_cast<size_t>(t.row_of[game]);
     const size_t arena = static_cast<size_t>(game) * t.cap;
     const uint32_t leaf = hdr->leaf;
     uint32_t n_nodes = hdr->n_nodes;
     // ---- Default::Expand with extraCheck (MonteCarlo.hpp:71-80): probability not 0 and the cell is free; ascending cell id ----
-    const float* p = probs + static_cast<size_t>(game) * kCells;
+    const float* p = probs + row * kCells;
     float pv[4];
     bool take[4];
     int rank[4], total = 0;
@@ -189,7 +196,7 @@ void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* _
     }
     __threadfence_block();
     if (lane == 0) {
-        backup(t.stat + arena, t.parent + arena, leaf, -values[game]);                  // node_value = -state_value (MCTS.cpp:166-168)
+        backup(t.stat + arena, t.parent + arena, leaf, -values[row]);                  // node_value = -state_value (MCTS.cpp:166-168)
         hdr->leaf_pending = 0;
     }
 }
@@ -198,6 +205,45 @@ void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* _
 // level into the other arena (root at 0, children consecutive); a move without a child starts a new node.  The move is
 // played on the root position.  One wavefront per game.
 struct AzArena { uint2* stat; uint2* kids; float* prior; uint32_t* parent; };
+// Continuous batching (gmk_az_set_slots): the handle's games are SLOTS that play n_total games between them; slot g plays game slot_game[g]
+// (-1: none left), its record goes to that game's rows, and when the game ends the slot takes the next game nobody has started.
+struct AzSlots {
+    int32_t* slot_game;              // [n_slots], null: slot g plays game g and is not refilled
+    int32_t* next_game;              // [1]
+    int n_total;
+    const uint8_t* open_moves;       // [n_total][open_stride] the moves that lead to a game's first root (black first), may be null
+    const int32_t* open_lens;        // [n_total]
+    int open_stride;
+};
+
+// The subtree of node `src` of arena t becomes the tree of arena b: root at 0, children consecutive, level by level.  All 64 lanes of the
+// game's workgroup call it.
+__device__ void az_keep_subtree(const AzTree& t, const AzArena& b, size_t base, uint32_t src, int lane, AzHeader& hdr) {
+    if (lane == 0) { b.stat[base] = t.stat[base + src]; b.kids[base] = t.kids[base + src]; b.prior[base] = t.prior[base + src]; b.parent[base] = kNoNode; }
+    __syncthreads();
+    uint32_t next = 1;
+    for (uint32_t i0 = 0, chunk = 0; i0 < next; i0 += chunk) {
+        chunk = min(64u, next - i0);                            // nodes appended while this chunk is handled come after it
+        const uint2 old = static_cast<uint32_t>(lane) < chunk ? b.kids[base + i0 + lane] : make_uint2(0u, 0u);
+        unsigned long long todo = __ballot((old.y & 0xFFu) != 0u);
+        while (todo) {
+            const int j = __ffsll(static_cast<long long>(todo)) - 1;
+            todo &= todo - 1ull;
+            const uint32_t of = __shfl(old.x, j), oy = __shfl(old.y, j), nk = oy & 0xFFu, node = i0 + static_cast<uint32_t>(j);
+            for (uint32_t k = lane; k < nk; k += 64) {
+                b.stat[base + next + k] = t.stat[base + of + k];
+                b.kids[base + next + k] = t.kids[base + of + k];       // still the OLD child range: rewritten when the scan gets there
+                b.prior[base + next + k] = t.prior[base + of + k];
+                b.parent[base + next + k] = node;
+            }
+            if (lane == 0) b.kids[base + node] = make_uint2(next, oy);
+            next += nk;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    if (lane == 0) hdr.n_nodes = next;
+}
 
 __global__ __launch_bounds__(64)
 void az_step_kernel(AzTree t, AzArena b, const int16_t* forced) {
@@ -239,30 +285,137 @@ void az_step_kernel(AzTree t, AzArena b, const int16_t* forced) {
         if (lane == 0) { b.stat[base] = make_uint2(0u, 0u); b.kids[base] = make_uint2(0u, cell << 8); b.prior[base] = 1.0f; b.parent[base] = kNoNode; hdr.n_nodes = 1; }
         return;
     }
-    if (lane == 0) { b.stat[base] = t.stat[base + src]; b.kids[base] = t.kids[base + src]; b.prior[base] = t.prior[base + src]; b.parent[base] = kNoNode; }
-    __syncthreads();
-    uint32_t next = 1;
-    for (uint32_t i0 = 0, chunk = 0; i0 < next; i0 += chunk) {
-        chunk = min(64u, next - i0);                            // nodes appended while this chunk is handled come after it
-        const uint2 old = static_cast<uint32_t>(lane) < chunk ? b.kids[base + i0 + lane] : make_uint2(0u, 0u);
-        unsigned long long todo = __ballot((old.y & 0xFFu) != 0u);
-        while (todo) {
-            const int j = __ffsll(static_cast<long long>(todo)) - 1;
-            todo &= todo - 1ull;
-            const uint32_t of = __shfl(old.x, j), oy = __shfl(old.y, j), nk = oy & 0xFFu, node = i0 + static_cast<uint32_t>(j);
-            for (uint32_t k = lane; k < nk; k += 64) {
-                b.stat[base + next + k] = t.stat[base + of + k];
-                b.kids[base + next + k] = t.kids[base + of + k];       // still the OLD child range: rewritten when the scan gets there
-                b.prior[base + next + k] = t.prior[base + of + k];
-                b.parent[base + next + k] = node;
-            }
-            if (lane == 0) b.kids[base + node] = make_uint2(next, oy);
-            next += nk;
+    az_keep_subtree(t, b, base, src, lane, hdr);
+}
+
+// One self-play move for every game that is still played, on the device (what selfplay.play_network_games did with numpy boards, a
+// root_stats copy down and a move list up every ply): the most visited child of the root -- first maximum in child order, i.e. ascending
+// cells, as MCTS::stepForward()'s max_element (MCTS.cpp:129-134) -- goes into the game's record with the root's visit counts
+// (MCTSAgent.eval_state's pi is made from them), Board::applyMove with its victory check (Game.cpp:37-49, 88-136) decides whether the
+// game goes on, and the tree is re-rooted: the child's subtree into the other arena (reuse) or a new root.  A root without a visited
+// child ends the game where it stands.  Finished games leave a childless root behind in both arenas, so that no kernel ever walks a
+// stale tree.  One wavefront per game.
+__global__ __launch_bounds__(64)
+void az_advance_kernel(AzTree t, AzArena b, uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
+                       int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse, AzSlots sl) {
+    __shared__ uint32_t s_rows[16];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= t.n_games) return;
+    AzHeader& hdr = t.hdr[slot];
+    const size_t base = static_cast<size_t>(slot) * t.cap;
+    const int game = sl.slot_game ? sl.slot_game[slot] : slot;      // the rows of the records
+    if ((hdr.status & kStatusOver) || game < 0) {
+        if (reuse && lane == 0) { b.stat[base] = make_uint2(0u, 0u); b.kids[base] = make_uint2(0u, 0u); b.prior[base] = 1.0f; b.parent[base] = kNoNode; }
+        return;
+    }
+    const uint2 rk = t.kids[base];
+    const uint32_t first = rk.x, n = rk.y & 0xFFu;
+    uint32_t best_v = 0, best_i = 0xFFFFFFFFu;                   // visits, first maximum in child order
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t v = t.stat[base + first + i].x;
+        if (v > best_v) { best_v = v; best_i = i; }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        const uint32_t ov = __shfl_down(best_v, s), oi = __shfl_down(best_i, s);
+        if (ov > best_v || (ov == best_v && ov != 0u && oi < best_i)) { best_v = ov; best_i = oi; }
+    }
+    best_v = __shfl(best_v, 0);
+    best_i = __shfl(best_i, 0);
+    const uint32_t stones = hdr.stones;
+    const int len = rec_lens[game];
+    bool over = best_v == 0u || stones >= 225u || len >= 225;    // nothing the search wants to play
+    int winner = 0;
+    uint32_t cell = 255u;
+    if (!over) {
+        cell = (t.kids[base + first + best_i].y >> 8) & 0xFFu;
+        if (rec_visits) {
+            uint16_t* rv = rec_visits + (static_cast<size_t>(game) * kCells + static_cast<size_t>(len)) * kCells;
+            for (int i = lane; i < kCells; i += 64) rv[i] = 0;
             __syncthreads();
+            for (uint32_t i = lane; i < n; i += 64) rv[(t.kids[base + first + i].y >> 8) & 0xFFu] = static_cast<uint16_t>(min(t.stat[base + first + i].x, 65535u));
         }
+        const int shift = (stones & 1u) ? 16 : 0;                // black moves on even stone counts
+        if (lane < 16) s_rows[lane] = hdr.rows[lane] | ((lane == static_cast<int>(cell / 15u)) ? 1u << (cell % 15u + shift) : 0u);
+        __syncthreads();
+        const bool five = five_through<1>(s_rows, static_cast<int>(cell % 15u), static_cast<int>(cell / 15u), shift);
+        if (lane == 0) {
+            hdr.rows[cell / 15u] = s_rows[cell / 15u];
+            hdr.stones = stones + 1u;
+            hdr.last_move2 = hdr.last_move;
+            hdr.last_move = cell;
+            hdr.leaf_pending = 0;
+            rec_moves[static_cast<size_t>(game) * kCells + len] = static_cast<uint8_t>(cell);
+            rec_lens[game] = len + 1;
+        }
+        winner = five ? (shift ? -1 : 1) : 0;
+        over = five || len + 1 == 225;
+    }
+    if (over) {
+        if (lane == 0) {
+            rec_winner[game] = static_cast<int8_t>(winner);
+            const int next = sl.slot_game ? atomicAdd(sl.next_game, 1) : 0x7FFFFFFF;
+            uint32_t root_cell = 0u;
+            if (next < sl.n_total) {                            // the slot goes on with the next unstarted game: its opening is the root position
+                const int n_open = sl.open_moves ? sl.open_lens[next] : 0;
+                for (int y = 0; y < 16; ++y) hdr.rows[y] = 0u;
+                uint32_t last = 255u, last2 = 255u;
+                for (int i = 0; i < n_open; ++i) {
+                    const uint32_t c = sl.open_moves[static_cast<size_t>(next) * sl.open_stride + i];
+                    hdr.rows[c / 15u] |= 1u << (c % 15u + ((i & 1) ? 16 : 0));
+                    last2 = last;
+                    last = c;
+                }
+                hdr.stones = static_cast<uint32_t>(n_open);
+                hdr.last_move = last;
+                hdr.last_move2 = last2;
+                sl.slot_game[slot] = next;
+                root_cell = (last & 0xFFu) << 8;                // as az_init_roots_kernel
+                atomicAdd(unfinished, 1);
+            } else {
+                if (sl.slot_game) sl.slot_game[slot] = -1;
+                hdr.status |= kStatusOver;
+            }
+            hdr.leaf_pending = 0;
+            hdr.n_nodes = 1;
+            t.stat[base] = make_uint2(0u, 0u); t.kids[base] = make_uint2(0u, root_cell); t.prior[base] = 1.0f; t.parent[base] = kNoNode;
+            if (reuse) { b.stat[base] = make_uint2(0u, 0u); b.kids[base] = make_uint2(0u, root_cell); b.prior[base] = 1.0f; b.parent[base] = kNoNode; }
+        }
+        return;
+    }
+    if (lane == 0) atomicAdd(unfinished, 1);
+    if (reuse) {
+        az_keep_subtree(t, b, base, first + best_i, lane, hdr);
+    } else if (lane == 0) {                                      // a new root, as gmk_az_set_roots makes it
+        t.stat[base] = make_uint2(0u, 0u); t.kids[base] = make_uint2(0u, cell << 8); t.prior[base] = 1.0f; t.parent[base] = kNoNode;
+        hdr.n_nodes = 1;
+    }
+}
+
+// The leaf batch holds the games that are still played, and nothing else: row_of[g] = the number of live games before g.  The network's
+// work per playout then follows the number of live games instead of the number of slots (the end of a batch of games is long: lengths
+// run from 9 to 225 plies).  One workgroup.
+__global__ __launch_bounds__(1024)
+void az_compact_kernel(const AzHeader* __restrict__ hdr, int n_games, int32_t* __restrict__ row_of, int32_t* __restrict__ n_live) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < n_games; g0 += 1024) {
+        const int g = g0 + tid;
+        const bool live = g < n_games && !(hdr[g].status & kStatusOver);
+        const unsigned long long b = __ballot(live);
+        const int before = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
+        if ((tid & 63) == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int waves_before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) waves_before += s_wave[w]; total += s_wave[w]; }
+        if (g < n_games) row_of[g] = live ? s_base + waves_before + before : -1;
+        __syncthreads();
+        if (tid == 0) s_base += total;
         __syncthreads();
     }
-    if (lane == 0) hdr.n_nodes = next;
+    if (tid == 0) *n_live = s_base;
 }
 
 // Default::AddNoise (MonteCarlo.hpp:97-108): the root children's priors, by cell, as the host computed them
@@ -311,6 +464,12 @@ struct gmk_az {
     AzArena other{};                                             // second arena, allocated by the first gmk_az_step
     int16_t* d_forced = nullptr;
     float* d_noise_priors = nullptr;
+    int32_t* d_unfinished = nullptr;                             // gmk_az_advance's counter
+    int32_t* d_row_of = nullptr;                                 // [n_games] + the number of live games (AzTree::row_of)
+    int n_live = 0;
+    AzSlots slots{};                                             // gmk_az_set_slots (device memory owned by the handle)
+    uint8_t* d_open_moves = nullptr;
+    int32_t* d_open_lens = nullptr;
     std::vector<uint32_t> game_ids;                              // the game a slot is playing, relative to the callers' first_game_id (default: the slot number)
     bool second_arena = false;
     // device scratch of the host-driven form (gmk_az_select_host / gmk_az_expand_host)
@@ -323,7 +482,8 @@ extern "C" int gmk_az_destroy(gmk_az* a) {
     if (!a) return GMK_OK;
     (void)hipFree(a->t.hdr); (void)hipFree(a->t.stat); (void)hipFree(a->t.kids); (void)hipFree(a->t.prior); (void)hipFree(a->t.parent);
     (void)hipFree(a->other.stat); (void)hipFree(a->other.kids); (void)hipFree(a->other.prior); (void)hipFree(a->other.parent);
-    (void)hipFree(a->d_forced); (void)hipFree(a->d_noise_priors);
+    (void)hipFree(a->d_forced); (void)hipFree(a->d_noise_priors); (void)hipFree(a->d_unfinished); (void)hipFree(a->d_row_of);
+    (void)hipFree(a->slots.slot_game); (void)hipFree(a->d_open_moves); (void)hipFree(a->d_open_lens);
     (void)hipFree(a->h_states); (void)hipFree(a->h_values); (void)hipFree(a->h_probs); (void)hipFree(a->h_paths); (void)hipFree(a->h_lens);
     delete a;
     return GMK_OK;
@@ -339,10 +499,28 @@ extern "C" int gmk_az_create(int n_games, int node_capacity, double c_puct, gmk_
     const bool ok = hipMalloc(&a->t.hdr, static_cast<size_t>(n_games) * sizeof(AzHeader)) == hipSuccess &&
                     hipMalloc(&a->t.stat, nodes * 8) == hipSuccess && hipMalloc(&a->t.kids, nodes * 8) == hipSuccess &&
                     hipMalloc(&a->t.prior, nodes * 4) == hipSuccess && hipMalloc(&a->t.parent, nodes * 4) == hipSuccess;
-    if (!ok) { gmk_az_destroy(a); gmk::set_error("gmk_az_create: device allocation failed"); return GMK_ERR_HIP; }
+    if (!ok || hipMalloc(&a->d_row_of, (static_cast<size_t>(n_games) + 1) * 4) != hipSuccess) { gmk_az_destroy(a); gmk::set_error("gmk_az_create: device allocation failed"); return GMK_ERR_HIP; }
+    a->t.row_of = a->d_row_of;
     a->game_ids.resize(static_cast<size_t>(n_games));
     for (int g = 0; g < n_games; ++g) a->game_ids[static_cast<size_t>(g)] = static_cast<uint32_t>(g);
     *out = a;
+    return GMK_OK;
+}
+
+// row_of and the number of live games, after anything that changes which games are played
+static int az_compact(gmk_az* a, hipStream_t s) {
+    hipLaunchKernelGGL(az_compact_kernel, dim3(1), dim3(1024), 0, s, a->t.hdr, a->t.n_games, a->d_row_of, a->d_row_of + a->t.n_games);
+    GMK_HIP_CHECK(hipGetLastError());
+    int32_t n = 0;
+    GMK_HIP_CHECK(hipMemcpyAsync(&n, a->d_row_of + a->t.n_games, 4, hipMemcpyDeviceToHost, s));
+    GMK_HIP_CHECK(hipStreamSynchronize(s));
+    a->n_live = n;
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_live_games(gmk_az* a, int32_t* n_live) {
+    if (!a || !n_live) { gmk::set_error("gmk_az_live_games: bad arguments"); return GMK_ERR_ARG; }
+    *n_live = a->n_live;
     return GMK_OK;
 }
 
@@ -377,7 +555,65 @@ extern "C" int gmk_az_set_roots(gmk_az* a, const uint16_t* h_planes, const int16
     GMK_HIP_CHECK(hipGetLastError());
     GMK_HIP_CHECK(hipDeviceSynchronize());
     a->rooted = true;
+    if (const int rc = az_compact(a, nullptr); rc != GMK_OK) return rc;
+    (void)hipFree(a->slots.slot_game); (void)hipFree(a->d_open_moves); (void)hipFree(a->d_open_lens);       // slot g plays game g again
+    a->slots = AzSlots{}; a->d_open_moves = nullptr; a->d_open_lens = nullptr;
     return GMK_OK;
+}
+
+// Continuous batching for whole-game self-play: the handle's n_games slots play n_total games between them.  The first min(n_games,
+// n_total) games start in the slots, from their openings (this call makes the roots: it takes gmk_az_set_roots's place); gmk_az_advance
+// then writes a slot's move into the record rows of the GAME it plays and hands a finished game's slot to the next unstarted game.
+extern "C" int gmk_az_set_slots(gmk_az* a, int n_total, const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens) {
+    if (!a || n_total <= 0 || (h_open_moves && (!h_open_lens || open_stride <= 0))) { gmk::set_error("gmk_az_set_slots: bad arguments"); return GMK_ERR_ARG; }
+    const int n_slots = a->t.n_games, started = std::min(n_slots, n_total);
+    const size_t ns = static_cast<size_t>(n_slots), nt = static_cast<size_t>(n_total);
+    std::vector<int32_t> open_lens(nt, 0);
+    if (h_open_moves)
+        for (size_t g = 0; g < nt; ++g) {
+            if (h_open_lens[g] < 0 || h_open_lens[g] > 8 || h_open_lens[g] > open_stride) { gmk::set_error("gmk_az_set_slots: opening of game %zu has %d moves (at most 8: an opening cannot be a finished game)", g, h_open_lens[g]); return GMK_ERR_ARG; }
+            open_lens[g] = h_open_lens[g];
+        }
+    std::vector<AzHeader> hdr(ns);
+    std::vector<int32_t> state(ns + 1, -1);
+    for (size_t g = 0; g < ns; ++g) {
+        AzHeader& h = hdr[g];
+        std::memset(&h, 0, sizeof h);
+        h.n_nodes = 1;
+        h.last_move = h.last_move2 = 255u;
+        if (g >= static_cast<size_t>(started)) { h.status = kStatusOver; continue; }
+        state[g] = static_cast<int32_t>(g);
+        for (int i = 0; i < open_lens[g]; ++i) {
+            const uint32_t c = h_open_moves[g * static_cast<size_t>(open_stride) + i];
+            if (c >= 225u || ((h.rows[c / 15u] | (h.rows[c / 15u] >> 16)) >> (c % 15u)) & 1u) { gmk::set_error("gmk_az_set_slots: opening of game %zu is not a sequence of moves", g); return GMK_ERR_ARG; }
+            h.rows[c / 15u] |= 1u << (c % 15u + ((i & 1) ? 16 : 0));
+            h.last_move2 = h.last_move;
+            h.last_move = c;
+        }
+        h.stones = static_cast<uint32_t>(open_lens[g]);
+    }
+    state[ns] = started;                                         // next_game
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    (void)hipFree(a->slots.slot_game); (void)hipFree(a->d_open_moves); (void)hipFree(a->d_open_lens);
+    a->slots = AzSlots{}; a->d_open_moves = nullptr; a->d_open_lens = nullptr;
+    GMK_HIP_CHECK(hipMalloc(&a->slots.slot_game, state.size() * 4));
+    GMK_HIP_CHECK(hipMemcpy(a->slots.slot_game, state.data(), state.size() * 4, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMalloc(&a->d_open_lens, nt * 4));
+    GMK_HIP_CHECK(hipMemcpy(a->d_open_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
+    if (h_open_moves) {
+        GMK_HIP_CHECK(hipMalloc(&a->d_open_moves, nt * static_cast<size_t>(open_stride)));
+        GMK_HIP_CHECK(hipMemcpy(a->d_open_moves, h_open_moves, nt * static_cast<size_t>(open_stride), hipMemcpyHostToDevice));
+    }
+    a->slots.next_game = a->slots.slot_game + ns;
+    a->slots.n_total = n_total;
+    a->slots.open_moves = a->d_open_moves; a->slots.open_lens = a->d_open_lens; a->slots.open_stride = open_stride;
+    GMK_HIP_CHECK(hipMemcpy(a->t.hdr, hdr.data(), hdr.size() * sizeof(AzHeader), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(az_init_roots_kernel, dim3((a->t.n_games + 255) / 256), dim3(256), 0, nullptr, a->t);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    for (size_t g = 0; g < ns; ++g) a->game_ids[g] = state[g] >= 0 ? static_cast<uint32_t>(state[g]) : 0u;
+    a->rooted = true;
+    return az_compact(a, nullptr);
 }
 
 extern "C" int gmk_az_select(gmk_az* a, float* d_states, void* stream) {
@@ -399,23 +635,28 @@ extern "C" int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_pr
 extern "C" int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
                                  float* h_root_value, int32_t* h_n_nodes, int32_t* h_status);
 
+static int az_second_arena(gmk_az* a) {
+    if (a->second_arena) return GMK_OK;
+    const size_t n = static_cast<size_t>(a->t.n_games), nodes = n * static_cast<size_t>(a->t.cap);
+    const bool ok = hipMalloc(&a->other.stat, nodes * 8) == hipSuccess && hipMalloc(&a->other.kids, nodes * 8) == hipSuccess &&
+                    hipMalloc(&a->other.prior, nodes * 4) == hipSuccess && hipMalloc(&a->other.parent, nodes * 4) == hipSuccess &&
+                    hipMalloc(&a->d_forced, n * 2) == hipSuccess;
+    if (!ok) {                                                      // all or nothing: a later call must not find half an arena
+        (void)hipFree(a->other.stat); (void)hipFree(a->other.kids); (void)hipFree(a->other.prior); (void)hipFree(a->other.parent); (void)hipFree(a->d_forced);
+        a->other = AzArena{}; a->d_forced = nullptr;
+        (void)hipGetLastError();
+        gmk::set_error("gmk_az: hipMalloc of the second arena (%zu nodes) failed", nodes);
+        return GMK_ERR_HIP;
+    }
+    a->second_arena = true;
+    return GMK_OK;
+}
+
 extern "C" int gmk_az_step(gmk_az* a, const int16_t* h_moves) {
     if (!a) { gmk::set_error("gmk_az_step: bad arguments"); return GMK_ERR_ARG; }
     if (!a->rooted) { gmk::set_error("gmk_az_step: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
-    const size_t n = static_cast<size_t>(a->t.n_games), nodes = n * static_cast<size_t>(a->t.cap);
-    if (!a->second_arena) {
-        const bool ok = hipMalloc(&a->other.stat, nodes * 8) == hipSuccess && hipMalloc(&a->other.kids, nodes * 8) == hipSuccess &&
-                        hipMalloc(&a->other.prior, nodes * 4) == hipSuccess && hipMalloc(&a->other.parent, nodes * 4) == hipSuccess &&
-                        hipMalloc(&a->d_forced, n * 2) == hipSuccess;
-        if (!ok) {                                                  // all or nothing: a later call must not find half an arena
-            (void)hipFree(a->other.stat); (void)hipFree(a->other.kids); (void)hipFree(a->other.prior); (void)hipFree(a->other.parent); (void)hipFree(a->d_forced);
-            a->other = AzArena{}; a->d_forced = nullptr;
-            (void)hipGetLastError();
-            gmk::set_error("gmk_az_step: hipMalloc of the second arena (%zu nodes) failed", nodes);
-            return GMK_ERR_HIP;
-        }
-        a->second_arena = true;
-    }
+    const size_t n = static_cast<size_t>(a->t.n_games);
+    if (const int rc = az_second_arena(a); rc != GMK_OK) return rc;
     GMK_HIP_CHECK(hipDeviceSynchronize());
     if (h_moves) GMK_HIP_CHECK(hipMemcpy(a->d_forced, h_moves, n * 2, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(az_step_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, a->other, h_moves ? a->d_forced : nullptr);
@@ -425,11 +666,36 @@ extern "C" int gmk_az_step(gmk_az* a, const int16_t* h_moves) {
     return GMK_OK;
 }
 
+// One self-play move of every game still played (az_advance_kernel).  h_unfinished: the games that go on.
+extern "C" int gmk_az_advance(gmk_az* a, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int reuse_subtree, int32_t* h_unfinished,
+                              void* stream) {
+    if (!a || !d_moves || !d_lens || !d_winner) { gmk::set_error("gmk_az_advance: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_advance: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    if (reuse_subtree)
+        if (const int rc = az_second_arena(a); rc != GMK_OK) return rc;
+    if (!a->d_unfinished) GMK_HIP_CHECK(hipMalloc(&a->d_unfinished, 4));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GMK_HIP_CHECK(hipMemsetAsync(a->d_unfinished, 0, 4, s));
+    hipLaunchKernelGGL(az_advance_kernel, dim3(a->t.n_games), dim3(64), 0, s, a->t, a->other, d_moves, d_visits, d_lens, d_winner, a->d_unfinished, reuse_subtree ? 1 : 0, a->slots);
+    GMK_HIP_CHECK(hipGetLastError());
+    int32_t unfinished = 0;
+    GMK_HIP_CHECK(hipMemcpyAsync(&unfinished, a->d_unfinished, 4, hipMemcpyDeviceToHost, s));
+    if (const int rc = az_compact(a, s); rc != GMK_OK) return rc;   // (synchronises: both numbers are here now, and they agree)
+    if (reuse_subtree) { std::swap(a->t.stat, a->other.stat); std::swap(a->t.kids, a->other.kids); std::swap(a->t.prior, a->other.prior); std::swap(a->t.parent, a->other.parent); }
+    if (h_unfinished) *h_unfinished = unfinished;
+    return GMK_OK;
+}
+
 // Default::AddNoise on every root with children, seeded like gmk_mcts_add_root_noise / gmk_trad_add_root_noise
 extern "C" int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id) {
     if (!a || !(alpha > 0.0f)) { gmk::set_error("gmk_az_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
     if (!a->rooted) { gmk::set_error("gmk_az_add_root_noise: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(a->t.n_games);
+    if (a->slots.slot_game) {                                    // continuous batching: the random stream belongs to the GAME a slot plays
+        std::vector<int32_t> slot_game(n);
+        GMK_HIP_CHECK(hipMemcpy(slot_game.data(), a->slots.slot_game, n * 4, hipMemcpyDeviceToHost));
+        for (size_t g = 0; g < n; ++g) a->game_ids[g] = slot_game[g] >= 0 ? static_cast<uint32_t>(slot_game[g]) : 0u;
+    }
     std::vector<float> priors(n * 225);
     int rc = gmk_az_root_stats(a, nullptr, nullptr, priors.data(), nullptr, nullptr, nullptr, nullptr);
     if (rc != GMK_OK) return rc;

@@ -37,7 +37,7 @@ EXPORTS = [
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_set_game_ids", "gmk_mcts_run", "gmk_mcts_root_stats",
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_selfplay_run", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
-    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_root_stats",
+    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_step", "gmk_az_advance", "gmk_az_set_slots", "gmk_az_live_games", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_root_stats",
     "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_trad_selfplay_run", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
 ]
 
@@ -108,6 +108,9 @@ def load():
     L.gmk_az_expand.argtypes = [vp, vp, vp, vp]
     L.gmk_az_select_host.argtypes = [vp, vp, vp]
     L.gmk_az_step.argtypes = [vp, vp]
+    L.gmk_az_live_games.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.gmk_az_set_slots.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    L.gmk_az_advance.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int32), vp]
     L.gmk_az_add_root_noise.argtypes = [vp, C.c_float, C.c_float, C.c_uint64, C.c_uint32]
     L.gmk_az_expand_host.argtypes = [vp, vp, vp]
     L.gmk_az_root_stats.argtypes = [vp] * 8
@@ -518,6 +521,7 @@ class AlphaZeroMCTS:
         _check(load().gmk_az_create(n_games, int(node_capacity), float(c_puct), C.byref(h)))
         self.h = h
         self.states = torch.zeros((n_games, 6, 15, 15), dtype=torch.float32, device="cuda")
+        self.live = n_games                                        # rows of the leaf batch (see select)
 
     def close(self):
         if getattr(self, "h", None) and load is not None:
@@ -526,7 +530,7 @@ class AlphaZeroMCTS:
 
     __del__ = close
 
-    STATUS_ARENA_FULL, STATUS_ILLEGAL_STEP = 2, 4      # bits of root_stats()["status"]
+    STATUS_OVER, STATUS_ARENA_FULL, STATUS_ILLEGAL_STEP = 1, 2, 4      # bits of root_stats()["status"]
 
     def set_game_ids(self, ids):
         """The game each slot is playing, relative to add_root_noise's first_game_id (uint32[n]; default: the slot number)."""
@@ -540,17 +544,25 @@ class AlphaZeroMCTS:
         last_moves = np.ascontiguousarray(last_moves, dtype=np.int16)
         assert planes.shape == (self.n, 2, 16) and last_moves.shape == (self.n, 2)
         _check(load().gmk_az_set_roots(self.h, planes.ctypes.data, last_moves.ctypes.data))
+        self.n_total = None
+        self._refresh_live()
+
+    def _refresh_live(self):
+        """self.live = rows of the leaf batch: the games still played, in slot order (gmk_az_live_games)"""
+        n = C.c_int32(0)
+        _check(load().gmk_az_live_games(self.h, C.byref(n)))
+        self.live = n.value
 
     def select(self, stream=None):
         import torch
         stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _check(load().gmk_az_select(self.h, self.states.data_ptr(), stream))
-        return self.states
+        return self.states[:self.live]                             # the games still played (all of them until advance() ends one)
 
     def expand(self, values, probs, stream=None):
         import torch
         assert values.dtype == torch.float32 and probs.dtype == torch.float32 and values.is_contiguous() and probs.is_contiguous()
-        assert values.numel() == self.n and probs.numel() == self.n * N
+        assert values.numel() == self.live and probs.numel() == self.live * N
         stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
         _check(load().gmk_az_expand(self.h, values.data_ptr(), probs.data_ptr(), stream))
 
@@ -562,6 +574,34 @@ class AlphaZeroMCTS:
             m = np.ascontiguousarray(moves, dtype=np.int16)
             assert m.shape == (self.n,)
             _check(load().gmk_az_step(self.h, m.ctypes.data))
+
+    def set_slots(self, n_total, open_moves=None, open_lens=None):
+        """Continuous batching (gmk_az_set_slots): the n slots of this handle play n_total games between them, from their openings
+        (uint8[n_total, stride], int32[n_total]); takes set_roots's place.  advance() then wants records of n_total rows."""
+        self.n_total = int(n_total)
+        if open_moves is None:
+            _check(load().gmk_az_set_slots(self.h, int(n_total), None, 0, None))
+        else:
+            m = np.ascontiguousarray(open_moves, dtype=np.uint8)
+            l = np.ascontiguousarray(open_lens, dtype=np.int32)
+            assert m.ndim == 2 and m.shape[0] == n_total and l.shape == (n_total,)
+            _check(load().gmk_az_set_slots(self.h, int(n_total), m.ctypes.data, m.shape[1], l.ctypes.data))
+        self._refresh_live()
+
+    def advance(self, moves, visits, lens, winner, reuse_subtree=True, stream=None):
+        """One self-play move for every game still played, on the device (gmk_az_advance): moves uint8[n,225], visits int16/uint16
+        [n,225,225] or None, lens int32[n], winner int8[n] are torch tensors on the GPU (the games' records, openings included);
+        returns the number of games that go on."""
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        rows = getattr(self, "n_total", None) or self.n
+        assert moves.dtype == torch.uint8 and moves.shape == (rows, N) and lens.dtype == torch.int32 and lens.shape == (rows,) and winner.dtype == torch.int8 and winner.shape == (rows,)
+        assert visits is None or (visits.element_size() == 2 and visits.shape == (rows, N, N))
+        unfinished = C.c_int32(0)
+        _check(load().gmk_az_advance(self.h, moves.data_ptr(), visits.data_ptr() if visits is not None else None, lens.data_ptr(), winner.data_ptr(),
+                                     int(bool(reuse_subtree)), C.byref(unfinished), stream))
+        self._refresh_live()
+        return unfinished.value
 
     def add_root_noise(self, alpha=0.05, epsilon=0.25, seed=DEFAULT_SEED, first_game_id=0):
         _check(load().gmk_az_add_root_noise(self.h, alpha, epsilon, seed, first_game_id))

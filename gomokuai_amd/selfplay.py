@@ -421,19 +421,46 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
 
 
 def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                       device=None, node_capacity=None, reuse_subtree=True, root_noise=(0.05, 0.25), slots=None):
+                       device=None, node_capacity=None, reuse_subtree=True, root_noise=(0.05, 0.25), slots=None, device_loop=True):
     """n_games complete games of the network-guided searcher against itself (agents/alphazero.py:5-9 on both sides: the
     reference's AlphaZero self-play), all games in lock step on the current GPU: every move = `playouts` lock-step playouts of
     K7 with `network(states [n,6,15,15]) -> (value [n], probs [n,225])` at the leaves (network.FusedPolicyValueNetwork = K9),
     then every game plays its most visited child (MCTSAgent.eval_state -> MCTS::stepForward); with reuse_subtree the child's
     subtree is kept and root_noise = (alpha, epsilon) is mixed into the root priors before every search (MCTS.cpp:182).
-    slots (fresh roots only, reuse_subtree=False): at most that many games in flight, a finished game hands its slot to the next one
-    (see play_supervisor_games).  Returns GameRecords like play_games."""
+    slots: at most that many games in flight, a finished game hands its slot to the next one (see play_supervisor_games; on the
+    host-driven loop with fresh roots only).  device_loop (all games at once): the move, the record, the end-of-game check and the re-rooting are one
+    kernel per ply (gmk_az_advance) and the host sees four bytes per move (plus the root priors when root_noise is mixed in, which is a
+    host step); False = the host-driven loop it replaced (numpy boards, root statistics down and moves up every ply), kept for the
+    tests that compare the two.  Returns GameRecords like play_games."""
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    if slots is not None and slots < n_games and device_loop:
+        # continuous batching on the device (gmk_az_set_slots + gmk_az_advance): the batch the network sees stays full of live games
+        # until fewer games than slots remain, with kept subtrees and root noise as well
+        games = _HostGames(n_games)
+        if opening_plies > 0:
+            m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
+            games.open_with(m, l, opening_plies)
+        slots = int(slots)
+        cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * N + 1, (1 << 24) - 1)
+        tree = G.AlphaZeroMCTS(slots, node_capacity=cap, c_puct=c_puct)
+        tree.set_slots(n_games, games.moves[:, :max(int(games.lens.max()), 1)], games.lens)
+        d_moves, d_lens = torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev)
+        d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
+        d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev)
+        with torch.no_grad():
+            for _ in range((n_games // slots + 2) * N):
+                if root_noise is not None:
+                    tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
+                tree.search(network, playouts)
+                if tree.advance(d_moves, d_visits, d_lens, d_winner, reuse_subtree) == 0:
+                    break
+        overflow = bool((tree.root_stats()["status"] & G.AlphaZeroMCTS.STATUS_ARENA_FULL).any())
+        tree.close()
+        return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, overflow)
     if slots is not None and slots < n_games:
         if reuse_subtree:
-            raise ValueError("play_network_games: slots need fresh roots (reuse_subtree=False)")
+            raise ValueError("play_network_games: slots on the host-driven loop need fresh roots (reuse_subtree=False)")
         games = _HostGames(n_games)
         if opening_plies > 0:
             m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
@@ -477,10 +504,24 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
     if opening_plies > 0:
         m, l, _ = G.synth_boards(n_games, 0, seed=seed, first_board=first_game_id)
         games.open_with(m, l, opening_plies)
-    visits = np.zeros((n_games, N, N), dtype=np.uint16)
     cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * N + 1, (1 << 24) - 1)
     tree = G.AlphaZeroMCTS(n_games, node_capacity=cap, c_puct=c_puct)
     tree.set_roots(G.moves_to_planes(games.moves, games.lens), games.last_two())
+    if device_loop:
+        d_moves, d_lens = torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev)
+        d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
+        d_visits = torch.zeros((n_games, N, N), dtype=torch.int16, device=dev)
+        with torch.no_grad():
+            for ply in range(max_moves):
+                if root_noise is not None:
+                    tree.add_root_noise(root_noise[0], root_noise[1], seed=seed, first_game_id=first_game_id)
+                tree.search(network, playouts)
+                if tree.advance(d_moves, d_visits, d_lens, d_winner, reuse_subtree) == 0:
+                    break
+        overflow = bool((tree.root_stats()["status"] & G.AlphaZeroMCTS.STATUS_ARENA_FULL).any())
+        tree.close()
+        return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, overflow)
+    visits = np.zeros((n_games, N, N), dtype=np.uint16)
     overflow = False
     with torch.no_grad():
         for ply in range(max_moves):

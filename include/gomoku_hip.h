@@ -276,17 +276,36 @@ int gmk_trad_root_amaf(gmk_trad* t, uint32_t* h_amaf_visits, float* h_amaf_value
  * Default::Expand with extraCheck = true (:71-80), Default::BackPropogate (:90-95).  One playout of every game =
  * gmk_az_select (writes the leaves' Board.encoded_states planes, core/py_ext/src/game_ext.hpp:87-104, as float32
  * [n][6][15][15]; games that are over at the leaf are backed up at once and get a zero row), the caller's network on that
- * batch, gmk_az_expand with its value [n] and probabilities [n][225] (device pointers, same stream). */
+ * batch, gmk_az_expand with its value [n] and probabilities [n][225] (device pointers, same stream).
+ * The batch holds the games that are still PLAYED, in slot order: n = gmk_az_live_games, which is n_games until gmk_az_advance ends a
+ * game (or gmk_az_set_slots leaves slots idle); a finished game has no row, so the network's work follows the live games. */
 typedef struct gmk_az gmk_az;
 int gmk_az_create(int n_games, int node_capacity, double c_puct, gmk_az** out);
 int gmk_az_destroy(gmk_az* a);
 /* fresh roots; h_planes uint16[n][2][16] as gmk_eval_batch, h_last_moves int16[n][2] = {last move, the one before} or -1 */
 int gmk_az_set_roots(gmk_az* a, const uint16_t* h_planes, const int16_t* h_last_moves);
+int gmk_az_live_games(gmk_az* a, int32_t* n_live);            /* rows of the leaf batch; changed by gmk_az_set_roots / _set_slots / _advance only */
 int gmk_az_select(gmk_az* a, float* d_states, void* stream);
 int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_probs, void* stream);
 /* MCTS::stepForward() / stepForward(move) (core/lib/src/MCTS.cpp:129-147) for every game, subtree kept (as gmk_trad_step): h_moves
  * int16[n] = the cell to step to, -1 = the most visited child, NULL = -1 for all; status bit 2 = not a legal move. */
 int gmk_az_step(gmk_az* a, const int16_t* h_moves);
+/* One self-play move for every game still played, on the device (replaces the per-ply host work of the reference's self-play loop,
+ * network/data_helper.py:56-83 with agents/alphazero.py:5-9 on both sides, as gmk_mcts_advance does for K3): the most visited child of
+ * the root (first maximum in cell order, MCTS.cpp:129-134) is appended to the game's record with the root's visit counts, played on the
+ * root position with Board::applyMove's victory check (Game.cpp:37-49, 88-136), and the tree is re-rooted (reuse_subtree: the child's
+ * subtree is kept as gmk_az_step keeps it; otherwise a new root).  A root without a visited child ends its game where it stands.
+ * Finished games (status bit 0) are skipped by gmk_az_select / gmk_az_expand from then on.
+ * Records on the device, row g = game g: d_moves uint8[n][225] and d_lens int32[n] must hold the moves that led to the roots (the
+ * openings), d_winner int8[n] zero; d_visits uint16[n][225][225] may be NULL.  h_unfinished: the games that go on.  Synchronises `stream`. */
+/* Continuous batching for whole-game self-play (as gmk_selfplay_run / gmk_trad_selfplay_run have it): the handle's n_games slots play
+ * n_total games between them.  This call takes gmk_az_set_roots's place: the first min(n_games, n_total) games start in the slots from
+ * their openings (h_open_moves uint8[n_total][open_stride], h_open_lens int32[n_total], at most 8 moves each; NULL: empty boards);
+ * gmk_az_advance then writes a slot's move to the record rows of the GAME it plays (rows = n_total) and hands a finished game's slot to
+ * the next unstarted game; gmk_az_add_root_noise keys a slot's draws by that game.  gmk_az_set_roots ends the mode. */
+int gmk_az_set_slots(gmk_az* a, int n_total, const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens);
+int gmk_az_advance(gmk_az* a, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int reuse_subtree, int32_t* h_unfinished,
+                   void* stream);
 /* Default::AddNoise on every root with children (core/lib/include/algorithms/MonteCarlo.hpp:97-108); the stream of slot g is keyed
  * by first_game_id + ids[g], ids as set by gmk_az_set_game_ids (uint32[n], host; default: the slot number) */
 int gmk_az_set_game_ids(gmk_az* a, const uint32_t* h_ids);
@@ -296,7 +315,7 @@ int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, 
  * -1 = nothing to evaluate); expand from host memory.  Synchronous. */
 int gmk_az_select_host(gmk_az* a, int16_t* h_paths, int32_t* h_lens);
 int gmk_az_expand_host(gmk_az* a, const float* h_values, const float* h_probs);
-/* host outputs, any may be NULL; status bit 1 = node arena full (playouts of that game were dropped) */
+/* host outputs, any may be NULL; status bit 0 = the game is over (gmk_az_advance), bit 1 = node arena full (playouts of that game were dropped) */
 int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
                       float* h_root_value, int32_t* h_n_nodes, int32_t* h_status);
 

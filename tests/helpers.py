@@ -143,3 +143,22 @@ def encoded_states_of(moves):
             planes[3 + back].reshape(-1)[int(moves[len(moves) - 1 - back])] = 1
     planes[5][:] = 1 if black_to_move else 0
     return planes
+
+
+class PaddedNetwork:
+    """A network behind a fixed batch size: the rows it is given, padded with empty positions to `rows`, so that its dense layers (library
+    GEMMs, whose summation order may follow the batch size) see the same shapes whatever the number of live games.  For tests that want
+    the games of two self-play loops to be equal bit for bit although one of them hands the network live games only."""
+
+    def __init__(self, network, rows):
+        self.network, self.rows = network, rows
+
+    def __call__(self, states):
+        import torch
+        n = states.shape[0]
+        if n == self.rows:
+            return self.network(states)
+        padded = torch.zeros((self.rows,) + tuple(states.shape[1:]), dtype=states.dtype, device=states.device)
+        padded[:n] = states
+        value, probs = self.network(padded)
+        return value[:n], probs[:n]

@@ -371,6 +371,53 @@ def test_slots_do_not_change_noisy_supervisor_games():
         assert len(games) > 3, policy                    # nine different games, not three sets of copies
 
 
+@pytest.mark.parametrize("reuse,noise", [(True, (0.05, 0.25)), (True, None), (False, None)])
+def test_device_resident_network_loop_plays_the_host_loops_games(reuse, noise):
+    """gmk_az_advance (MCTS::stepForward's move, the record with the root's visit counts, Board::applyMove's victory check and the
+    re-rooting as ONE kernel per ply) against the host-driven loop it replaces (numpy boards, root statistics down and moves up every
+    ply): the same moves, lengths, winners and visit counts, with kept subtrees and root noise (the reference agent's semantics), with
+    kept subtrees alone and with new roots; a move cap cuts both the same way."""
+    from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
+    from helpers import PaddedNetwork
+    net = FusedPolicyValueNetwork(PolicyValueNetwork(seed=6).cuda().eval())
+    fused = PaddedNetwork(net, 9)                                # (the device loop hands the network the games still played only)
+    kw = dict(opening_plies=2, first_game_id=21, seed=5, reuse_subtree=reuse, root_noise=noise)
+    dev = selfplay.play_network_games(9, fused, 24, device_loop=True, **kw)
+    host = selfplay.play_network_games(9, fused, 24, device_loop=False, **kw)
+    rd, rh = dev.cpu(), host.cpu()
+    assert not dev.overflow and not host.overflow
+    assert (rd.lens == rh.lens).all() and (rd.winner == rh.winner).all() and int(rd.lens.min()) >= 9
+    for g in range(9):
+        n = int(rd.lens[g])
+        assert (rd.moves[g, :n] == rh.moves[g, :n]).all()
+        assert (rd.visits[g, :n] == rh.visits[g, :n]).all()
+    cd = selfplay.play_network_games(9, fused, 24, device_loop=True, max_moves=5, **kw).cpu()
+    ch = selfplay.play_network_games(9, fused, 24, device_loop=False, max_moves=5, **kw).cpu()
+    assert (cd.lens == ch.lens).all() and int(cd.lens.max()) <= 7 and (cd.moves[:, :7] == ch.moves[:, :7]).all()
+    net.close()
+
+
+def test_network_self_play_through_slots_on_the_device():
+    """gmk_az_set_slots: eleven games through four slots play the games that eleven slots play (a game's search does not depend on the
+    slot that runs it, its root noise is keyed by its global id): with kept subtrees and root noise, and with new roots; the host-driven
+    slot loop (new roots only) agrees as well."""
+    from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
+    from helpers import PaddedNetwork
+    net = FusedPolicyValueNetwork(PolicyValueNetwork(seed=8).cuda().eval())
+    fused = PaddedNetwork(net, 11)
+    for reuse, noise in ((True, (0.05, 0.25)), (False, None)):
+        kw = dict(opening_plies=2, first_game_id=70, seed=2, reuse_subtree=reuse, root_noise=noise)
+        few = selfplay.play_network_games(11, fused, 20, slots=4, **kw).cpu()
+        full = selfplay.play_network_games(11, fused, 20, **kw).cpu()
+        assert (few.lens == full.lens).all() and (few.winner == full.winner).all() and int(few.lens.min()) >= 9
+        for g in range(11):
+            n = int(few.lens[g])
+            assert (few.moves[g, :n] == full.moves[g, :n]).all() and (few.visits[g, :n] == full.visits[g, :n]).all()
+    host = selfplay.play_network_games(11, fused, 20, slots=4, device_loop=False, opening_plies=2, first_game_id=70, seed=2, reuse_subtree=False, root_noise=None).cpu()
+    assert (host.lens == few.lens).all() and (host.moves == few.moves).all()
+    net.close()
+
+
 def test_network_self_play_reports_a_full_arena():
     """K7 reports a full node arena as status bit 1 (value 2): play_network_games must pass it on as GameRecords.overflow."""
     import torch

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--reuse", action="store_true", help="keep the subtree of the played move (MCTS::stepForward)")
     ap.add_argument("--noise", action="store_true", help="Default::AddNoise(0.05, 0.25) before every search (needs --reuse)")
     ap.add_argument("--augment", action="store_true")
-    ap.add_argument("--host-loop", action="store_true", help="traditional / poolrave: drive the games from the host ply by ply (the loop the device-resident one replaced)")
+    ap.add_argument("--host-loop", action="store_true", help="traditional / poolrave / network: drive the games from the host ply by ply (the loop the device-resident one replaced)")
     ap.add_argument("--slots", default=None, help="games in flight: a finished game hands its slot to the next one (random: on the device, gmk_selfplay_run; default there: "
                     "selfplay.SLOTS_PER_GPU when a rank has more games than that); 0 = all games at once")
     ap.add_argument("--policy", default="random", choices=["random", "traditional", "poolrave", "network"],
@@ -44,7 +44,7 @@ def main():
     elif args.policy == "network":
         from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
         net = FusedPolicyValueNetwork(PolicyValueNetwork(seed=1).cuda().eval())
-        rec = selfplay.play_network_games(n, net, args.playouts, first_game_id=first, opening_plies=2, reuse_subtree=args.reuse, root_noise=noise)
+        rec = selfplay.play_network_games(n, net, args.playouts, first_game_id=first, opening_plies=2, reuse_subtree=args.reuse, root_noise=noise, device_loop=not args.host_loop)
     else:
         rec = selfplay.play_supervisor_games(n, args.playouts, c_puct=5.0 if args.policy == "traditional" else 2.0, first_game_id=first, opening_plies=2,
                                              reuse_subtree=args.reuse, root_noise=noise, policy=args.policy, slots=slots, device_loop=not args.host_loop)
