@@ -73,6 +73,50 @@ def test_two_handles_with_different_rollout_counts(oracle):
         t.close()
 
 
+def _no_five_positions(n, lo, hi, seed):
+    """n move sequences of lo .. hi-1 stones in which neither colour ever lines up five (two colour classes that cannot)."""
+    rng = np.random.RandomState(seed)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    moves = np.zeros((n, 225), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(b.pop())
+            if w:
+                seq.append(w.pop())
+        moves[g] = seq
+        lens[g] = rng.randint(lo, hi)
+    return moves, lens
+
+
+@pytest.mark.parametrize("c_rollouts,form", [(5, "quads"), (16, "quads, all 64 lanes"), (20, "pairs"), (32, "pairs, all 64 lanes"), (40, "one lane")])
+def test_every_lane_form_of_the_rollouts(oracle, c_rollouts, form):
+    """A rollout runs on four lanes (one line direction each), on two, or on one, whichever the wavefront's games x rollouts leave room for
+    (mcts_kernel.hip / rollout_device.h); with one game per wavefront the rollout count picks the form.  All of them must play the
+    oracle's rollouts: visit counts, tree size and the bits of the root value, from openings and from late positions (boards that fill up
+    inside a rollout block)."""
+    for late, playouts in ((False, 120), (True, 60)):
+        if late:
+            moves, lens = _no_five_positions(5, 150, 215, seed=c_rollouts)
+            planes = G.moves_to_planes(moves, lens)
+            last = np.array([moves[g, lens[g] - 1] for g in range(5)], dtype=np.int16)
+        else:
+            moves, lens, planes, last = _openings(5, 4, first=11)
+        t = G.BatchedMCTS(5, playouts_capacity=playouts, c_rollouts=c_rollouts)
+        assert t.launch_info()["grid"] == 5                       # one game per wavefront
+        t.set_roots(planes, last, first_game_id=300)
+        t.run(playouts)
+        visits, q, rv, nodes, status = t.root_stats()
+        for g in range(5):
+            ov, oq, _, osize, _ = _oracle_search(oracle, moves[g], int(lens[g]), playouts, 300 + g, c_rollouts=c_rollouts)
+            assert (visits[g] == ov).all() and nodes[g] == osize and q[g].tobytes() == oq.tobytes(), "%s, %d stones, game %d" % (form, int(lens[g]), g)
+        t.close()
+
+
 def test_one_game_one_rollout(oracle):
     """The smallest search handle: one game, c_rollouts = 1 (one rollout lane in the workgroup: both fast-division constants are for 1)."""
     moves, lens, planes, last = _openings(1, 4, first=77)
