@@ -438,12 +438,37 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
         net_ms, trunk_ms, torch_ms = timed(lambda: fused(s)), timed(lambda: fused.trunk(s)), timed(lambda: net(s))
         dv, dp = fused(s), net(s)
         err = max(float((dv[0] - dp[0]).abs().max()), float((dv[1] - dp[1]).abs().max()))
-    if distributed:
-        t = torch.tensor([ms], dtype=torch.float64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        ms = float(t[0])
     tree.close()
+    # whole games of this searcher against itself (AlphaZero-style self-play, the reference agent's semantics: kept subtrees, root noise before
+    # every search), the loop resident on the device: gmk_az_advance per ply, continuous batching (gmk_az_set_slots), the leaf batch = the
+    # games still played
+    pipe_s, pipe_moves = 0.0, 0
+    if args.az_selfplay_games > 0:
+        import time
+        from gomokuai_amd import selfplay
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        rec = selfplay.play_network_games(args.az_selfplay_games, fused, args.az_selfplay_playouts, first_game_id=rank * args.az_selfplay_games, opening_plies=2,
+                                          slots=max(1, args.az_selfplay_games // 4), reuse_subtree=True, root_noise=(0.05, 0.25))
+        torch.cuda.synchronize()
+        pipe_s = time.perf_counter() - t0
+        pipe_moves = int(rec.lens.sum()) - 2 * args.az_selfplay_games
+    if distributed:
+        t = torch.tensor([ms, pipe_s], dtype=torch.float64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms, pipe_s = float(t[0]), float(t[1])
+        t = torch.tensor([float(pipe_moves)], dtype=torch.float64, device=REDUCE_DEVICE or dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        pipe_moves = int(t[0])
     fused.close()
+    pipeline = None
+    if args.az_selfplay_games > 0:
+        pipeline = {"metric": "self-play games/s", "value": args.az_selfplay_games * world / pipe_s, "unit": "games/s", "playouts_per_s": pipe_moves * args.az_selfplay_playouts / pipe_s,
+                    "seconds": pipe_s, "moves": pipe_moves,
+                    "config": {"workload": "network-guided self-play (K7 + K9), %d games per GPU through %d slots, %d playouts per move, kept subtrees and root noise (0.05, 0.25), 2-ply openings; "
+                                           "loop resident on the device (gmk_az_set_slots / gmk_az_advance), leaf batch = the games still played" % (args.az_selfplay_games, max(1, args.az_selfplay_games // 4), args.az_selfplay_playouts)}}
     conv_flop = 2.0 * 225 * (54 * 32 + 288 * 64 + 576 * 128 + 128 * 6) * n
     return {"metric": "network-guided-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_step": ms / P,
             "network_ms_per_step": net_ms,
@@ -451,7 +476,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
             "roofline": {"bound": "mfma", "achieved": conv_flop / (trunk_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": conv_flop / (trunk_ms * 1e-3) / 1e12 / 157.3, "traffic": measured_traffic("pvnet_trunk_kernel", "positions_per_launch", n), "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes; not re-measured in this run)", "kernel": "pvnet_trunk_kernel", "kernel_ms": trunk_ms,
                          "alg_flop_per_launch": conv_flop, "note": "dense f32-input MFMA peak (MI355X_MICROARCH.md); the convolution FLOPs of the 225 real pixels"},
-            "pytorch_module_ms_per_step": torch_ms, "max_abs_diff_vs_pytorch_module": err,
+            "pytorch_module_ms_per_step": torch_ms, "max_abs_diff_vs_pytorch_module": err, "selfplay_pipeline": pipeline,
             "note": "the step is the network's forward pass: K9 (one fused kernel for the convolutions, float32 MFMA) + three small dense layers through PyTorch-ROCm; "
                     "the select and expand kernels take the remainder"}
 
@@ -569,6 +594,8 @@ def parse_args(argv=None):
     ap.add_argument("--evalstate-games", type=int, default=1792, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
     ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
     ap.add_argument("--az-playouts", type=int, default=60)
+    ap.add_argument("--az-selfplay-games", type=int, default=4096, help="whole games per GPU of the network-guided searcher against itself (through a quarter as many slots); 0 = skip")
+    ap.add_argument("--az-selfplay-playouts", type=int, default=32)
     ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
