@@ -28,9 +28,23 @@ constexpr int kLineWords = 96, kColBase = 20, kDiagBase = 36, kAntiBase = 65;   
 // update dearer (profiles/r02f_k2_phases.txt): measured, not kept.
 __host__ __device__ constexpr int pdist_index(int cell, int type) { return cell * 8 + type; }
 constexpr int kPdistWords = pdist_index(225, 7) + 1;
-constexpr int oLines = 0, oScores = oLines + kLineWords, oDensity = oScores + 4 * kCells, oPdist = oDensity + 4 * kCells,
+// density: ONE word per (colour, cell): the count in the low half, the weight in the high half, both as int16 (|count| <= 49, |weight| <= 246: a
+// 7x7 block of nibble weights; occupied cells hold -v-1).  Half the words of two int32 planes: what decides how many games fit a CU's LDS.
+constexpr int oLines = 0, oScores = oLines + kLineWords, oDensity = oScores + 4 * kCells, oPdist = oDensity + 2 * kCells,
               oCdist = oPdist + kPdistWords, oRecord = oCdist + 226 * 3, oMeta = oRecord + 57;
-constexpr int kStateWords = (oMeta + 4 + 3) & ~3;                                // 4448 words = 17 792 B
+constexpr int kStateWords = (oMeta + 4 + 3) & ~3;                                // 3996 words = 15 984 B
+__host__ __device__ __forceinline__ int density_count(uint32_t w) { return static_cast<int16_t>(w & 0xFFFFu); }
+__host__ __device__ __forceinline__ int density_weight_of(uint32_t w) { return static_cast<int16_t>(w >> 16); }
+__host__ __device__ __forceinline__ uint32_t density_word(int count, int weight) { return (static_cast<uint32_t>(count) & 0xFFFFu) | (static_cast<uint32_t>(weight) << 16); }
+// host mirror: int32 [colour][count, weight][cell] (the layout of gmk_evalstate_read) from the packed words of one state
+inline void unpack_density(const uint32_t* state, int32_t* out) {
+    for (int colour = 0; colour < 2; ++colour)
+        for (int cell = 0; cell < kCells; ++cell) {
+            const uint32_t w = state[oDensity + colour * kCells + cell];
+            out[(colour * 2 + 0) * kCells + cell] = density_count(w);
+            out[(colour * 2 + 1) * kCells + cell] = density_weight_of(w);
+        }
+}
 // meta: [0] moves played, [1] player to move (+1 black, -1 white, 0 game over), [2] winner, [3] error bits
 constexpr int kResultCap = 16;                                                   // matches covering the centre, per direction
 constexpr int kCompoundCap = 64;                                                 // compound components handled in one pass
@@ -323,11 +337,11 @@ __device__ inline void update_compounds(const Ctx& c, int move, int delta) {
         // only blanks; the centre lies on all four lines and is handled once (findCompound)
         if (!(i == 6 && dir != 0) && ((syms >> (2 * i)) & 3u) == 3u) {
             const int cell = move + (i - 6) * dir_stride(dir);
-            const int32_t* density = reinterpret_cast<const int32_t*>(c.st + oDensity);
+            const uint32_t* density = c.st + oDensity;
             const uint32_t* pd = c.st + oPdist + pdist_index(cell, 0);
             const uint32_t any = pd[5] | pd[4] | pd[3];
             for (int pb = 0; pb < 2; ++pb) {                    // { White, Black }
-                if (density[(pb * 2 + 0) * kCells + cell] < 2) continue;
+                if (density_count(density[pb * kCells + cell]) < 2) continue;
                 const uint32_t bits = (any >> (8 * group2(pb, pb))) & 0xFFu;           // Compound::Test (Pattern.cpp:424-433)
                 if (!(bits & (bits - 1u))) continue;
                 queue_compound(c, cell, pb, delta);
@@ -346,18 +360,17 @@ __device__ inline void update_block(const Ctx& c, int move, int delta, int src_b
     const int x = move % 15 + dx, y = move / 15 + dy;
     if (static_cast<unsigned>(x) >= 15u || static_cast<unsigned>(y) >= 15u) return;
     const int q = y * 15 + x, w = static_cast<int>((kW[dy + 3] >> (4 * (6 - (dx + 3)))) & 15u);
-    int32_t* density = reinterpret_cast<int32_t*>(c.st + oDensity);
+    uint32_t* density = c.st + oDensity;
     int32_t* scores = reinterpret_cast<int32_t*>(c.st + oScores);
-    int32_t* count = density + (src_black * 2 + 0) * kCells;
-    int32_t* weight = density + (src_black * 2 + 1) * kCells;
+    uint32_t* mine = density + src_black * kCells + q;          // count | weight << 16 of the mover's colour at q
     int32_t* score = scores + group2(src_black, src_black) * kCells;
     const bool centre = q == move;
-    int32_t* o_count = density + ((src_black ^ 1) * 2 + 0) * kCells + move;             // the other colour's entries of the centre cell
-    int32_t* o_weight = density + ((src_black ^ 1) * 2 + 1) * kCells + move;
+    uint32_t* other = density + (src_black ^ 1) * kCells + move;                       // the other colour's entry of the centre cell
     int32_t* o_score = scores + group2(src_black ^ 1, src_black ^ 1) * kCells + move;
     // everything is read first (one LDS round trip), updated in registers in the reference's order, then stored
-    int wv = weight[q], cv = count[q], sv = score[q];
-    int ocv = centre ? *o_count : 0, owv = centre ? *o_weight : 0, osv = centre ? *o_score : 0;
+    const uint32_t mw = *mine, ow = centre ? *other : 0u;
+    int wv = density_weight_of(mw), cv = density_count(mw), sv = score[q];
+    int ocv = density_count(ow), owv = density_weight_of(ow), osv = centre ? *o_score : 0;
     const int before = wv > 0;
     wv += (wv < 0 ? -1 : 1) * delta * w;
     cv += (wv < 0 ? -1 : 1) * delta * (w > 0 ? 1 : 0);          // the sign of the UPDATED weight (a lazily evaluated expression in the reference)
@@ -369,8 +382,8 @@ __device__ inline void update_block(const Ctx& c, int move, int delta, int src_b
     }
     sv += 160 * ((wv > 0) - before);
     if (centre && ocv != 0 && ocv != -1) osv -= delta * 160;
-    weight[q] = wv; count[q] = cv; score[q] = sv;
-    if (centre) { *o_count = ocv; *o_weight = owv; *o_score = osv; }
+    *mine = density_word(cv, wv); score[q] = sv;
+    if (centre) { *other = density_word(ocv, owv); *o_score = osv; }
 }
 
 // BoardMap::applyMove / revertMove (Mapping.cpp:37-59): lanes 0..3, one line word each.  Placing a stone turns the cell's

@@ -12,7 +12,7 @@
 namespace {
 
 using namespace gmk::evs;
-constexpr int kGamesPerBlock = 7;                // 7 x 19.1 KB of state and scratch + 14.8 KB of automaton tables fit one CU's 160 KB of LDS
+constexpr int kGamesPerBlock = 8;                // 8 x 17.4 KB of state and scratch + 14.4 KB of automaton tables fit one CU's 160 KB of LDS (7 before the density words were packed)
 constexpr int kThreads = 64 * kGamesPerBlock;
 
 __global__ __launch_bounds__(kThreads)
@@ -32,7 +32,6 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
         uint4* dst = reinterpret_cast<uint4*>(st);
         // six loads in flight per lane (one by one the copy is eighteen trips to memory in a row)
         constexpr int kQuads = kStateWords / 4, kRounds = kQuads / 64;              // whole rounds of 64 lanes, then the rest
-        static_assert(kRounds % 6 == 5 && kQuads % 64 != 0, "copy batches below");
 #pragma unroll
         for (int r0 = 0; r0 < kRounds + 1; r0 += 6) {
             uint4 t[6];
@@ -162,7 +161,7 @@ extern "C" int gmk_evalstate_read(gmk_evalstate* e, int32_t* h_scores, int32_t* 
     for (int g = 0; g < e->n_games; ++g) {
         const uint32_t* s = all.data() + static_cast<size_t>(g) * kStateWords;
         if (h_scores) std::memcpy(h_scores + static_cast<size_t>(g) * 900, s + oScores, 3600);
-        if (h_density) std::memcpy(h_density + static_cast<size_t>(g) * 900, s + oDensity, 3600);
+        if (h_density) unpack_density(s, h_density + static_cast<size_t>(g) * 900);
         if (h_pattern_dist)
             for (int cell = 0; cell < 226; ++cell) std::memcpy(h_pattern_dist + (static_cast<size_t>(g) * 226 + cell) * 8, s + oPdist + pdist_index(cell, 0), 32);
         if (h_compound_dist) std::memcpy(h_compound_dist + static_cast<size_t>(g) * 226 * 3, s + oCdist, 226 * 3 * 4);

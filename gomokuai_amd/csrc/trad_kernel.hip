@@ -33,7 +33,10 @@ namespace {
 using namespace gmk::evs;
 using namespace gmk::tree;
 
-constexpr int kGamesPerBlock = 7;
+#ifndef GMK_TRAD_GAMES
+#define GMK_TRAD_GAMES 7
+#endif
+constexpr int kGamesPerBlock = GMK_TRAD_GAMES;
 constexpr int kThreads = 64 * kGamesPerBlock;
 constexpr int kPathCap = 228;                    // a path has at most 226 nodes
 constexpr int kRecordWords = 57;
@@ -105,13 +108,13 @@ __device__ __forceinline__ void normalize225(Cells& x, int lane) {
 
 // Heuristic::DensityWeight (Heuristic.hpp:39-45)
 __device__ __forceinline__ Cells density_weight(const uint32_t* st, int black, int lane) {
-    const int32_t* counts = reinterpret_cast<const int32_t*>(st + oDensity) + (black * 2 + 0) * kCells;
-    const int32_t* weights = reinterpret_cast<const int32_t*>(st + oDensity) + (black * 2 + 1) * kCells;
+    const uint32_t* packed = st + oDensity + black * kCells;      // count | weight << 16
     Cells out;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = min(lane + 64 * j, kCells - 1);
-        const float N = static_cast<float>(max(counts[q], 0)), W = static_cast<float>(max(weights[q], 0));
+        const uint32_t w = packed[q];
+        const float N = static_cast<float>(max(density_count(w), 0)), W = static_cast<float>(max(density_weight_of(w), 0));
         out.v[j] = (3.0f * W) / (1.0f + 2.0f * N);
     }
     normalize225(out, lane);
@@ -1095,7 +1098,7 @@ extern "C" int gmk_trad_read_evaluators(gmk_trad* t, int32_t* h_scores, int32_t*
     for (int g = 0; g < t->n_games; ++g) {
         const uint32_t* s = all.data() + static_cast<size_t>(g) * kStateWords;
         if (h_scores) std::memcpy(h_scores + static_cast<size_t>(g) * 900, s + oScores, 3600);
-        if (h_density) std::memcpy(h_density + static_cast<size_t>(g) * 900, s + oDensity, 3600);
+        if (h_density) unpack_density(s, h_density + static_cast<size_t>(g) * 900);
         if (h_pattern_dist)
             for (int cell = 0; cell < 226; ++cell) std::memcpy(h_pattern_dist + (static_cast<size_t>(g) * 226 + cell) * 8, s + oPdist + pdist_index(cell, 0), 32);
         if (h_compound_dist) std::memcpy(h_compound_dist + static_cast<size_t>(g) * 226 * 3, s + oCdist, 226 * 3 * 4);
