@@ -259,7 +259,7 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
     tree.close()
     saturated = None
     if args.trad_saturated_games > n:
-        # 1 792 games are exactly the wavefronts the chip holds (7 per CU: the evaluator states fill the LDS), so that launch lasts as long as
+        # 2 048 games are exactly the wavefronts the chip holds (8 per CU: the evaluator states fill the LDS), so that launch lasts as long as
         # its slowest game; with four times the games the workgroups that finish early are replaced: the search rate without that wait
         ns = args.trad_saturated_games
         big = G.TraditionalMCTS(ns, node_capacity=args.trad_nodes, c_puct=5.0)
@@ -591,16 +591,16 @@ def parse_args(argv=None):
     ap.add_argument("--mcts-saturated-games", type=int, default=16384, help="games per GPU for the saturated-batch K3 figure beside configs[2]; 0 = skip")
     ap.add_argument("--selfplay-games", type=int, default=32768,
                     help="games IN TOTAL (over all GPUs) for the self-play pipeline measurement (BASELINE configs[3]); 0 = skip")
-    ap.add_argument("--evalstate-games", type=int, default=1792, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
+    ap.add_argument("--evalstate-games", type=int, default=2048, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
     ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
     ap.add_argument("--az-playouts", type=int, default=60)
     ap.add_argument("--az-selfplay-games", type=int, default=4096, help="whole games per GPU of the network-guided searcher against itself (through a quarter as many slots); 0 = skip")
     ap.add_argument("--az-selfplay-playouts", type=int, default=32)
-    ap.add_argument("--trad-games", type=int, default=1792, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
+    ap.add_argument("--trad-games", type=int, default=2048, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
-    ap.add_argument("--trad-saturated-games", type=int, default=7168, help="games per GPU for the saturated-batch K6 figure beside the 1 792-game one; 0 = skip")
-    ap.add_argument("--sup-games", type=int, default=7168, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots); 0 = skip")
+    ap.add_argument("--trad-saturated-games", type=int, default=8192, help="games per GPU for the saturated-batch K6 figure beside the 2 048-game one; 0 = skip")
+    ap.add_argument("--sup-games", type=int, default=8192, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots); 0 = skip")
     ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
     ap.add_argument("--rave-playouts", type=int, default=400)
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which `--gpus N` without a launcher stops its rank processes")

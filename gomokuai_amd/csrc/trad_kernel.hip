@@ -34,14 +34,22 @@ using namespace gmk::evs;
 using namespace gmk::tree;
 
 #ifndef GMK_TRAD_GAMES
-#define GMK_TRAD_GAMES 7
+#define GMK_TRAD_GAMES 8
 #endif
 constexpr int kGamesPerBlock = GMK_TRAD_GAMES;
 constexpr int kThreads = 64 * kGamesPerBlock;
 constexpr int kPathCap = 228;                    // a path has at most 226 nodes
+#ifndef GMK_TRAD_LINK_LDS
+#define GMK_TRAD_LINK_LDS 48                      // (a test build with 2 sends every search of the suite through the HBM part)
+#endif
+constexpr int kLinkLds = GMK_TRAD_LINK_LDS;                     // levels whose child range is kept in LDS; deeper ones (no search of the suite gets there) go through HBM
+constexpr int kPathSpill = kPathCap - kLinkLds;
 constexpr int kRecordWords = 57;
-// per-game LDS: evaluator state | evaluator scratch | path nodes (id | cell << 24) | path child ranges | record copy
-constexpr int kPerGame = (kStateWords + kScratchWords + 2 * kPathCap + kRecordWords + 3) & ~3;
+// per-game LDS: evaluator state | evaluator scratch | path nodes (id | cell << 24) | path child ranges (the first kLinkLds levels) | record copy
+// 8 x 18.2 KB + 14.4 KB of tables = 159.9 of a CU's 160 KB: what a search gains from one more game per CU it gains in full (the chains do
+// not slow each other: 5 / 6 / 7 games per CU searched at 17.7 / 21.3 / 24.0 M playouts/s)
+constexpr int kPerGame = (kStateWords + kScratchWords + kPathCap + kLinkLds + kRecordWords + 3) & ~3;
+static_assert(kGamesPerBlock * kPerGame + 2224 + 1248 + gmk::kPrefixWords <= 160 * 256, "LDS of a workgroup (production tables: 2 224 + 1 248 words)");
 
 struct TradParams {
     uint32_t* states;                            // [n_games][kStateWords]
@@ -56,6 +64,7 @@ struct TradParams {
     const uint32_t* g_trans;
     const uint32_t* g_records;
     int trans_words, record_words;
+    uint32_t* path_spill;                        // [n_games][kPathSpill]
     int n_games, cap, playouts;
     int profile;                                 // diagnostic runs only
     double c_puct;
@@ -181,7 +190,10 @@ __device__ __forceinline__ void decisive_filter(const uint32_t* st, int cur_blac
 struct Game {
     Ctx c;
     uint32_t* path_node;
-    uint32_t* path_link;
+    uint32_t* path_link;                             // [kLinkLds] in LDS
+    uint32_t* path_spill;                            // [kPathSpill] in HBM
+    __device__ __forceinline__ uint32_t link_at(int d) const { return d < kLinkLds ? path_link[d] : path_spill[d - kLinkLds]; }
+    __device__ __forceinline__ void set_link(int d, uint32_t v) const { if (d < kLinkLds) path_link[d] = v; else path_spill[d - kLinkLds] = v; }
     uint8_t* record_copy;
     uint2* stat;
     uint2* info;
@@ -215,7 +227,8 @@ void trad_playouts_kernel(TradParams prm) {
               reinterpret_cast<const char*>(lds + prm.trans_words + prm.record_words - gmk::kPrefixWords), lane};
     g.path_node = base + kStateWords + kScratchWords;
     g.path_link = g.path_node + kPathCap;
-    g.record_copy = reinterpret_cast<uint8_t*>(g.path_link + kPathCap);
+    g.path_spill = prm.path_spill + static_cast<size_t>(game) * kPathSpill;
+    g.record_copy = reinterpret_cast<uint8_t*>(g.path_link + kLinkLds);
     const size_t arena = static_cast<size_t>(game) * prm.cap;
     g.stat = prm.stat + arena;
     g.info = prm.info + arena;
@@ -268,7 +281,7 @@ void trad_playouts_kernel(TradParams prm) {
 
     // path[0 .. valid] is known to be the chain of first children from the root (node id | cell << 24, child range)
     int valid = 0;
-    if (lane == 0) { g.path_node[0] = 0u; g.path_link[0] = fresh ? 0u : g.link[0]; }
+    if (lane == 0) { g.path_node[0] = 0u; g.set_link(0, fresh ? 0u : g.link[0]); }
     wave_phase_fence();
 
     struct Level {                                              // what backup needs of one path node: its statistics and its children
@@ -277,7 +290,7 @@ void trad_playouts_kernel(TradParams prm) {
     };
     auto load_level = [&](int d) {
         Level L;
-        const uint32_t nd = g.path_node[d] & 0xFFFFFFu, lk = g.path_link[d], first = lk & 0xFFFFFFu, n = lk >> 24;
+        const uint32_t nd = g.path_node[d] & 0xFFFFFFu, lk = g.link_at(d), first = lk & 0xFFFFFFu, n = lk >> 24;
         L.ns = g.stat[nd];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -296,13 +309,13 @@ void trad_playouts_kernel(TradParams prm) {
             // ---- select: always the first child in the current order (RAVE::Select): the tree walk needs no evaluator ----
             depth = valid;
             node = g.path_node[depth] & 0xFFFFFFu;
-            link = g.path_link[depth];
+            link = g.link_at(depth);
             while (link >> 24) {
                 const uint2 rec = g.front[node];
                 node = rec.x & 0xFFFFFFu;
                 link = rec.y;
                 ++depth;
-                if (lane == 0) { g.path_node[depth] = rec.x; g.path_link[depth] = link; }
+                if (lane == 0) { g.path_node[depth] = rec.x; g.set_link(depth, link); }
             }
             wave_phase_fence();
             // ---- Heuristic::CachedApplyMove (Heuristic.hpp:165-189) for the moves of the path: the ones the evaluator's record
@@ -350,7 +363,7 @@ void trad_playouts_kernel(TradParams prm) {
                     g.stat[0] = make_uint2(0u, 0u);
                     g.info[0] = make_uint2(kNoParent | ((n_position ? slot_moves[n_position - 1] : 255u) << 24), __float_as_uint(1.0f));
                     g.link[0] = 0u;
-                    g.path_link[0] = 0u;
+                    g.set_link(0, 0u);
                 }
                 n_nodes = 1;
                 status = 0;
@@ -428,9 +441,9 @@ void trad_playouts_kernel(TradParams prm) {
                         g.link[node] = link;
                         g.front[node] = make_uint2(front_rec, 0u);
                         if (depth > 0) g.front[g.path_node[depth - 1] & 0xFFFFFFu] = make_uint2(g.path_node[depth], link);      // the parent's record of this node
-                        g.path_link[depth] = link;
+                        g.set_link(depth, link);
                         g.path_node[depth + 1] = front_rec;
-                        g.path_link[depth + 1] = 0u;
+                        g.set_link(depth + 1, 0u);
                     }
                     path_len = depth + 1;
                     n_nodes += total;
@@ -453,7 +466,7 @@ void trad_playouts_kernel(TradParams prm) {
         for (int d = depth; d >= 0; --d, value = -value) {
             Level nxt;
             if (d > 0) nxt = load_level(d - 1);                 // in flight while this level is reduced
-            const uint32_t nd = g.path_node[d] & 0xFFFFFFu, lk = g.path_link[d];
+            const uint32_t nd = g.path_node[d] & 0xFFFFFFu, lk = g.link_at(d);
             const uint32_t first = lk & 0xFFFFFFu, n = lk >> 24;
             const double sqrt_n = sqrt(static_cast<double>(cur.ns.x));
             double best_score = -INFINITY;
@@ -498,7 +511,7 @@ void trad_playouts_kernel(TradParams prm) {
         }
         wave_phase_fence();
         if (swap_level >= 0) {                                  // below the shallowest swap the chain of first children is a different one
-            if (lane == 0) { g.path_node[swap_level + 1] = swap_rec.x; g.path_link[swap_level + 1] = swap_rec.y; }
+            if (lane == 0) { g.path_node[swap_level + 1] = swap_rec.x; g.set_link(swap_level + 1, swap_rec.y); }
             valid = swap_level + 1;
         } else {
             valid = path_len;
@@ -877,7 +890,7 @@ extern "C" int gmk_trad_destroy(gmk_trad* t) {
     if (!t) return GMK_OK;
     (void)hipFree(t->d_states); (void)hipFree(t->d_stat); (void)hipFree(t->d_info); (void)hipFree(t->d_link);
     (void)hipFree(t->d_front); (void)hipFree(t->d_ord); (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_front2);
-    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_amaf); (void)hipFree(t->d_amaf2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens); (void)hipFree(t->d_game_ids);
+    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_amaf); (void)hipFree(t->d_amaf2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens); (void)hipFree(t->d_game_ids); (void)hipFree(t->d_path_spill);
     delete t;
     return GMK_OK;
 }
@@ -904,7 +917,8 @@ extern "C" int gmk_trad_create(int n_games, int node_capacity, gmk_trad** out) {
               hipMalloc(&t->d_hdr, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess &&
               hipMalloc(&t->d_moves, static_cast<size_t>(n_games) * 225) == hipSuccess &&
               hipMalloc(&t->d_lens, static_cast<size_t>(n_games) * 4) == hipSuccess &&
-              hipMalloc(&t->d_game_ids, static_cast<size_t>(n_games) * 4) == hipSuccess;
+              hipMalloc(&t->d_game_ids, static_cast<size_t>(n_games) * 4) == hipSuccess &&
+              hipMalloc(&t->d_path_spill, static_cast<size_t>(n_games) * kPathSpill * 4) == hipSuccess;
     if (ok) ok = hipMemset(t->d_hdr, 0, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess;
     if (ok) {
         t->game_ids.resize(static_cast<size_t>(n_games));
@@ -974,7 +988,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     TradParams prm;
     prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.front = t->d_front; prm.ord = t->d_ord; prm.hdr = t->d_hdr;
     prm.moves = t->d_moves; prm.lens = t->d_lens;
-    prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4 + gmk::kPrefixWords;
+    prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4 + gmk::kPrefixWords; prm.path_spill = t->d_path_spill;
     prm.n_games = t->n_games; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
     prm.selfplay = 0; prm.sp = TradSelfPlay{};
     static const bool profile = gmk::profile_env("GMK_TRAD_PROFILE") != nullptr;
@@ -1208,7 +1222,7 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
         TradParams prm;
         prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.front = t->d_front; prm.ord = t->d_ord; prm.hdr = t->d_hdr;
         prm.moves = t->d_moves; prm.lens = t->d_lens;
-        prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4 + gmk::kPrefixWords;
+        prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4 + gmk::kPrefixWords; prm.path_spill = t->d_path_spill;
         prm.n_games = n_slots; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
         prm.profile = 0; prm.selfplay = 1; prm.sp = sp;
         hipLaunchKernelGGL(trad_playouts_kernel, dim3((n_slots + kGamesPerBlock - 1) / kGamesPerBlock), dim3(kThreads), lds, s, prm);

@@ -101,6 +101,7 @@ struct gmk_trad {
     int32_t* d_lens = nullptr;
     std::vector<uint32_t> game_ids;                                         // the game a slot is playing, relative to the callers' first_game_id (default: the slot number)
     uint32_t* d_game_ids = nullptr;
+    uint32_t* d_path_spill = nullptr;            // [n_games][kPathSpill] K6: the child ranges of path levels the LDS copy has no room for
     bool attr_set = false, positioned = false, second_arena = false;
     int policy = 0;                                                          // 0 not searched yet, 1 TraditionalPolicy (gmk_trad_run), 2 PoolRAVEPolicy (gmk_trad_run_poolrave): one per handle
 

@@ -31,7 +31,7 @@ def k3():
 
 
 def k6():
-    n = 1792
+    n = 2048
     moves, lens, _ = G.synth_boards(n, 1)
     t = G.TraditionalMCTS(n, node_capacity=1 << 18)
     t.set_positions([[int(m) for m in moves[g, :min(int(lens[g]), 12)]] for g in range(n)])

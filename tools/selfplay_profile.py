@@ -7,7 +7,7 @@ import numpy as np, torch
 from gomokuai_amd import lib as G
 from gomokuai_amd.selfplay import _HostGames
 torch.cuda.set_device(0); G.init(0)
-n = 1792
+n = 2048
 games = _HostGames(n)
 m, l, _ = G.synth_boards(n, 0)
 games.open_with(m, l, 2)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gomokuai_amd import lib as G
 torch.cuda.set_device(0); G.init(0)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1792
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 playouts = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 cap = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 18
 moves, lens, _ = G.synth_boards(n, 1)
