@@ -16,7 +16,7 @@ for p in glob.glob("gpurun_out/pmc_k2p/m_%s/**/*counter_collection.csv" % m, rec
     for r in csv.DictReader(open(p)):
         if "evalstate_update" in r["Kernel_Name"]:
             v[r["Counter_Name"]].append(float(r["Counter_Value"]))
-upd = 1792 * 59.5 / 2          # updates per launch of tools/evalstate_time.py (apply or revert)
+upd = 2048 * 59.5 / 2          # updates per launch of tools/evalstate_time.py (apply or revert)
 print("mask %3s  %s | per update: " % (m, sys.argv[2]) + " ".join("%s %.1f" % (k[3:], sum(x) / len(x) / upd) for k, x in sorted(v.items())))
 PY
   rm -rf $out/m_$m
