@@ -573,6 +573,12 @@ extern "C" int gmk_az_set_slots(gmk_az* a, int n_total, const uint8_t* h_open_mo
         for (size_t g = 0; g < nt; ++g) {
             if (h_open_lens[g] < 0 || h_open_lens[g] > 8 || h_open_lens[g] > open_stride) { gmk::set_error("gmk_az_set_slots: opening of game %zu has %d moves (at most 8: an opening cannot be a finished game)", g, h_open_lens[g]); return GMK_ERR_ARG; }
             open_lens[g] = h_open_lens[g];
+            uint32_t seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // every opening is checked here: the device plays the later ones unseen
+            for (int i = 0; i < open_lens[g]; ++i) {
+                const uint32_t c = h_open_moves[g * static_cast<size_t>(open_stride) + i];
+                if (c >= 225u || ((seen[c >> 5] >> (c & 31u)) & 1u)) { gmk::set_error("gmk_az_set_slots: opening of game %zu is not a sequence of moves", g); return GMK_ERR_ARG; }
+                seen[c >> 5] |= 1u << (c & 31u);
+            }
         }
     std::vector<AzHeader> hdr(ns);
     std::vector<int32_t> state(ns + 1, -1);

@@ -234,3 +234,22 @@ def test_nearly_full_boards(oracle):
         np.testing.assert_array_equal(st["values"][g].view(np.uint32), q.view(np.uint32))
         assert st["root_visits"][g] == om.root_visits and st["n_nodes"][g] == om.size
     tree.close()
+
+
+def test_set_slots_checks_every_opening():
+    """gmk_az_set_slots: the openings of ALL games are checked on the host (the later ones are played by the device, unseen): a cell
+    outside the board, a cell played twice and an opening of more than eight moves are refused, for a game that starts in a slot and for
+    one that waits."""
+    t = G.AlphaZeroMCTS(2, node_capacity=4096)
+    good = np.array([[112, 113, 0], [0, 1, 2], [7, 8, 9], [30, 31, 32]], dtype=np.uint8)
+    t.set_slots(4, good, np.array([2, 3, 3, 1], dtype=np.int32))
+    assert t.live == 2
+    for bad_game in (0, 3):
+        for bad in ([230, 1, 2], [5, 5, 6]):
+            m = good.copy()
+            m[bad_game] = bad
+            with pytest.raises(G.GmkError):
+                t.set_slots(4, m, np.array([3, 3, 3, 3], dtype=np.int32))
+    with pytest.raises(G.GmkError):
+        t.set_slots(4, np.zeros((4, 12), dtype=np.uint8) + np.arange(12, dtype=np.uint8), np.array([9, 1, 1, 1], dtype=np.int32))
+    t.close()
