@@ -46,10 +46,9 @@ inline void unpack_density(const uint32_t* state, int32_t* out) {
         }
 }
 // meta: [0] moves played, [1] player to move (+1 black, -1 white, 0 game over), [2] winner, [3] error bits
-constexpr int kResultCap = 16;                                                   // matches covering the centre, per direction
 constexpr int kCompoundCap = 64;                                                 // compound components handled in one pass
-constexpr int oResultCount = 2 * 4 * kResultCap * 2, oItemCount = oResultCount + 8, oItems = oItemCount + 4;
-constexpr int kScratchWords = oItems + kCompoundCap;                             // two result sets + their counters + the component queue
+constexpr int oItemCount = 0, oItems = oItemCount + 4;
+constexpr int kScratchWords = oItems + kCompoundCap;                             // the component queue and its counter (the matches travel in registers)
 
 __device__ __forceinline__ int dir_stride(int dir) { return dir == 0 ? 1 : dir == 1 ? 15 : dir == 2 ? 16 : 14; }
 __device__ __forceinline__ int group2(int favour_black, int perspective_black) { return (favour_black << 1) | perspective_black; }   // Pattern.h:159-161
@@ -62,7 +61,7 @@ __device__ __forceinline__ void wave_phase_fence() {
 
 struct Ctx {
     uint32_t* st;                // state in LDS
-    uint32_t* scratch;           // results[2][4][kResultCap][2] + count[2][4]
+    uint32_t* scratch;           // compound component queue: count, items
     const char* trans;           // device transition words (pattern_tables.h)
     const uint4* rec;            // emission records
     const char* prefix;          // DeviceTables::dev_prefix4 (in LDS, behind the records)
@@ -118,18 +117,24 @@ __device__ __forceinline__ uint64_t window_symbols(const uint32_t* lines, int ce
 
 // Updater::matchPatterns (Pattern.cpp:128-136).  The reference matches twice per update, before and after the stone
 // changes; the two 13-symbol windows differ in the centre symbol only and do not depend on anything else the update
-// touches, so both are matched at once (window 0 = the board as it is -> result set 0, window 1 = `new_sym` in the
-// centre -> result set 1).  Only transitions at window indices 6..12 can report a match that covers the centre, and the
-// automaton forgets where it started after 7 symbols (checked for all 556 states x 4^7 strings when the tables are
-// built, PatternAutomaton::flatten), so every such transition gets its own lane: lane = (window * 4 + direction) * 7 +
+// touches, so both are matched at once (window 0 = the board as it is, window 1 = `new_sym` in the centre).  Only
+// transitions at window indices 6..12 can report a match that covers the centre, and the automaton forgets where it
+// started after 7 symbols (checked for all 556 states x 4^7 strings when the tables are built,
+// PatternAutomaton::flatten), so every such transition gets its own lane: lane = (window * 4 + direction) * 7 +
 // (k - 6) starts at the root at index max(0, k - 7) and is at the right state after at most 7 lookups -- of which the first four
-// (from the root, their reports unused) are ONE lookup in dev_prefix4.  A chain of 5 dependent LDS reads instead of 13; the order of
-// the results does not matter (every update they feed commutes).
-__device__ inline void match_patterns_both(const Ctx& c, int move, uint32_t new_sym) {
-    if (c.lane < 8) c.scratch[oResultCount + c.lane] = 0u;
-    wave_phase_fence();
+// (from the root, their reports unused) are ONE lookup in dev_prefix4.  A chain of 5 dependent LDS reads instead of 13.
+// The matches stay in registers: a transition reports at most two, the lane keeps the first for the pattern phase of ITS window
+// and hands the second to the lane of the same transition in the OTHER window (lane +- 28, two ds_bpermute), which is idle in that
+// phase: every lane then has at most one match per pattern phase, and nothing goes through an LDS queue (no counter, no slots, no
+// read-back).  The order in which the matches are applied does not matter (every update they feed commutes).
+struct Matches {
+    uint32_t w0[2], w1[2];       // [window whose pattern phase applies it]: the match (pattern_tables.h record words; w0 = 0: none),
+                                 // bits 28..30 of w0 = how far the match's last symbol lies beyond the centre
+};
+__device__ inline Matches match_patterns_both(const Ctx& c, int move, uint32_t new_sym) {
+    uint32_t first_w0 = 0, first_w1 = 0, second_w0 = 0, second_w1 = 0;
+    const int wd = c.lane / 7, k = 6 + c.lane % 7, dir = wd & 3, w = (wd >> 2) & 1;
     if (c.lane < 56) {
-        const int wd = c.lane / 7, k = 6 + c.lane % 7, dir = wd & 3, w = wd >> 2;
         uint64_t syms = window_symbols(c.st + oLines, move, dir);
         if (w) syms = (syms & ~(3ull << 12)) | (static_cast<uint64_t>(new_sym) << 12);
         const int start = k > 7 ? k - 7 : 0;
@@ -145,29 +150,36 @@ __device__ inline void match_patterns_both(const Ctx& c, int move, uint32_t new_
         if (k == 6) tw = tw_before;
         const uint32_t rid = gmk::dev_trans_record(tw);
         if (rid) {
-            uint32_t* out = c.scratch + (w * 4 + dir) * kResultCap * 2;
             const uint4 r = c.rec[rid];
             const uint32_t w0s[2] = {r.x, r.z}, w1s[2] = {r.y, r.w};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const uint32_t w0 = w0s[e];
-                if (!w0) continue;
                 const int back = k - static_cast<int>((w0 >> 27) & 1u) - 6, len = (w0 >> 5) & 7;      // HasCovered (Pattern.cpp:22-25)
-                if (back < 0 || back >= len) continue;
-                const uint32_t n = atomicAdd(&c.scratch[oResultCount + w * 4 + dir], 1u);
-                if (n < static_cast<uint32_t>(kResultCap)) { out[2 * n] = (w0 & 0x07FFFFFFu) | (static_cast<uint32_t>(back) << 28); out[2 * n + 1] = w1s[e]; }
-                else c.st[oMeta + 3] |= 4u;
+                const bool covers = w0 != 0u && back >= 0 && back < len;
+                const uint32_t kept = covers ? (w0 & 0x07FFFFFFu) | (static_cast<uint32_t>(back) << 28) : 0u;
+                if (e == 0) { first_w0 = kept; first_w1 = w1s[0]; } else { second_w0 = kept; second_w1 = w1s[1]; }
             }
+            if (!first_w0) { first_w0 = second_w0; first_w1 = second_w1; second_w0 = 0u; }       // (a lone second match is the lane's own)
         }
     }
+    // the second match goes to the same transition's lane in the other window
+    const int partner = (c.lane < 28 ? c.lane + 28 : c.lane - 28) * 4;
+    const uint32_t from_w0 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(partner, static_cast<int>(second_w0)));
+    const uint32_t from_w1 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(partner, static_cast<int>(second_w1)));
+    Matches m;
+    const bool live = c.lane < 56;
+    m.w0[w] = first_w0; m.w1[w] = first_w1;
+    m.w0[w ^ 1] = live ? from_w0 : 0u; m.w1[w ^ 1] = from_w1;
+    return m;
 }
 
-// Updater::updatePatterns (Pattern.cpp:138-165): lane = direction * 16 + result slot
-__device__ inline void update_patterns(const Ctx& c, int move, int slot, int delta) {
-    const int dir = c.lane >> 4, r = c.lane & 15;
-    if (r >= min(static_cast<int>(c.scratch[oResultCount + slot * 4 + dir]), kResultCap)) return;
-    const uint32_t* res = c.scratch + ((slot * 4 + dir) * kResultCap + r) * 2;
-    const uint32_t w0 = res[0], w1 = res[1];
+// Updater::updatePatterns (Pattern.cpp:138-165) for the matches of window `slot`: lane = the transition that found the match (or its
+// twin in the other window, for a transition's second match)
+__device__ inline void update_patterns(const Ctx& c, int move, const Matches& found, int slot, int delta) {
+    const uint32_t w0 = found.w0[slot], w1 = found.w1[slot];
+    if (!w0) return;
+    const int dir = (c.lane / 7) & 3;
     const int type = w0 & 15, fav = (w0 >> 4) & 1, back = static_cast<int>(w0 >> 28);
     int32_t* meta = reinterpret_cast<int32_t*>(c.st + oMeta);
     if (type == 8) { meta[1] = 0; meta[2] = fav ? 1 : -1; return; }                    // Five ends the game (:140-145)
@@ -402,13 +414,14 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     uint8_t* record = reinterpret_cast<uint8_t*>(c.st + oRecord);
     unsigned long long t_last = c.prof ? __builtin_amdgcn_s_memtime() : 0ull;
     // symbol the centre takes: the mover's stone (0 black, 1 white) when a move is applied, blank (3) when it is taken back
-    if (c.phases & 1) match_patterns_both(c, move, src != 0 ? (src > 0 ? 0u : 1u) : 3u);
+    Matches found{};
+    if (c.phases & 1) found = match_patterns_both(c, move, src != 0 ? (src > 0 ? 0u : 1u) : 3u);
     wave_phase_fence();
     prof_mark(c, 0, t_last);
     if (c.phases & 2) update_compounds(c, move, -1);
     wave_phase_fence();
     prof_mark(c, 1, t_last);
-    if (c.phases & 4) update_patterns(c, move, 0, -1);
+    if (c.phases & 4) update_patterns(c, move, found, 0, -1);
     wave_phase_fence();
     prof_mark(c, 2, t_last);
     // the stone itself (line words, move record, player to move) and the 7x7 block touch different words: one phase
@@ -429,7 +442,7 @@ __device__ inline void update_move(const Ctx& c, int move, int src) {
     if (c.phases & 8) update_block(c, move, src != 0 ? 1 : -1, block_colour);
     wave_phase_fence();
     prof_mark(c, 3, t_last);
-    if (c.phases & 16) update_patterns(c, move, 1, 1);
+    if (c.phases & 16) update_patterns(c, move, found, 1, 1);
     wave_phase_fence();
     prof_mark(c, 5, t_last);
     if (c.phases & 32) update_compounds(c, move, 1);
