@@ -591,7 +591,7 @@ def parse_args(argv=None):
     ap.add_argument("--mcts-saturated-games", type=int, default=16384, help="games per GPU for the saturated-batch K3 figure beside configs[2]; 0 = skip")
     ap.add_argument("--selfplay-games", type=int, default=32768,
                     help="games IN TOTAL (over all GPUs) for the self-play pipeline measurement (BASELINE configs[3]); 0 = skip")
-    ap.add_argument("--evalstate-games", type=int, default=2048, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
+    ap.add_argument("--evalstate-games", type=int, default=2304, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
     ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
     ap.add_argument("--az-playouts", type=int, default=60)
     ap.add_argument("--az-selfplay-games", type=int, default=4096, help="whole games per GPU of the network-guided searcher against itself (through a quarter as many slots); 0 = skip")

@@ -12,7 +12,7 @@
 namespace {
 
 using namespace gmk::evs;
-constexpr int kGamesPerBlock = 8;                // 8 x 17.4 KB of state and scratch + 14.4 KB of automaton tables fit one CU's 160 KB of LDS (7 before the density words were packed)
+constexpr int kGamesPerBlock = 9;                // 9 x 16.3 KB of state and scratch + 14.4 KB of automaton tables fit one CU's 160 KB of LDS (7 before the density words were packed and the matches left their LDS queue)
 constexpr int kThreads = 64 * kGamesPerBlock;
 
 __global__ __launch_bounds__(kThreads)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gomokuai_amd import lib as G
 torch.cuda.set_device(0); G.init(0)
-n, k = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 40
+n, k = int(sys.argv[1]) if len(sys.argv) > 1 else 2304, 40
 moves, lens, _ = G.synth_boards(n, 1)
 scr = np.full((n, k), -1, np.int16)
 for g in range(n):
