@@ -74,6 +74,33 @@ def test_config3_4096_games_800_playouts(oracle):
     tree.close()
 
 
+@pytest.mark.parametrize("n,per_wave", [(5000, 3), (7000, 4)])
+def test_k3_three_and_four_games_per_wavefront(oracle, n, per_wave):
+    """Batches that put three (rollouts on quads, select on quarter-waves) and four (rollouts on lane pairs) games into a wavefront --
+    gmk_mcts_create picks that from the number of games -- against the oracle on a strided sample, 60 playouts each; the last wavefront
+    is partly filled in both."""
+    P = 60
+    moves, lens, _ = G.synth_boards(n, 0, first_board=400000)
+    lens = np.minimum(lens, 6).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[i, lens[i] - 1] for i in range(n)], dtype=np.int16)
+    tree = G.BatchedMCTS(n, playouts_capacity=P)
+    assert tree.launch_info()["grid"] == -(-n // per_wave)
+    tree.set_roots(planes, last, first_game_id=123)
+    tree.run(P)
+    visits, q, rv, nodes, status = tree.root_stats()
+    assert (rv == P).all() and not status.any() and (visits.sum(1) == P - 1).all()
+    for g in list(range(0, n, n // 24)) + [n - 2, n - 1]:
+        b = oracle.new_board()
+        for i in range(int(lens[g])):
+            oracle.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
+        om = oracle.MCTS(P, 5.0, 5, G.DEFAULT_SEED, 123 + g)
+        om.run_playouts(b)
+        ov, _, _ = om.root_children()
+        assert (ov == visits[g]).all() and np.float32(q[g]).tobytes() == np.float32(om.root_value).tobytes() and nodes[g] == om.size, "game %d" % g
+    tree.close()
+
+
 def test_config4_32768_games_through_the_self_play_loop(oracle):
     """BASELINE configs[3] at its full game count, in the suite (only bench.py ran this size): 32 768 games through
     selfplay.play_games (device-resident continuous batching, two search handles), at a small playout budget so that it takes seconds.
