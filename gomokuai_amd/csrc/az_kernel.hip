@@ -480,11 +480,11 @@ struct gmk_az {
 
 extern "C" int gmk_az_destroy(gmk_az* a) {
     if (!a) return GMK_OK;
-    (void)hipFree(a->t.hdr); (void)hipFree(a->t.stat); (void)hipFree(a->t.kids); (void)hipFree(a->t.prior); (void)hipFree(a->t.parent);
-    (void)hipFree(a->other.stat); (void)hipFree(a->other.kids); (void)hipFree(a->other.prior); (void)hipFree(a->other.parent);
-    (void)hipFree(a->d_forced); (void)hipFree(a->d_noise_priors); (void)hipFree(a->d_unfinished); (void)hipFree(a->d_row_of);
-    (void)hipFree(a->slots.slot_game); (void)hipFree(a->d_open_moves); (void)hipFree(a->d_open_lens);
-    (void)hipFree(a->h_states); (void)hipFree(a->h_values); (void)hipFree(a->h_probs); (void)hipFree(a->h_paths); (void)hipFree(a->h_lens);
+    (void)gmk::device_free(a->t.hdr); (void)gmk::device_free(a->t.stat); (void)gmk::device_free(a->t.kids); (void)gmk::device_free(a->t.prior); (void)gmk::device_free(a->t.parent);
+    (void)gmk::device_free(a->other.stat); (void)gmk::device_free(a->other.kids); (void)gmk::device_free(a->other.prior); (void)gmk::device_free(a->other.parent);
+    (void)gmk::device_free(a->d_forced); (void)gmk::device_free(a->d_noise_priors); (void)gmk::device_free(a->d_unfinished); (void)gmk::device_free(a->d_row_of);
+    (void)gmk::device_free(a->slots.slot_game); (void)gmk::device_free(a->d_open_moves); (void)gmk::device_free(a->d_open_lens);
+    (void)gmk::device_free(a->h_states); (void)gmk::device_free(a->h_values); (void)gmk::device_free(a->h_probs); (void)gmk::device_free(a->h_paths); (void)gmk::device_free(a->h_lens);
     delete a;
     return GMK_OK;
 }
@@ -496,10 +496,10 @@ extern "C" int gmk_az_create(int n_games, int node_capacity, double c_puct, gmk_
     gmk_az* a = new gmk_az;
     a->t.n_games = n_games; a->t.cap = node_capacity; a->t.c_puct = c_puct;
     const size_t nodes = static_cast<size_t>(n_games) * node_capacity;
-    const bool ok = hipMalloc(&a->t.hdr, static_cast<size_t>(n_games) * sizeof(AzHeader)) == hipSuccess &&
-                    hipMalloc(&a->t.stat, nodes * 8) == hipSuccess && hipMalloc(&a->t.kids, nodes * 8) == hipSuccess &&
-                    hipMalloc(&a->t.prior, nodes * 4) == hipSuccess && hipMalloc(&a->t.parent, nodes * 4) == hipSuccess;
-    if (!ok || hipMalloc(&a->d_row_of, (static_cast<size_t>(n_games) + 1) * 4) != hipSuccess) { gmk_az_destroy(a); gmk::set_error("gmk_az_create: device allocation failed"); return GMK_ERR_HIP; }
+    const bool ok = gmk::device_malloc(&a->t.hdr, static_cast<size_t>(n_games) * sizeof(AzHeader)) == hipSuccess &&
+                    gmk::device_malloc(&a->t.stat, nodes * 8) == hipSuccess && gmk::device_malloc(&a->t.kids, nodes * 8) == hipSuccess &&
+                    gmk::device_malloc(&a->t.prior, nodes * 4) == hipSuccess && gmk::device_malloc(&a->t.parent, nodes * 4) == hipSuccess;
+    if (!ok || gmk::device_malloc(&a->d_row_of, (static_cast<size_t>(n_games) + 1) * 4) != hipSuccess) { gmk_az_destroy(a); gmk::set_error("gmk_az_create: device allocation failed"); return GMK_ERR_HIP; }
     a->t.row_of = a->d_row_of;
     a->game_ids.resize(static_cast<size_t>(n_games));
     for (int g = 0; g < n_games; ++g) a->game_ids[static_cast<size_t>(g)] = static_cast<uint32_t>(g);
@@ -556,7 +556,7 @@ extern "C" int gmk_az_set_roots(gmk_az* a, const uint16_t* h_planes, const int16
     GMK_HIP_CHECK(hipDeviceSynchronize());
     a->rooted = true;
     if (const int rc = az_compact(a, nullptr); rc != GMK_OK) return rc;
-    (void)hipFree(a->slots.slot_game); (void)hipFree(a->d_open_moves); (void)hipFree(a->d_open_lens);       // slot g plays game g again
+    (void)gmk::device_free(a->slots.slot_game); (void)gmk::device_free(a->d_open_moves); (void)gmk::device_free(a->d_open_lens);       // slot g plays game g again
     a->slots = AzSlots{}; a->d_open_moves = nullptr; a->d_open_lens = nullptr;
     return GMK_OK;
 }
@@ -600,14 +600,14 @@ extern "C" int gmk_az_set_slots(gmk_az* a, int n_total, const uint8_t* h_open_mo
     }
     state[ns] = started;                                         // next_game
     GMK_HIP_CHECK(hipDeviceSynchronize());
-    (void)hipFree(a->slots.slot_game); (void)hipFree(a->d_open_moves); (void)hipFree(a->d_open_lens);
+    (void)gmk::device_free(a->slots.slot_game); (void)gmk::device_free(a->d_open_moves); (void)gmk::device_free(a->d_open_lens);
     a->slots = AzSlots{}; a->d_open_moves = nullptr; a->d_open_lens = nullptr;
-    GMK_HIP_CHECK(hipMalloc(&a->slots.slot_game, state.size() * 4));
+    GMK_HIP_CHECK(gmk::device_malloc(&a->slots.slot_game, state.size() * 4));
     GMK_HIP_CHECK(hipMemcpy(a->slots.slot_game, state.data(), state.size() * 4, hipMemcpyHostToDevice));
-    GMK_HIP_CHECK(hipMalloc(&a->d_open_lens, nt * 4));
+    GMK_HIP_CHECK(gmk::device_malloc(&a->d_open_lens, nt * 4));
     GMK_HIP_CHECK(hipMemcpy(a->d_open_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
     if (h_open_moves) {
-        GMK_HIP_CHECK(hipMalloc(&a->d_open_moves, nt * static_cast<size_t>(open_stride)));
+        GMK_HIP_CHECK(gmk::device_malloc(&a->d_open_moves, nt * static_cast<size_t>(open_stride)));
         GMK_HIP_CHECK(hipMemcpy(a->d_open_moves, h_open_moves, nt * static_cast<size_t>(open_stride), hipMemcpyHostToDevice));
     }
     a->slots.next_game = a->slots.slot_game + ns;
@@ -644,11 +644,11 @@ extern "C" int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values,
 static int az_second_arena(gmk_az* a) {
     if (a->second_arena) return GMK_OK;
     const size_t n = static_cast<size_t>(a->t.n_games), nodes = n * static_cast<size_t>(a->t.cap);
-    const bool ok = hipMalloc(&a->other.stat, nodes * 8) == hipSuccess && hipMalloc(&a->other.kids, nodes * 8) == hipSuccess &&
-                    hipMalloc(&a->other.prior, nodes * 4) == hipSuccess && hipMalloc(&a->other.parent, nodes * 4) == hipSuccess &&
-                    hipMalloc(&a->d_forced, n * 2) == hipSuccess;
+    const bool ok = gmk::device_malloc(&a->other.stat, nodes * 8) == hipSuccess && gmk::device_malloc(&a->other.kids, nodes * 8) == hipSuccess &&
+                    gmk::device_malloc(&a->other.prior, nodes * 4) == hipSuccess && gmk::device_malloc(&a->other.parent, nodes * 4) == hipSuccess &&
+                    gmk::device_malloc(&a->d_forced, n * 2) == hipSuccess;
     if (!ok) {                                                      // all or nothing: a later call must not find half an arena
-        (void)hipFree(a->other.stat); (void)hipFree(a->other.kids); (void)hipFree(a->other.prior); (void)hipFree(a->other.parent); (void)hipFree(a->d_forced);
+        (void)gmk::device_free(a->other.stat); (void)gmk::device_free(a->other.kids); (void)gmk::device_free(a->other.prior); (void)gmk::device_free(a->other.parent); (void)gmk::device_free(a->d_forced);
         a->other = AzArena{}; a->d_forced = nullptr;
         (void)hipGetLastError();
         gmk::set_error("gmk_az: hipMalloc of the second arena (%zu nodes) failed", nodes);
@@ -679,7 +679,7 @@ extern "C" int gmk_az_advance(gmk_az* a, uint8_t* d_moves, uint16_t* d_visits, i
     if (!a->rooted) { gmk::set_error("gmk_az_advance: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
     if (reuse_subtree)
         if (const int rc = az_second_arena(a); rc != GMK_OK) return rc;
-    if (!a->d_unfinished) GMK_HIP_CHECK(hipMalloc(&a->d_unfinished, 4));
+    if (!a->d_unfinished) GMK_HIP_CHECK(gmk::device_malloc(&a->d_unfinished, 4));
     hipStream_t s = static_cast<hipStream_t>(stream);
     GMK_HIP_CHECK(hipMemsetAsync(a->d_unfinished, 0, 4, s));
     hipLaunchKernelGGL(az_advance_kernel, dim3(a->t.n_games), dim3(64), 0, s, a->t, a->other, d_moves, d_visits, d_lens, d_winner, a->d_unfinished, reuse_subtree ? 1 : 0, a->slots);
@@ -713,7 +713,7 @@ extern "C" int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint
         for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
         if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + a->game_ids[g], hdr[g].stones));
     });
-    if (!a->d_noise_priors) GMK_HIP_CHECK(hipMalloc(&a->d_noise_priors, n * 225 * 4));
+    if (!a->d_noise_priors) GMK_HIP_CHECK(gmk::device_malloc(&a->d_noise_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(a->d_noise_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(az_set_root_priors_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, a->d_noise_priors);
     GMK_HIP_CHECK(hipGetLastError());
@@ -743,9 +743,9 @@ __global__ void az_leaf_path_kernel(AzTree t, int16_t* paths, int32_t* lens) {
 static bool az_host_scratch(gmk_az* a) {
     if (a->h_states) return true;
     const size_t n = static_cast<size_t>(a->t.n_games);
-    return hipMalloc(&a->h_states, n * 6 * 225 * 4) == hipSuccess && hipMalloc(&a->h_values, n * 4) == hipSuccess &&
-           hipMalloc(&a->h_probs, n * 225 * 4) == hipSuccess && hipMalloc(&a->h_paths, n * 226 * 2) == hipSuccess &&
-           hipMalloc(&a->h_lens, n * 4) == hipSuccess;
+    return gmk::device_malloc(&a->h_states, n * 6 * 225 * 4) == hipSuccess && gmk::device_malloc(&a->h_values, n * 4) == hipSuccess &&
+           gmk::device_malloc(&a->h_probs, n * 225 * 4) == hipSuccess && gmk::device_malloc(&a->h_paths, n * 226 * 2) == hipSuccess &&
+           gmk::device_malloc(&a->h_lens, n * 4) == hipSuccess;
 }
 
 // gmk_az_select, then for every game the moves from the root to its pending leaf: h_paths int16[n][226], h_lens int32[n]
@@ -780,10 +780,10 @@ extern "C" int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values,
     const size_t n = static_cast<size_t>(a->t.n_games);
     uint32_t *d_visits = nullptr, *d_root_visits = nullptr;
     float *d_values = nullptr, *d_priors = nullptr, *d_root_value = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_values); (void)hipFree(d_priors); (void)hipFree(d_root_visits); (void)hipFree(d_root_value); };
+    auto cleanup = [&]() { (void)gmk::device_free(d_visits); (void)gmk::device_free(d_values); (void)gmk::device_free(d_priors); (void)gmk::device_free(d_root_visits); (void)gmk::device_free(d_root_value); };
 #define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
-    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4)); GMK_TRY(hipMalloc(&d_priors, n * 225 * 4));
-    GMK_TRY(hipMalloc(&d_root_visits, n * 4)); GMK_TRY(hipMalloc(&d_root_value, n * 4));
+    GMK_TRY(gmk::device_malloc(&d_visits, n * 225 * 4)); GMK_TRY(gmk::device_malloc(&d_values, n * 225 * 4)); GMK_TRY(gmk::device_malloc(&d_priors, n * 225 * 4));
+    GMK_TRY(gmk::device_malloc(&d_root_visits, n * 4)); GMK_TRY(gmk::device_malloc(&d_root_value, n * 4));
     GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_priors, 0, n * 225 * 4));
     GMK_TRY(hipDeviceSynchronize());
     hipLaunchKernelGGL(az_root_stats_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, d_visits, d_values, d_priors, d_root_visits, d_root_value);

@@ -1,4 +1,5 @@
 // capi.hip -- library lifecycle + pattern-table accessors of the C-ABI (include/gomoku_hip.h).
+#include <mutex>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +28,67 @@ using gmk::device_state;
 using gmk::production_automaton;
 
 extern "C" const char* gmk_last_error(void) { return gmk::g_error; }
+
+namespace gmk {
+namespace {
+struct PoolBlock { void* p; size_t bytes; bool used; };
+std::mutex g_pool_mutex;
+std::vector<PoolBlock> g_pool;
+constexpr size_t kPoolMinBytes = size_t(16) << 20, kPoolCapBytes = size_t(160) << 30;
+size_t pool_idle_bytes() { size_t t = 0; for (const PoolBlock& b : g_pool) if (!b.used) t += b.bytes; return t; }
+void pool_drop_idle(size_t keep) {                                 // gives idle blocks back to the driver, largest first, until at most `keep` bytes idle
+    while (pool_idle_bytes() > keep) {
+        size_t at = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); ++i) if (!g_pool[i].used && (at == g_pool.size() || g_pool[i].bytes > g_pool[at].bytes)) at = i;
+        if (at == g_pool.size()) return;
+        (void)hipFree(g_pool[at].p);
+        g_pool.erase(g_pool.begin() + static_cast<long>(at));
+    }
+}
+}  // namespace
+
+hipError_t device_malloc_bytes(void** p, size_t bytes) {
+    if (bytes < kPoolMinBytes) return hipMalloc(p, bytes);
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    size_t best = g_pool.size();
+    for (size_t i = 0; i < g_pool.size(); ++i)
+        if (!g_pool[i].used && g_pool[i].bytes >= bytes && g_pool[i].bytes - bytes <= bytes / 4 && (best == g_pool.size() || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    if (best != g_pool.size()) {
+        g_pool[best].used = true;
+        *p = g_pool[best].p;
+        if (kProfileBuild && profile_env("GMK_POOL_POISON")) return hipMemset(*p, 0xA5, g_pool[best].bytes);      // diagnostic: a reused block is NOT zero
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {                                          // make room: everything idle goes back to the driver, then once more
+        (void)hipGetLastError();
+        pool_drop_idle(0);
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) g_pool.push_back(PoolBlock{*p, bytes, true});
+    return e;
+}
+
+hipError_t device_free(void* p) {
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (PoolBlock& b : g_pool)
+            if (b.p == p) {
+                (void)hipDeviceSynchronize();                      // as hipFree would: nothing may still be running on the block when the next handle gets it
+                b.used = false;
+                pool_drop_idle(kPoolCapBytes);
+                return hipSuccess;
+            }
+    }
+    return hipFree(p);
+}
+
+void device_pool_release() {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    pool_drop_idle(0);
+}
+}  // namespace gmk
 
 extern "C" int gmk_init(int device) {
     gmk::DeviceState& st = device_state();
@@ -59,6 +121,7 @@ extern "C" int gmk_init(int device) {
 extern "C" int gmk_shutdown(void) {
     gmk::DeviceState& st = device_state();
     if (!st.ready) return GMK_OK;
+    gmk::device_pool_release();
     (void)hipFree(st.d_trans);
     (void)hipFree(st.d_records);
     st = gmk::DeviceState{};

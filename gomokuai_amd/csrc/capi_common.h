@@ -35,6 +35,17 @@ inline const char* profile_env(const char*) { return nullptr; }
 constexpr bool kProfileBuild = false;
 #endif
 
+// Device memory for the handles.  The tree arenas are tens of GB per handle, and the driver clears what it takes back before it hands it
+// out again: a 24 GB hipMalloc that follows a hipFree of that size takes ~1.5 s instead of 1 ms (tools/alloc_probe.py), which is a third
+// of a self-play batch.  So a large block (>= 16 MB) that a handle gives up is kept in a process-wide pool and the next handle that asks for
+// about as much (the block is at most a quarter larger) gets it back, uncleared -- no kernel reads a node it has not written -- and small
+// requests go to the driver as before.  The pool holds at most kPoolCapBytes; gmk_shutdown returns everything.
+hipError_t device_malloc_bytes(void** p, size_t bytes);
+hipError_t device_free(void* p);
+void device_pool_release();
+template <class T>
+inline hipError_t device_malloc(T** p, size_t bytes) { return device_malloc_bytes(reinterpret_cast<void**>(p), bytes); }
+
 #define GMK_HIP_CHECK(expr)                                                                   \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \

@@ -663,9 +663,19 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
                          uint32_t* __restrict__ parent2, size_t cap, int n_games,
                          uint8_t* __restrict__ rec_moves, uint16_t* __restrict__ rec_visits, int32_t* __restrict__ rec_lens,
                          int8_t* __restrict__ rec_winner, int32_t* __restrict__ unfinished, int reuse,
-                         const int16_t* __restrict__ forced, SlotRefill slots) {
+                         const int16_t* __restrict__ forced, SlotRefill slots, int32_t* __restrict__ counters) {
     if (static_cast<int>(blockIdx.x) >= n_games) return;
-    advance_one(blockIdx.x, threadIdx.x, headers, stats, link, parent, stats2, link2, parent2, cap, rec_moves, rec_visits, rec_lens, rec_winner, unfinished, reuse, forced, slots);
+    // counters[0] counts the games that go on, counters[1] the workgroups that are through: the last one hands the count to the caller and
+    // leaves both at zero for the next launch -- no memset in front of every step (a four-byte fill is a launch of its own, and beside a
+    // second handle's search it waited milliseconds for a wavefront slot)
+    advance_one(blockIdx.x, threadIdx.x, headers, stats, link, parent, stats2, link2, parent2, cap, rec_moves, rec_visits, rec_lens, rec_winner, &counters[0], reuse, forced, slots);
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&counters[1], 1) == n_games - 1) {
+            *unfinished = atomicExch(&counters[0], 0);
+            atomicExch(&counters[1], 0);
+        }
+    }
 }
 
 __global__ void mcts_root_flags_kernel(GameHeader* __restrict__ headers, const uint32_t* __restrict__ link, size_t cap, int n_games) {
@@ -718,6 +728,7 @@ struct gmk_mcts {
     SlotRefill slots{};                // continuous batching (gmk_selfplay_run); all null otherwise
     struct { uint8_t* moves; uint16_t* visits; int32_t* lens; int8_t* winner; int32_t* unfinished; } persistent_rec{};     // set while gmk_selfplay_run's ONE launch is issued
     int32_t* d_slot_state = nullptr;   // [n_games + 1] slot_game, next_game
+    int32_t* d_step_counters = nullptr; // [2] mcts_advance_kernel's own (zero between launches)
     uint8_t* d_open_moves = nullptr;
     int32_t* d_open_lens = nullptr;
     void* d_step_scratch = nullptr;    // record outputs of gmk_mcts_step_host
@@ -746,8 +757,8 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
     if (const char* env = gmk::profile_env("GMK_MCTS_GAMES_PER_BLOCK")) gpb = std::atoi(env);
     m->games_per_block = std::max(1, std::min(max_gpb, gpb));
     const size_t nodes = static_cast<size_t>(n_games) * static_cast<size_t>(node_capacity);
-    if (hipMalloc(&m->d_headers, sizeof(GameHeader) * n_games) != hipSuccess || hipMalloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess ||
-        hipMalloc(&m->d_link, nodes * 4) != hipSuccess || hipMalloc(&m->d_parent, nodes * 4) != hipSuccess) {
+    if (gmk::device_malloc(&m->d_headers, sizeof(GameHeader) * n_games) != hipSuccess || gmk::device_malloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess ||
+        gmk::device_malloc(&m->d_link, nodes * 4) != hipSuccess || gmk::device_malloc(&m->d_parent, nodes * 4) != hipSuccess) {
         gmk::set_error("gmk_mcts_create: hipMalloc of %zu nodes (%.1f GB) failed", nodes, nodes * 16.0 / 1e9);
         gmk_mcts_destroy(m);
         return GMK_ERR_HIP;
@@ -762,7 +773,9 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
     }
     float value[129] = {};
     for (int s = -c_rollouts; s <= c_rollouts; ++s) value[s + c_rollouts] = static_cast<float>(static_cast<double>(s) / static_cast<double>(c_rollouts));
-    if (hipMalloc(&m->d_value, sizeof value) != hipSuccess || hipMemcpy(m->d_value, value, sizeof value, hipMemcpyHostToDevice) != hipSuccess) {
+    const int32_t zeros[2] = {0, 0};                   // (a synchronous copy: the first step may be launched on any stream)
+    if (gmk::device_malloc(&m->d_step_counters, 8) != hipSuccess || hipMemcpy(m->d_step_counters, zeros, 8, hipMemcpyHostToDevice) != hipSuccess ||
+        gmk::device_malloc(&m->d_value, sizeof value) != hipSuccess || hipMemcpy(m->d_value, value, sizeof value, hipMemcpyHostToDevice) != hipSuccess) {
         gmk::set_error("gmk_mcts_create: value table upload failed");
         gmk_mcts_destroy(m);
         return GMK_ERR_HIP;
@@ -773,9 +786,9 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
 
 extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     if (!m) return GMK_OK;
-    (void)hipFree(m->d_headers); (void)hipFree(m->d_stats); (void)hipFree(m->d_link); (void)hipFree(m->d_parent); (void)hipFree(m->d_value);
-    (void)hipFree(m->d_slot_state); (void)hipFree(m->d_open_moves); (void)hipFree(m->d_open_lens);
-    (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2); (void)hipFree(m->d_root_prior); (void)hipFree(m->d_step_scratch);
+    (void)gmk::device_free(m->d_headers); (void)gmk::device_free(m->d_stats); (void)gmk::device_free(m->d_link); (void)gmk::device_free(m->d_parent); (void)gmk::device_free(m->d_value);
+    (void)gmk::device_free(m->d_slot_state); (void)gmk::device_free(m->d_open_moves); (void)gmk::device_free(m->d_open_lens); (void)gmk::device_free(m->d_step_counters);
+    (void)gmk::device_free(m->d_stats2); (void)gmk::device_free(m->d_link2); (void)gmk::device_free(m->d_parent2); (void)gmk::device_free(m->d_root_prior); (void)gmk::device_free(m->d_step_scratch);
     delete m;
     return GMK_OK;
 }
@@ -862,19 +875,18 @@ extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t
     m->last_stream = s;
     if (reuse_subtree && !m->d_stats2) {
         const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
-        if (hipMalloc(&m->d_stats2, nodes * sizeof(uint2)) != hipSuccess || hipMalloc(&m->d_link2, nodes * 4) != hipSuccess ||
-            hipMalloc(&m->d_parent2, nodes * 4) != hipSuccess) {
-            (void)hipFree(m->d_stats2); (void)hipFree(m->d_link2); (void)hipFree(m->d_parent2);      // all or nothing: the guard above tests d_stats2
+        if (gmk::device_malloc(&m->d_stats2, nodes * sizeof(uint2)) != hipSuccess || gmk::device_malloc(&m->d_link2, nodes * 4) != hipSuccess ||
+            gmk::device_malloc(&m->d_parent2, nodes * 4) != hipSuccess) {
+            (void)gmk::device_free(m->d_stats2); (void)gmk::device_free(m->d_link2); (void)gmk::device_free(m->d_parent2);      // all or nothing: the guard above tests d_stats2
             m->d_stats2 = nullptr; m->d_link2 = nullptr; m->d_parent2 = nullptr;
             (void)hipGetLastError();
             gmk::set_error("gmk_mcts_step: hipMalloc of the second arena (%zu nodes) failed", nodes);
             return GMK_ERR_HIP;
         }
     }
-    GMK_HIP_CHECK(hipMemsetAsync(d_unfinished, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(mcts_advance_kernel, dim3(m->n_games), dim3(64), 0, s, m->d_headers, m->d_stats, m->d_link, m->d_parent,
                        m->d_stats2, m->d_link2, m->d_parent2, static_cast<size_t>(m->node_capacity), m->n_games,
-                       d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, d_forced_moves, m->slots);
+                       d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, d_forced_moves, m->slots, m->d_step_counters);
     GMK_HIP_CHECK(hipGetLastError());
     if (reuse_subtree) {                                            // the copy is the live tree from here on
         std::swap(m->d_stats, m->d_stats2);
@@ -922,13 +934,13 @@ extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id
     slot_state[static_cast<size_t>(n_slots)] = started;                         // next_game
     int rc = gmk_mcts_set_roots(m, planes.data(), last.data(), first_game_id);
     if (rc != GMK_OK) return rc;
-    if (!m->d_slot_state) GMK_HIP_CHECK(hipMalloc(&m->d_slot_state, (static_cast<size_t>(n_slots) + 1) * 4));
-    (void)hipFree(m->d_open_moves); (void)hipFree(m->d_open_lens);
+    if (!m->d_slot_state) GMK_HIP_CHECK(gmk::device_malloc(&m->d_slot_state, (static_cast<size_t>(n_slots) + 1) * 4));
+    (void)gmk::device_free(m->d_open_moves); (void)gmk::device_free(m->d_open_lens);
     m->d_open_moves = nullptr; m->d_open_lens = nullptr;
-    GMK_HIP_CHECK(hipMalloc(&m->d_open_lens, nt * 4));
+    GMK_HIP_CHECK(gmk::device_malloc(&m->d_open_lens, nt * 4));
     GMK_HIP_CHECK(hipMemcpy(m->d_open_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
     if (h_open_moves) {
-        GMK_HIP_CHECK(hipMalloc(&m->d_open_moves, nt * static_cast<size_t>(open_stride)));
+        GMK_HIP_CHECK(gmk::device_malloc(&m->d_open_moves, nt * static_cast<size_t>(open_stride)));
         GMK_HIP_CHECK(hipMemcpy(m->d_open_moves, h_open_moves, nt * static_cast<size_t>(open_stride), hipMemcpyHostToDevice));
     }
     GMK_HIP_CHECK(hipMemcpy(m->d_slot_state, slot_state.data(), slot_state.size() * 4, hipMemcpyHostToDevice));
@@ -943,7 +955,7 @@ extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id
     }
     m->slots = SlotRefill{m->d_slot_state, m->d_slot_state + n_slots, n_total, m->d_open_moves, m->d_open_lens, open_stride, first_game_id};
     int32_t* d_unfinished = nullptr;
-    GMK_HIP_CHECK(hipMalloc(&d_unfinished, 4));
+    GMK_HIP_CHECK(gmk::device_malloc(&d_unfinished, 4));
     int32_t steps = 0;
     rc = GMK_OK;
     // Without kept subtrees and root noise the whole run is ONE launch (SearchParams::persistent): every wavefront plays its slots' games
@@ -966,7 +978,7 @@ extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id
         if (hipMemcpyAsync(&unfinished, d_unfinished, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { gmk::set_error("gmk_selfplay_run: readback failed"); rc = GMK_ERR_HIP; break; }
         if (unfinished == 0) break;
     }
-    (void)hipFree(d_unfinished);
+    (void)gmk::device_free(d_unfinished);
     m->slots = SlotRefill{};
     if (h_steps) *h_steps = steps;
     return rc;
@@ -975,7 +987,7 @@ extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id
 extern "C" int gmk_mcts_step_host(gmk_mcts* m, const int16_t* h_moves, int reuse_subtree) {
     if (!m || !h_moves) { gmk::set_error("gmk_mcts_step_host: bad arguments"); return GMK_ERR_ARG; }
     const size_t n = static_cast<size_t>(m->n_games);
-    if (!m->d_step_scratch) GMK_HIP_CHECK(hipMalloc(&m->d_step_scratch, n * (225 + 4 + 2 + 1) + 64));
+    if (!m->d_step_scratch) GMK_HIP_CHECK(gmk::device_malloc(&m->d_step_scratch, n * (225 + 4 + 2 + 1) + 64));
     uint8_t* base = static_cast<uint8_t*>(m->d_step_scratch);
     int32_t* d_lens = reinterpret_cast<int32_t*>(base);
     int32_t* d_unfinished = reinterpret_cast<int32_t*>(base + n * 4);
@@ -1000,7 +1012,7 @@ extern "C" int gmk_mcts_add_root_noise(gmk_mcts* m, float alpha, float epsilon, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     m->last_stream = s;
     const size_t n = static_cast<size_t>(m->n_games);
-    if (!m->d_root_prior) GMK_HIP_CHECK(hipMalloc(&m->d_root_prior, n * 225 * sizeof(float)));
+    if (!m->d_root_prior) GMK_HIP_CHECK(gmk::device_malloc(&m->d_root_prior, n * 225 * sizeof(float)));
     hipLaunchKernelGGL(mcts_root_flags_kernel, dim3((m->n_games + 255) / 256), dim3(256), 0, s, m->d_headers, m->d_link,
                        static_cast<size_t>(m->node_capacity), m->n_games);
     GMK_HIP_CHECK(hipGetLastError());
@@ -1042,13 +1054,13 @@ extern "C" int gmk_mcts_root_stats(gmk_mcts* m, uint32_t* h_visits, float* h_roo
     uint32_t *d_visits = nullptr, *d_rv = nullptr, *d_nodes = nullptr;
     float* d_q = nullptr;
     int32_t* d_status = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_rv); (void)hipFree(d_nodes); (void)hipFree(d_q); (void)hipFree(d_status); };
+    auto cleanup = [&]() { (void)gmk::device_free(d_visits); (void)gmk::device_free(d_rv); (void)gmk::device_free(d_nodes); (void)gmk::device_free(d_q); (void)gmk::device_free(d_status); };
 #define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
-    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4));
-    GMK_TRY(hipMalloc(&d_rv, n * 4));
-    GMK_TRY(hipMalloc(&d_nodes, n * 4));
-    GMK_TRY(hipMalloc(&d_q, n * 4));
-    GMK_TRY(hipMalloc(&d_status, n * 4));
+    GMK_TRY(gmk::device_malloc(&d_visits, n * 225 * 4));
+    GMK_TRY(gmk::device_malloc(&d_rv, n * 4));
+    GMK_TRY(gmk::device_malloc(&d_nodes, n * 4));
+    GMK_TRY(gmk::device_malloc(&d_q, n * 4));
+    GMK_TRY(gmk::device_malloc(&d_status, n * 4));
     hipLaunchKernelGGL(mcts_root_stats_kernel, dim3(m->n_games), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link,
                        static_cast<size_t>(m->node_capacity), m->n_games, d_visits, d_q, d_rv, d_nodes, d_status);
     GMK_TRY(hipGetLastError());

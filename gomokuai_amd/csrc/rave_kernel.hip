@@ -350,7 +350,7 @@ extern "C" int gmk_trad_run_poolrave(gmk_trad* t, int playouts, double c_puct, u
     t->policy = 2;
     if (!t->d_amaf) {
         const size_t nodes = static_cast<size_t>(t->n_games) * static_cast<size_t>(t->cap);
-        GMK_HIP_CHECK(hipMalloc(&t->d_amaf, nodes * 8));
+        GMK_HIP_CHECK(gmk::device_malloc(&t->d_amaf, nodes * 8));
         GMK_HIP_CHECK(hipMemset(t->d_amaf, 0, nodes * 8));
     }
     RaveParams prm;
@@ -382,9 +382,9 @@ extern "C" int gmk_trad_root_amaf(gmk_trad* t, uint32_t* h_amaf_visits, float* h
     const size_t n = static_cast<size_t>(t->n_games);
     uint32_t* d_visits = nullptr;
     float* d_values = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_values); };
+    auto cleanup = [&]() { (void)gmk::device_free(d_visits); (void)gmk::device_free(d_values); };
 #define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
-    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4));
+    GMK_TRY(gmk::device_malloc(&d_visits, n * 225 * 4)); GMK_TRY(gmk::device_malloc(&d_values, n * 225 * 4));
     GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4));
     hipLaunchKernelGGL(rave_root_amaf_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->arena(), t->d_hdr, t->cap, d_visits, d_values);
     GMK_TRY(hipGetLastError());

@@ -888,9 +888,9 @@ void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t
 
 extern "C" int gmk_trad_destroy(gmk_trad* t) {
     if (!t) return GMK_OK;
-    (void)hipFree(t->d_states); (void)hipFree(t->d_stat); (void)hipFree(t->d_info); (void)hipFree(t->d_link);
-    (void)hipFree(t->d_front); (void)hipFree(t->d_ord); (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_front2);
-    (void)hipFree(t->d_link2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_amaf); (void)hipFree(t->d_amaf2); (void)hipFree(t->d_forced); (void)hipFree(t->d_priors); (void)hipFree(t->d_hdr); (void)hipFree(t->d_moves); (void)hipFree(t->d_lens); (void)hipFree(t->d_game_ids); (void)hipFree(t->d_path_spill);
+    (void)gmk::device_free(t->d_states); (void)gmk::device_free(t->d_stat); (void)gmk::device_free(t->d_info); (void)gmk::device_free(t->d_link);
+    (void)gmk::device_free(t->d_front); (void)gmk::device_free(t->d_ord); (void)gmk::device_free(t->d_stat2); (void)gmk::device_free(t->d_info2); (void)gmk::device_free(t->d_front2);
+    (void)gmk::device_free(t->d_link2); (void)gmk::device_free(t->d_ord2); (void)gmk::device_free(t->d_amaf); (void)gmk::device_free(t->d_amaf2); (void)gmk::device_free(t->d_forced); (void)gmk::device_free(t->d_priors); (void)gmk::device_free(t->d_hdr); (void)gmk::device_free(t->d_moves); (void)gmk::device_free(t->d_lens); (void)gmk::device_free(t->d_game_ids); (void)gmk::device_free(t->d_path_spill);
     delete t;
     return GMK_OK;
 }
@@ -911,14 +911,14 @@ extern "C" int gmk_trad_create(int n_games, int node_capacity, gmk_trad** out) {
     t->n_games = n_games;
     t->cap = node_capacity;
     const size_t nodes = static_cast<size_t>(n_games) * node_capacity;
-    bool ok = hipMalloc(&t->d_states, static_cast<size_t>(n_games) * kStateWords * 4) == hipSuccess &&
-              hipMalloc(&t->d_stat, nodes * 8) == hipSuccess && hipMalloc(&t->d_info, nodes * 8) == hipSuccess &&
-              hipMalloc(&t->d_link, nodes * 4) == hipSuccess && hipMalloc(&t->d_front, nodes * 8) == hipSuccess && hipMalloc(&t->d_ord, nodes) == hipSuccess &&
-              hipMalloc(&t->d_hdr, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess &&
-              hipMalloc(&t->d_moves, static_cast<size_t>(n_games) * 225) == hipSuccess &&
-              hipMalloc(&t->d_lens, static_cast<size_t>(n_games) * 4) == hipSuccess &&
-              hipMalloc(&t->d_game_ids, static_cast<size_t>(n_games) * 4) == hipSuccess &&
-              hipMalloc(&t->d_path_spill, static_cast<size_t>(n_games) * kPathSpill * 4) == hipSuccess;
+    bool ok = gmk::device_malloc(&t->d_states, static_cast<size_t>(n_games) * kStateWords * 4) == hipSuccess &&
+              gmk::device_malloc(&t->d_stat, nodes * 8) == hipSuccess && gmk::device_malloc(&t->d_info, nodes * 8) == hipSuccess &&
+              gmk::device_malloc(&t->d_link, nodes * 4) == hipSuccess && gmk::device_malloc(&t->d_front, nodes * 8) == hipSuccess && gmk::device_malloc(&t->d_ord, nodes) == hipSuccess &&
+              gmk::device_malloc(&t->d_hdr, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess &&
+              gmk::device_malloc(&t->d_moves, static_cast<size_t>(n_games) * 225) == hipSuccess &&
+              gmk::device_malloc(&t->d_lens, static_cast<size_t>(n_games) * 4) == hipSuccess &&
+              gmk::device_malloc(&t->d_game_ids, static_cast<size_t>(n_games) * 4) == hipSuccess &&
+              gmk::device_malloc(&t->d_path_spill, static_cast<size_t>(n_games) * kPathSpill * 4) == hipSuccess;
     if (ok) ok = hipMemset(t->d_hdr, 0, static_cast<size_t>(n_games) * sizeof(TradHeader)) == hipSuccess;
     if (ok) {
         t->game_ids.resize(static_cast<size_t>(n_games));
@@ -1017,11 +1017,11 @@ extern "C" int gmk_trad_step(gmk_trad* t, const int16_t* h_moves) {
     if (!t->positioned) { gmk::set_error("gmk_trad_step: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(t->n_games), nodes = n * static_cast<size_t>(t->cap);
     if (!t->second_arena) {
-        const bool ok = hipMalloc(&t->d_stat2, nodes * 8) == hipSuccess && hipMalloc(&t->d_info2, nodes * 8) == hipSuccess &&
-                        hipMalloc(&t->d_link2, nodes * 4) == hipSuccess && hipMalloc(&t->d_front2, nodes * 8) == hipSuccess &&
-                        hipMalloc(&t->d_ord2, nodes) == hipSuccess && hipMalloc(&t->d_forced, n * 2) == hipSuccess;
+        const bool ok = gmk::device_malloc(&t->d_stat2, nodes * 8) == hipSuccess && gmk::device_malloc(&t->d_info2, nodes * 8) == hipSuccess &&
+                        gmk::device_malloc(&t->d_link2, nodes * 4) == hipSuccess && gmk::device_malloc(&t->d_front2, nodes * 8) == hipSuccess &&
+                        gmk::device_malloc(&t->d_ord2, nodes) == hipSuccess && gmk::device_malloc(&t->d_forced, n * 2) == hipSuccess;
         if (!ok) {                                                  // all or nothing: a later call must not find half an arena
-            (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_link2); (void)hipFree(t->d_front2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_forced);
+            (void)gmk::device_free(t->d_stat2); (void)gmk::device_free(t->d_info2); (void)gmk::device_free(t->d_link2); (void)gmk::device_free(t->d_front2); (void)gmk::device_free(t->d_ord2); (void)gmk::device_free(t->d_forced);
             t->d_stat2 = t->d_info2 = t->d_front2 = nullptr; t->d_link2 = nullptr; t->d_ord2 = nullptr; t->d_forced = nullptr;
             (void)hipGetLastError();
             gmk::set_error("gmk_trad_step: hipMalloc of the second arena (%zu nodes) failed", nodes);
@@ -1031,7 +1031,7 @@ extern "C" int gmk_trad_step(gmk_trad* t, const int16_t* h_moves) {
     }
     GMK_HIP_CHECK(hipDeviceSynchronize());
     if (h_moves) GMK_HIP_CHECK(hipMemcpy(t->d_forced, h_moves, n * 2, hipMemcpyHostToDevice));
-    if (t->d_amaf && !t->d_amaf2 && hipMalloc(&t->d_amaf2, nodes * 8) != hipSuccess) { gmk::set_error("gmk_trad_step: hipMalloc of the second arena (%zu nodes) failed", nodes); return GMK_ERR_HIP; }
+    if (t->d_amaf && !t->d_amaf2 && gmk::device_malloc(&t->d_amaf2, nodes * 8) != hipSuccess) { gmk::set_error("gmk_trad_step: hipMalloc of the second arena (%zu nodes) failed", nodes); return GMK_ERR_HIP; }
     const TradArena a = t->arena(), b = t->arena2();
     hipLaunchKernelGGL(trad_step_kernel, dim3(t->n_games), dim3(64), 0, nullptr, a, b, t->d_hdr, t->cap, t->n_games,
                        h_moves ? t->d_forced : nullptr, t->d_moves, t->d_lens);
@@ -1058,7 +1058,7 @@ extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, 
         for (int i = 0; i < 225; ++i) any |= p[i] != 0.0f;
         if (any) gmk::mix_root_noise(p, 225, alpha, epsilon, gmk::root_noise_engine_seed(seed, first_game_id + t->game_ids[g], static_cast<uint32_t>(lens[g])));
     });
-    if (!t->d_priors) GMK_HIP_CHECK(hipMalloc(&t->d_priors, n * 225 * 4));
+    if (!t->d_priors) GMK_HIP_CHECK(gmk::device_malloc(&t->d_priors, n * 225 * 4));
     GMK_HIP_CHECK(hipMemcpy(t->d_priors, priors.data(), n * 225 * 4, hipMemcpyHostToDevice));
     const TradArena a = t->arena();
     hipLaunchKernelGGL(trad_set_root_priors_kernel, dim3(t->n_games), dim3(64), 0, nullptr, a, t->d_hdr, t->cap, t->d_priors);
@@ -1076,10 +1076,10 @@ extern "C" int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_val
     uint32_t *d_visits = nullptr, *d_root_visits = nullptr;
     float *d_values = nullptr, *d_priors = nullptr, *d_root_value = nullptr;
     int32_t* d_best = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_visits); (void)hipFree(d_values); (void)hipFree(d_priors); (void)hipFree(d_best); (void)hipFree(d_root_visits); (void)hipFree(d_root_value); };
+    auto cleanup = [&]() { (void)gmk::device_free(d_visits); (void)gmk::device_free(d_values); (void)gmk::device_free(d_priors); (void)gmk::device_free(d_best); (void)gmk::device_free(d_root_visits); (void)gmk::device_free(d_root_value); };
 #define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("%s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
-    GMK_TRY(hipMalloc(&d_visits, n * 225 * 4)); GMK_TRY(hipMalloc(&d_values, n * 225 * 4)); GMK_TRY(hipMalloc(&d_priors, n * 225 * 4));
-    GMK_TRY(hipMalloc(&d_best, n * 4)); GMK_TRY(hipMalloc(&d_root_visits, n * 4)); GMK_TRY(hipMalloc(&d_root_value, n * 4));
+    GMK_TRY(gmk::device_malloc(&d_visits, n * 225 * 4)); GMK_TRY(gmk::device_malloc(&d_values, n * 225 * 4)); GMK_TRY(gmk::device_malloc(&d_priors, n * 225 * 4));
+    GMK_TRY(gmk::device_malloc(&d_best, n * 4)); GMK_TRY(gmk::device_malloc(&d_root_visits, n * 4)); GMK_TRY(gmk::device_malloc(&d_root_value, n * 4));
     GMK_TRY(hipMemset(d_visits, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_values, 0, n * 225 * 4)); GMK_TRY(hipMemset(d_priors, 0, n * 225 * 4));
     hipLaunchKernelGGL(trad_root_stats_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->d_stat, t->d_info, t->d_link, t->d_ord, t->d_hdr, t->cap,
                        d_visits, d_values, d_priors, d_best, d_root_visits, d_root_value);
@@ -1175,14 +1175,14 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
     int32_t* d_state = nullptr;
     uint8_t* d_open_moves = nullptr;
     int32_t* d_open_lens = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_state); (void)hipFree(d_open_moves); (void)hipFree(d_open_lens); };
+    auto cleanup = [&]() { (void)gmk::device_free(d_state); (void)gmk::device_free(d_open_moves); (void)gmk::device_free(d_open_lens); };
 #define GMK_TRY(expr) do { if ((expr) != hipSuccess) { gmk::set_error("gmk_trad_selfplay_run: %s failed", #expr); cleanup(); return GMK_ERR_HIP; } } while (0)
-    GMK_TRY(hipMalloc(&d_state, state.size() * 4));
+    GMK_TRY(gmk::device_malloc(&d_state, state.size() * 4));
     GMK_TRY(hipMemcpy(d_state, state.data(), state.size() * 4, hipMemcpyHostToDevice));
-    GMK_TRY(hipMalloc(&d_open_lens, nt * 4));
+    GMK_TRY(gmk::device_malloc(&d_open_lens, nt * 4));
     GMK_TRY(hipMemcpy(d_open_lens, open_lens.data(), nt * 4, hipMemcpyHostToDevice));
     if (h_open_moves) {
-        GMK_TRY(hipMalloc(&d_open_moves, nt * static_cast<size_t>(open_stride)));
+        GMK_TRY(gmk::device_malloc(&d_open_moves, nt * static_cast<size_t>(open_stride)));
         GMK_TRY(hipMemcpy(d_open_moves, h_open_moves, nt * static_cast<size_t>(open_stride), hipMemcpyHostToDevice));
     }
     GMK_TRY(hipMemcpy(d_moves, first_moves.data(), nt * 225, hipMemcpyHostToDevice));
@@ -1190,11 +1190,11 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
     GMK_TRY(hipMemset(d_winner, 0, nt));
     if (reuse_subtree && !t->second_arena) {                     // the arenas flip at every step (as gmk_trad_step)
         const size_t nodes = ns * static_cast<size_t>(t->cap);
-        const bool ok = hipMalloc(&t->d_stat2, nodes * 8) == hipSuccess && hipMalloc(&t->d_info2, nodes * 8) == hipSuccess &&
-                        hipMalloc(&t->d_link2, nodes * 4) == hipSuccess && hipMalloc(&t->d_front2, nodes * 8) == hipSuccess &&
-                        hipMalloc(&t->d_ord2, nodes) == hipSuccess && hipMalloc(&t->d_forced, ns * 2) == hipSuccess;
+        const bool ok = gmk::device_malloc(&t->d_stat2, nodes * 8) == hipSuccess && gmk::device_malloc(&t->d_info2, nodes * 8) == hipSuccess &&
+                        gmk::device_malloc(&t->d_link2, nodes * 4) == hipSuccess && gmk::device_malloc(&t->d_front2, nodes * 8) == hipSuccess &&
+                        gmk::device_malloc(&t->d_ord2, nodes) == hipSuccess && gmk::device_malloc(&t->d_forced, ns * 2) == hipSuccess;
         if (!ok) {
-            (void)hipFree(t->d_stat2); (void)hipFree(t->d_info2); (void)hipFree(t->d_link2); (void)hipFree(t->d_front2); (void)hipFree(t->d_ord2); (void)hipFree(t->d_forced);
+            (void)gmk::device_free(t->d_stat2); (void)gmk::device_free(t->d_info2); (void)gmk::device_free(t->d_link2); (void)gmk::device_free(t->d_front2); (void)gmk::device_free(t->d_ord2); (void)gmk::device_free(t->d_forced);
             t->d_stat2 = t->d_info2 = t->d_front2 = nullptr; t->d_link2 = nullptr; t->d_ord2 = nullptr; t->d_forced = nullptr;
             (void)hipGetLastError();
             gmk::set_error("gmk_trad_selfplay_run: hipMalloc of the second arena (%zu nodes) failed", nodes);
@@ -1241,7 +1241,7 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
         }
         rc = poolrave ? gmk_trad_run_poolrave(t, playouts, c_puct, seed, first_game_id, s) : gmk_trad_run(t, playouts, c_puct, s);
         if (rc != GMK_OK) break;
-        if (reuse_subtree && t->d_amaf && !t->d_amaf2) GMK_TRY(hipMalloc(&t->d_amaf2, ns * static_cast<size_t>(t->cap) * 8));
+        if (reuse_subtree && t->d_amaf && !t->d_amaf2) GMK_TRY(gmk::device_malloc(&t->d_amaf2, ns * static_cast<size_t>(t->cap) * 8));
         GMK_TRY(hipMemsetAsync(sp.unfinished, 0, 4, s));
         hipLaunchKernelGGL(trad_advance_kernel, dim3(n_slots), dim3(64), 0, s, t->arena(), t->arena2(), t->d_hdr, t->cap, n_slots, t->d_moves, t->d_lens, sp, reuse_subtree ? 1 : 0);
         hipLaunchKernelGGL(trad_refill_kernel, dim3(1), dim3(64), 0, s, t->d_hdr, n_slots, t->d_moves, t->d_lens, sp);
