@@ -37,7 +37,7 @@ PY
 
 rm -rf $out/trace                                     # the per-dispatch trace is large (gpurun returns at most 64 MiB); the stats are what profiles/ keeps
 for d in $out/pmc_*/; do find $d -name "*agent_info.csv" -delete; done
-python3 tools/summarize_pmc.py $out 65536 3276800 2048000 1638400 135900 > $out/pmc_summary.txt
+python3 tools/summarize_pmc.py $out 65536 3276800 2048000 1638400 152808 > $out/pmc_summary.txt
 find $out -name "*counter_collection.csv" -size +8M -delete
 timeout -k 10 400 python3 bench.py > $out/bench_n1.json 2> $out/bench_n1.err
 tail -c 600 $out/bench_n1.json
