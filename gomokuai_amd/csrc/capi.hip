@@ -118,6 +118,11 @@ extern "C" int gmk_init(int device) {
     return GMK_OK;
 }
 
+extern "C" int gmk_pool_release(void) {
+    gmk::device_pool_release();
+    return GMK_OK;
+}
+
 extern "C" int gmk_shutdown(void) {
     gmk::DeviceState& st = device_state();
     if (!st.ready) return GMK_OK;

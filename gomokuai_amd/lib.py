@@ -30,7 +30,7 @@ _lib = None
 
 # every symbol include/gomoku_hip.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
-    "gmk_init", "gmk_shutdown", "gmk_last_error", "gmk_device_info",
+    "gmk_init", "gmk_shutdown", "gmk_pool_release", "gmk_last_error", "gmk_device_info",
     "gmk_tables_info", "gmk_tables_pattern", "gmk_tables_copy", "gmk_tables_copy_dat", "gmk_tables_scan",
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
@@ -143,6 +143,11 @@ def _check(rc):
 
 def init(device=0):
     _check(load().gmk_init(device))
+
+
+def release_pool():
+    """Returns the device blocks the library keeps from destroyed handles (up to 160 GB of tree arenas) to the driver."""
+    _check(load().gmk_pool_release())
 
 
 def device_info():

@@ -41,6 +41,10 @@ enum { GMK_BOARD_CELLS = 225, GMK_PLANE_WORDS = 16, GMK_TOTALS = 11 };
 /* ---- library ---- */
 int gmk_init(int device);                 /* builds the pattern automaton on the host and uploads it */
 int gmk_shutdown(void);
+/* Large device blocks (the tree arenas: tens of GB per handle) that a destroyed handle gives up are kept by the library for the next handle
+ * (the driver clears memory before it hands it out again: seconds per 24 GB); at most 160 GB idle.  This returns the idle ones to the
+ * driver, e.g. before another allocator in the process needs the memory; gmk_shutdown does it too. */
+int gmk_pool_release(void);
 const char *gmk_last_error(void);
 int gmk_device_info(int *cu_count, size_t *hbm_bytes, char *name, int name_cap);
 
