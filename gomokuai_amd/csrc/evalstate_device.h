@@ -167,10 +167,11 @@ __device__ inline Matches match_patterns_both(const Ctx& c, int move, uint32_t n
     const int partner = (c.lane < 28 ? c.lane + 28 : c.lane - 28) * 4;
     const uint32_t from_w0 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(partner, static_cast<int>(second_w0)));
     const uint32_t from_w1 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(partner, static_cast<int>(second_w1)));
-    Matches m;
-    const bool live = c.lane < 56;
-    m.w0[w] = first_w0; m.w1[w] = first_w1;
-    m.w0[w ^ 1] = live ? from_w0 : 0u; m.w1[w ^ 1] = from_w1;
+    Matches m;                                                    // (selects, not m.w0[w]: an array indexed per lane would live in scratch memory)
+    const bool live = c.lane < 56, own_is_0 = w == 0;
+    const uint32_t got_w0 = live ? from_w0 : 0u;
+    m.w0[0] = own_is_0 ? first_w0 : got_w0; m.w1[0] = own_is_0 ? first_w1 : from_w1;
+    m.w0[1] = own_is_0 ? got_w0 : first_w0; m.w1[1] = own_is_0 ? from_w1 : first_w1;
     return m;
 }
 
