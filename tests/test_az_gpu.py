@@ -253,3 +253,80 @@ def test_set_slots_checks_every_opening():
     with pytest.raises(G.GmkError):
         t.set_slots(4, np.zeros((4, 12), dtype=np.uint8) + np.arange(12, dtype=np.uint8), np.array([9, 1, 1, 1], dtype=np.int32))
     t.close()
+
+
+def test_advance_plays_late_positions_to_their_end(oracle):
+    """gmk_az_advance from positions with 2 .. 20 empty cells (no five on the board yet): every ply's recorded move is the root's most
+    visited child (first maximum in cell order), its visit counts are the root's, the records replay on the oracle's board to a finished
+    game with the recorded winner (five in a row, or the tie of a full board), and the leaf batch shrinks with the games (live rows only)."""
+    import torch
+    O = oracle
+    G.init()
+    rng = np.random.RandomState(23)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    n, playouts = 10, 40
+    moves = np.zeros((n, 225), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.int32)
+    for g in range(n):
+        b, w = list(rng.permutation(blacks)), list(rng.permutation(whites))
+        seq = []
+        while b or w:
+            if b:
+                seq.append(b.pop())
+            if w:
+                seq.append(w.pop())
+        rng.shuffle(seq[205:])                                   # the tail in any order: fives become possible
+        moves[g] = seq
+        lens[g] = 205 + 2 * g
+    start = lens.copy()
+    planes = G.moves_to_planes(moves, lens)
+    last = np.stack([moves[np.arange(n), lens - 1], moves[np.arange(n), lens - 2]], 1).astype(np.int16)
+    tree = G.AlphaZeroMCTS(n, node_capacity=1 << 15, c_puct=5.0)
+    tree.set_roots(planes, last)
+    d_moves = torch.from_numpy(np.where(np.arange(225)[None, :] < lens[:, None], moves, 0).astype(np.uint8)).cuda()
+    d_lens, d_winner = torch.from_numpy(lens.copy()).cuda(), torch.zeros(n, dtype=torch.int8, device="cuda")
+    d_visits = torch.zeros((n, 225, 225), dtype=torch.int16, device="cuda")
+
+    def host_network(states):
+        s = states.cpu().numpy()
+        vp = [surrogate(s[g]) for g in range(s.shape[0])]
+        return (torch.tensor([v for v, _ in vp], dtype=torch.float32, device="cuda"), torch.from_numpy(np.stack([p for _, p in vp])).cuda())
+
+    live_rows = []
+    stalled = np.zeros(n, dtype=bool)                             # the search had nothing to play: the evaluator gave every empty cell probability 0
+    for _ in range(30):
+        live_rows.append(tree.live)
+        tree.search(host_network, playouts)
+        st = tree.root_stats()
+        before = d_lens.cpu().numpy().copy()
+        over_before = (st["status"] & G.AlphaZeroMCTS.STATUS_OVER) != 0
+        left = tree.advance(d_moves, d_visits, d_lens, d_winner, reuse_subtree=True)
+        after, rec, vis = d_lens.cpu().numpy(), d_moves.cpu().numpy(), d_visits.cpu().numpy()
+        for g in range(n):
+            if over_before[g] or st["visits"][g].max() == 0:
+                assert after[g] == before[g]
+                stalled[g] |= not over_before[g]
+                continue
+            assert after[g] == before[g] + 1 and rec[g, before[g]] == int(st["visits"][g].argmax())
+            assert (vis[g, before[g]].astype(np.int64) == np.minimum(st["visits"][g], 65535)).all()
+        assert left == tree.live
+        if left == 0:
+            break
+    assert tree.live == 0 and live_rows[0] == n and live_rows == sorted(live_rows, reverse=True) and live_rows[-1] < n
+    rec, rl, rw = d_moves.cpu().numpy(), d_lens.cpu().numpy(), d_winner.cpu().numpy()
+    ties = 0
+    for g in range(n):
+        b = O.new_board()
+        for i in range(int(rl[g])):
+            assert O.lib().go_board_check_move(C.byref(b), int(rec[g, i])), "game %d move %d" % (g, i)
+            assert b.cur_player != 0 or i < start[g]
+            O.lib().go_board_apply(C.byref(b), int(rec[g, i]), 1)
+        assert (rec[g, :start[g]] == moves[g, :start[g]]).all()
+        if stalled[g]:                                            # ended where it stood (as the host-driven loop ends it): no winner
+            assert b.cur_player != 0 and rw[g] == 0, "game %d" % g
+        else:
+            assert b.cur_player == 0 and b.winner == int(rw[g]), "game %d" % g
+        ties += int(rw[g] == 0 and rl[g] == 225)
+    assert int((~stalled).sum()) >= n // 2
+    tree.close()
