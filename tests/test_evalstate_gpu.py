@@ -131,3 +131,33 @@ def test_dense_games_to_the_full_board_and_back(oracle):
     back = st.read()
     assert not back["scores"].any() and not back["pattern_dist"].any() and not back["compound_dist"].any() and (back["meta"][:, 0] == 0).all()
     st.close()
+
+
+def test_a_full_launch_of_games_with_reverts(oracle):
+    """2 400 games at once (more than a launch of nine per CU holds, the last workgroup partly filled): every game applies its clustered
+    synthetic game, takes a third of it back and plays on with other cells of the game; scores, packed density words, pattern and
+    compound flag words, move records: all equal the oracle's."""
+    n = 2400
+    rng = np.random.RandomState(11)
+    moves, lens, _ = G.synth_boards(n, 1, first_board=5000)
+    scripts = []
+    for g in range(n):
+        m = [int(c) for c in moves[g, :lens[g]]]
+        back = len(m) // 3
+        tail = m[len(m) - back:]
+        rng.shuffle(tail)
+        scripts.append(m + [-2] * back + tail[: max(1, back - 1)])
+    k = max(len(sc) for sc in scripts)
+    script = np.full((n, k), -1, dtype=np.int16)
+    for g, sc in enumerate(scripts):
+        script[g, :len(sc)] = sc
+    st = G.EvaluatorStates(n)
+    st.update(script)
+    states = st.read()
+    ref = _oracle_states(oracle, scripts)
+    for g, (scores, density, pdist, cdist, meta, record) in enumerate(ref):
+        same = (states["scores"][g] == scores).all() and (states["density"][g] == density).all() and (states["pattern_dist"][g] == pdist).all() and \
+               (states["compound_dist"][g] == cdist).all() and tuple(int(v) for v in states["meta"][g][:3]) == meta and list(states["record"][g][:meta[0]]) == record
+        assert same, "game %d" % g
+    assert (states["compound_dist"][:, :225] != 0).any(1).mean() > 0.2
+    st.close()
