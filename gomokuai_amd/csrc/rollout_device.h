@@ -155,7 +155,9 @@ __device__ inline int random_rollout_quads(uint32_t* lines /* [word * stride], i
                     open = ~(rw | (rw >> 16)) & 0x7FFFu;
                 }
                 x = static_cast<uint32_t>(__ffs(open)) - 1u;
-                const uint32_t at = static_cast<uint32_t>(__mul24(static_cast<int>(x), per_x) + __mul24(static_cast<int>(y), per_y) + line0);
+                int at_row = __mul24(static_cast<int>(y), per_y) + line0;              // two multiply-adds (summed in one expression they become two multiplies and an add3)
+                asm volatile("" : "+v"(at_row));
+                const uint32_t at = static_cast<uint32_t>(__mul24(static_cast<int>(x), per_x) + at_row);
                 const uint32_t stone = (j & 1) ? stone_odd : stone_even, half = (j & 1) ? half_odd : half_even;
                 const uint32_t old = *lds_at(at);
                 const uint32_t next_row = *lds_at(base + __umul24(y_next, sb));
@@ -219,8 +221,10 @@ __device__ inline int random_rollout_pairs(uint32_t* lines /* [word * stride], i
                     open = ~(rw | (rw >> 16)) & 0x7FFFu;
                 }
                 x = static_cast<uint32_t>(__ffs(open)) - 1u;
-                const uint32_t first_at = static_cast<uint32_t>(__mul24(static_cast<int>(x), first_x) + __mul24(static_cast<int>(y), first_y) + first0);
-                const uint32_t second_at = static_cast<uint32_t>(static_cast<int>(__umul24(x, sb)) + __mul24(static_cast<int>(y), second_y) + second0);
+                int first_row = __mul24(static_cast<int>(y), first_y) + first0, second_row = __mul24(static_cast<int>(y), second_y) + second0;
+                asm volatile("" : "+v"(first_row), "+v"(second_row));             // (multiply-adds: see random_rollout_quads)
+                const uint32_t first_at = static_cast<uint32_t>(__mul24(static_cast<int>(x), first_x) + first_row);
+                const uint32_t second_at = static_cast<uint32_t>(static_cast<int>(__umul24(x, sb)) + second_row);
                 const uint32_t stone = (j & 1) ? stone_odd : stone_even, halves = (j & 1) ? halves_odd : halves_even;
                 const uint32_t first_old = *lds_at(first_at), second_old = *lds_at(second_at);
                 const uint32_t next_row = *lds_at(base + __umul24(y_next, sb));
