@@ -131,7 +131,8 @@ __device__ inline int random_rollout_quads(uint32_t* lines /* [word * stride], i
     int line0 = static_cast<int>(base + (d == 0u ? 0u : d == 1u ? kColBase : d == 2u ? kDiagBase + 14u : kAntiBase) * sb);
     int per_x = d == 0u ? 0 : static_cast<int>(sb), per_y = d == 0u ? static_cast<int>(sb) : d == 1u ? 0 : d == 2u ? -static_cast<int>(sb) : static_cast<int>(sb);
     asm volatile("" : "+v"(line0), "+v"(per_x), "+v"(per_y));
-    const bool column = d == 1u;
+    uint32_t column_mask = d == 1u ? 0xFFFFFFFFu : 0u;            // the stone's bit position: y on the column's lane, x elsewhere -- one v_bfi with a mask in a register
+    asm volatile("" : "+v"(column_mask));                        // (as a lane predicate it sat in a spilled scalar pair: two v_readlane a ply)
     const uint32_t stone_even = to_move > 0 ? 1u : 0x10000u, stone_odd = stone_even ^ 0x10001u;
     const uint32_t half_even = to_move > 0 ? 0u : 16u, half_odd = half_even ^ 16u;          // where the mover's fifteen bits start
     const int last_ply = 224 - stones;
@@ -161,7 +162,7 @@ __device__ inline int random_rollout_quads(uint32_t* lines /* [word * stride], i
                 const uint32_t stone = (j & 1) ? stone_odd : stone_even, half = (j & 1) ? half_odd : half_even;
                 const uint32_t old = *lds_at(at);
                 const uint32_t next_row = *lds_at(base + __umul24(y_next, sb));
-                const uint32_t mine = old | (stone << (column ? y : x));
+                const uint32_t mine = old | (stone << ((y & column_mask) | (x & ~column_mask)));
                 *lds_at(at) = mine;
                 rw_ahead = y_next == y ? (rw | (stone << x)) : next_row;
                 const uint32_t h = (mine >> half) & 0x7FFFu;
@@ -200,6 +201,8 @@ __device__ inline int random_rollout_pairs(uint32_t* lines /* [word * stride], i
     asm volatile("" : "+v"(first0), "+v"(second0), "+v"(first_x), "+v"(first_y), "+v"(second_y));
     const uint32_t stone_even = to_move > 0 ? 1u : 0x10000u, stone_odd = stone_even ^ 0x10001u;
     const uint32_t halves_even = to_move > 0 ? 0x05040100u : 0x07060302u, halves_odd = halves_even ^ 0x02020202u;
+    uint32_t odd_mask = odd ? 0xFFFFFFFFu : 0u;                   // second word's bit position: x on the odd lane (anti-diagonal), y on the even one (column)
+    asm volatile("" : "+v"(odd_mask));
     const int last_ply = 224 - stones;
     uint32_t won = 0;
     bool live = true;
@@ -229,7 +232,7 @@ __device__ inline int random_rollout_pairs(uint32_t* lines /* [word * stride], i
                 const uint32_t first_old = *lds_at(first_at), second_old = *lds_at(second_at);
                 const uint32_t next_row = *lds_at(base + __umul24(y_next, sb));
                 const uint32_t put = stone << x;
-                const uint32_t first_new = first_old | put, second_new = second_old | (odd ? put : stone << y);
+                const uint32_t first_new = first_old | put, second_new = second_old | (stone << ((x & odd_mask) | (y & ~odd_mask)));
                 *lds_at(first_at) = first_new; *lds_at(second_at) = second_new;
                 rw_ahead = y_next == y ? (rw | put) : next_row;
                 const uint32_t both = __builtin_amdgcn_perm(second_new, first_new, halves);          // the mover's halves; bits 15 and 31 are gaps
