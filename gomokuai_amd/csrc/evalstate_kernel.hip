@@ -45,7 +45,8 @@ void evalstate_update_kernel(uint32_t* __restrict__ states, const int16_t* __res
     if (game >= n_games) return;
     Ctx c{st, st + kStateWords, reinterpret_cast<const char*>(s_trans), reinterpret_cast<const uint4*>(s_trans + trans_words),
           reinterpret_cast<const char*>(s_trans + trans_words + record_words - gmk::kPrefixWords), lane,
-          prof ? reinterpret_cast<unsigned long long*>(st + kStateWords + kScratchWords) : nullptr, phases};
+          gmk::kProfileBuild && prof ? reinterpret_cast<unsigned long long*>(st + kStateWords + kScratchWords) : nullptr,
+          gmk::kProfileBuild ? phases : 0x3F};                    // (the production build has neither: the update's seven timer tests and six phase tests fold away)
     if (prof && lane < 16) st[kStateWords + kScratchWords + lane] = 0u;
     // the script 64 steps at a time, one step per lane, handed out with v_readlane: a load per step would put a trip to memory in
     // front of every update (the wavefront has nothing else to do meanwhile)

@@ -198,7 +198,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     auto div_lanes = [&](uint32_t t) -> uint32_t { return n_rollout_lanes == 1 ? t : __umulhi(t, inv_lanes); };
     auto div_r = [&](uint32_t t) -> uint32_t { return R == 1 ? t : __umulhi(t, inv_r); };
 
-    unsigned long long prof[4] = {0, 0, 0, 0}, t_mark = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;   // diagnostic build only
+    unsigned long long prof[4] = {0, 0, 0, 0}, t_mark = (gmk::kProfileBuild && prm.profile) ? __builtin_amdgcn_s_memtime() : 0ull;   // diagnostic build only
     for (int playout = 0; playout < prm.playouts; ++playout) {
         if (lane < kMaxGamesPerBlock) s_sum[lane] = 0;
 
@@ -335,7 +335,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
             }
         }
         __syncthreads();
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[0] += t - t_mark; t_mark = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[0] += t - t_mark; t_mark = t; }
 
         // ---- terminal test at the leaf (Policy::checkGameEnd, MCTS.cpp:166) ----
         if (lane < games_here && s_active[lane]) {
@@ -347,7 +347,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
             s_term_value[lane] = five ? 1.0f : 0.0f;                 // CalcScore(node->player, winner): the mover won, or a tie
         }
         __syncthreads();
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[1] += t - t_mark; t_mark = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[1] += t - t_mark; t_mark = t; }
 
         // ---- simulate (Random.h:22-35).  First the random cells of all rollouts, with all 64 lanes: one Philox block = eight plies
         //      per task, block-major, so that the rollout loop below only plays (the generator is ~150 instructions a block, and
@@ -396,7 +396,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
             }
         }
         __syncthreads();
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[2] += t - t_mark; t_mark = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[2] += t - t_mark; t_mark = t; }
 
         // ---- expand + backup: quarter-wave per game (MonteCarlo.hpp:71-95) ----
         for (int round = 0; round < rounds; ++round) {
@@ -467,7 +467,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
             }
         }
         __syncthreads();
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[3] += t - t_mark; t_mark = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[3] += t - t_mark; t_mark = t; }
     }
 
     if (lane < games_here) {
@@ -475,7 +475,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         headers[game0 + lane].status = s_status[lane];
         headers[game0 + lane].alg_bytes = s_bytes[lane];
         if (s_active[lane]) headers[game0 + lane].playouts_done += static_cast<uint32_t>(prm.playouts);
-        if (prm.profile) for (int k = 0; k < 4; ++k) headers[game0 + lane].pad[k] = static_cast<uint32_t>(prof[k] >> 10);
+        if (gmk::kProfileBuild && prm.profile) for (int k = 0; k < 4; ++k) headers[game0 + lane].pad[k] = static_cast<uint32_t>(prof[k] >> 10);
     }
     if (!prm.persistent) break;
     // the step of every game of this wavefront (headers and trees were written by other lanes than the ones that read them now, and the

@@ -127,13 +127,13 @@ void rave_playouts_kernel(RaveParams prm) {
         return L;
     };
 
-    unsigned long long prof_sel = 0, prof_roll = 0, prof_back = 0, prof_t0 = 0, prof_all = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long prof_sel = 0, prof_roll = 0, prof_back = 0, prof_t0 = 0, prof_all = (gmk::kProfileBuild && prm.profile) ? __builtin_amdgcn_s_memtime() : 0ull;
     // The rollout is a serial chain per game that keeps ONE lane busy: the four games of a workgroup meet at a barrier and one
     // wavefront plays their four rollouts side by side (a quarter of the vector issue slots four separate one-lane loops would
     // take), the others wait at the next barrier for free.  Every wave makes every iteration, a stopped game just passes through.
     const int roll_wave = blockIdx.x % kWaves;                  // spread the rollout waves over the SIMDs
     for (int it = 0; it < prm.playouts; ++it) {
-        if (prm.profile) prof_t0 = __builtin_amdgcn_s_memtime();
+        if (gmk::kProfileBuild && prm.profile) prof_t0 = __builtin_amdgcn_s_memtime();
         const bool act = !(status & 1u);
         int depth = 0, ply = 0, path_len = 0;
         uint32_t node = 0;
@@ -211,7 +211,7 @@ void rave_playouts_kernel(RaveParams prm) {
             }
         }
         if (lane == 0) s_ply[wave] = rollout ? ply : -1;
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
         __syncthreads();
         // ---- Default::RandomRollout for the games of the workgroup, four lanes each; a finished game stays in its `lines` ----
         if (wave == roll_wave) {
@@ -228,7 +228,7 @@ void rave_playouts_kernel(RaveParams prm) {
             }
         }
         __syncthreads();
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_roll += t - prof_t0; prof_t0 = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_roll += t - prof_t0; prof_t0 = t; }
         if (!act || (status & 1u)) continue;
         float value;                                            // for the player of `node`
         if (rollout) {
@@ -307,7 +307,7 @@ void rave_playouts_kernel(RaveParams prm) {
             valid = path_len;
         }
         wave_phase_fence();
-        if (prm.profile) prof_back += __builtin_amdgcn_s_memtime() - prof_t0;
+        if (gmk::kProfileBuild && prm.profile) prof_back += __builtin_amdgcn_s_memtime() - prof_t0;
     }
 
     if (lane == 0 && exists) {
@@ -317,7 +317,7 @@ void rave_playouts_kernel(RaveParams prm) {
         hdr->fresh = 0;
         hdr->root_black = static_cast<uint32_t>(root_black);
         hdr->playouts_done = playout0 + static_cast<uint32_t>(prm.playouts);
-        if (prm.profile) {
+        if (gmk::kProfileBuild && prm.profile) {
             hdr->prof[0] = static_cast<uint32_t>(prof_sel >> 10); hdr->prof[1] = static_cast<uint32_t>(prof_roll >> 10);
             hdr->prof[2] = static_cast<uint32_t>(prof_back >> 10); hdr->prof[3] = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - prof_all) >> 10);
         }

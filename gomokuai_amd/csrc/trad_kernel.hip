@@ -249,7 +249,7 @@ void trad_playouts_kernel(TradParams prm) {
     int sp_game = prm.selfplay ? prm.sp.slot_game[game] : -1, cur_len = prm.lens[game];
     uint8_t* const slot_moves = prm.moves + static_cast<size_t>(game) * 225;
     unsigned long long playouts_run = hdr->playouts_done;
-    unsigned long long prof_sel = 0, prof_sim = 0, prof_back = 0, prof_t0 = 0, prof_all = prm.profile ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long prof_sel = 0, prof_sim = 0, prof_back = 0, prof_t0 = 0, prof_all = (gmk::kProfileBuild && prm.profile) ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
     const bool fresh = fresh_mode == 1u;
 
@@ -302,7 +302,7 @@ void trad_playouts_kernel(TradParams prm) {
     };
 
     for (int it = fresh_mode != 0u ? -1 : 0; it < prm.playouts && !(status & 1u); ++it) {
-        if (prm.profile) prof_t0 = __builtin_amdgcn_s_memtime();
+        if (gmk::kProfileBuild && prm.profile) prof_t0 = __builtin_amdgcn_s_memtime();
         int depth = 0;
         uint32_t node = 0, link = 0;
         if (it >= 0) {
@@ -373,7 +373,7 @@ void trad_playouts_kernel(TradParams prm) {
             continue;
         }
         if (n_revert + n_apply > 0 || rebuild) g.cached = meta[0];      // from the first move it did not hold on, the record follows the path
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sel += t - prof_t0; prof_t0 = t; }
         int path_len = depth;                                   // deepest level with a known node
 
         // ---- TraditionalPolicy::checkGameEnd -> Evaluator::checkGameEnd (Pattern.cpp:344-354) ----
@@ -455,7 +455,7 @@ void trad_playouts_kernel(TradParams prm) {
         }
         wave_phase_fence();
         if (status & 1u) break;
-        if (prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sim += t - prof_t0; prof_t0 = t; }
+        if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof_sim += t - prof_t0; prof_t0 = t; }
 
         // ---- RAVE::BackPropogate<false> (MonteCarlo.hpp:160-184), leaf to root ----
         int swap_level = -1;
@@ -518,7 +518,7 @@ void trad_playouts_kernel(TradParams prm) {
         }
         wave_phase_fence();
 
-        if (prm.profile) prof_back += __builtin_amdgcn_s_memtime() - prof_t0;
+        if (gmk::kProfileBuild && prm.profile) prof_back += __builtin_amdgcn_s_memtime() - prof_t0;
 
         // ---- Heuristic::CachedRevertMove (Heuristic.hpp:192-200) ----
         if (meta[0] != g.cached) status |= 4u;                  // the reference would take stones off the inner board only: not reproduced
@@ -609,7 +609,7 @@ void trad_playouts_kernel(TradParams prm) {
         hdr->root_black = static_cast<uint32_t>(root_black);
         hdr->playouts_done = static_cast<uint32_t>(playouts_run);
         hdr->evaluator_updates += g.updates;
-        if (prm.profile) {
+        if (gmk::kProfileBuild && prm.profile) {
             hdr->prof[0] = static_cast<uint32_t>(prof_sel >> 10); hdr->prof[1] = static_cast<uint32_t>(prof_sim >> 10);
             hdr->prof[2] = static_cast<uint32_t>(prof_back >> 10); hdr->prof[3] = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - prof_all) >> 10);
         }
