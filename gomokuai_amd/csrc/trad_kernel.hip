@@ -9,7 +9,7 @@
 //   moves     Heuristic::CachedApplyMove / CachedRevertMove: the evaluator stays at the last leaf and is rolled back
 //             (or rebuilt) only as far as the next path differs (Heuristic.hpp:165-200)
 // The search has no random numbers; it is a serial chain per game, so the GPU runs MANY games: one wavefront per
-// game, seven games per workgroup, the evaluator state (17.8 KB, evalstate_device.h) and the current path in LDS,
+// game, eight games per workgroup, the evaluator state (16.0 KB, evalstate_device.h) and the current path in LDS,
 // the tree in HBM (29 B per node: statistics, parent / cell / prior, child range, the record of its FIRST child, and
 // its own position in the parent's child order, which is all that BackPropogate's swaps change).  The search walks
 // first children only, so the path of the previous playout stays valid down to the shallowest level whose first
