@@ -21,6 +21,7 @@
 #include "board_device.h"
 #include "capi_common.h"
 #include "philox.h"
+#include "rollout_device.h"
 #include "root_noise.h"
 
 namespace {
@@ -150,7 +151,7 @@ void az_select_kernel(AzTree t, float* __restrict__ out_states) {
 }
 
 __global__ __launch_bounds__(64)
-void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* __restrict__ probs) {
+void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* __restrict__ probs, int stages /* bit 0: expand, bit 1: back up */) {
     const int game = blockIdx.x, lane = threadIdx.x;
     if (game >= t.n_games) return;
     AzHeader* hdr = t.hdr + game;
@@ -174,7 +175,7 @@ void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* _
         rank[j] = total + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b), 0u)));
         total += __popcll(b);
     }
-    if (total > 0) {
+    if (total > 0 && (stages & 1)) {
         if (n_nodes + total > static_cast<uint32_t>(t.cap)) {
             if (lane == 0) { hdr->status |= 2u; hdr->leaf_pending = 0; }               // arena full: this playout is dropped
             return;
@@ -196,7 +197,7 @@ void az_expand_kernel(AzTree t, const float* __restrict__ values, const float* _
     }
     __threadfence_block();
     if (lane == 0) {
-        backup(t.stat + arena, t.parent + arena, leaf, -values[row]);                  // node_value = -state_value (MCTS.cpp:166-168)
+        if (stages & 2) backup(t.stat + arena, t.parent + arena, leaf, -values[row]);  // node_value = -state_value (MCTS.cpp:166-168)
         hdr->leaf_pending = 0;
     }
 }
@@ -633,7 +634,7 @@ extern "C" int gmk_az_select(gmk_az* a, float* d_states, void* stream) {
 extern "C" int gmk_az_expand(gmk_az* a, const float* d_values, const float* d_probs, void* stream) {
     if (!a || !d_values || !d_probs) { gmk::set_error("gmk_az_expand: bad arguments"); return GMK_ERR_ARG; }
     if (!a->rooted) { gmk::set_error("gmk_az_expand: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
-    hipLaunchKernelGGL(az_expand_kernel, dim3(a->t.n_games), dim3(64), 0, static_cast<hipStream_t>(stream), a->t, d_values, d_probs);
+    hipLaunchKernelGGL(az_expand_kernel, dim3(a->t.n_games), dim3(64), 0, static_cast<hipStream_t>(stream), a->t, d_values, d_probs, 3);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }
@@ -770,6 +771,143 @@ extern "C" int gmk_az_expand_host(gmk_az* a, const float* h_values, const float*
     const int rc = gmk_az_expand(a, a->h_values, a->h_probs, nullptr);
     if (rc != GMK_OK) return rc;
     GMK_HIP_CHECK(hipDeviceSynchronize());
+    return GMK_OK;
+}
+
+// ---- Host-driven stages: Policy(select=, expand=, back_prop=) hands Python callables to MCTS::playout
+// (core/py_ext/src/mcts_ext.hpp:43-61, core/lib/include/MCTS.h:74-101).  A Python callable runs on the host by definition; the tree stays on the
+// device and the host reads the node it is asked about, decides, and tells the device: a node and its children out, the chosen leaf in, expand
+// and / or back up as separate steps, statistics of a path written back, and Default::Simulate's random rollout (MonteCarlo.hpp:83-88) from the
+// pending leaf as a one-wavefront kernel on the rollout code of K3.  One game of the handle at a time; synchronous; for CorePyExt's one-game MCTS.
+namespace {
+__global__ __launch_bounds__(64)
+void az_leaf_rollout_kernel(AzTree t, int game, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1, int32_t* winner) {
+    using namespace gmk::rollout;
+    __shared__ uint32_t s_lines[kLineWords];
+    __shared__ uint2 s_cells[30];
+    const int lane = threadIdx.x;
+    const AzHeader& hdr = t.hdr[game];
+    const int stones = static_cast<int>(hdr.leaf_stones);
+    for (int w = lane; w < kLineWords; w += 64) s_lines[w] = 0u;
+    __syncthreads();
+    if (lane < 15) {
+        const uint32_t row = hdr.leaf_rows[lane];
+        s_lines[lane] = row;
+        for (uint32_t m = (row | (row >> 16)) & 0x7FFFu; m; m &= m - 1u) {
+            const int x = __ffs(m) - 1, y = lane;
+            const uint32_t cb = ((row >> x) & 1u) ? 0u : 16u;
+            atomicOr(&s_lines[kColBase + x], 1u << (y + cb));
+            atomicOr(&s_lines[kDiagBase + x - y + 14], 1u << (x + cb));
+            atomicOr(&s_lines[kAntiBase + x + y], 1u << (x + cb));
+        }
+    }
+    if (lane < 30 && 8 * lane < 225 - stones) s_cells[lane] = rollout_cells(c0, c1, c2, static_cast<uint32_t>(lane), k0, k1);
+    __syncthreads();
+    if (lane == 0) *winner = random_rollout_blocks(s_lines, 1u, (stones & 1) ? -1 : 1, stones, 0, [&](uint32_t b) { return s_cells[b]; });
+}
+}  // namespace
+
+extern "C" int gmk_az_read_node_host(gmk_az* a, int game, uint32_t node, uint32_t* h_visits, float* h_value, float* h_prior, int32_t* h_cell, uint32_t* h_parent,
+                                     uint32_t* h_first_child, int32_t* h_n_children) {
+    if (!a || game < 0 || game >= a->t.n_games || node >= static_cast<uint32_t>(a->t.cap)) { gmk::set_error("gmk_az_read_node_host: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_read_node_host: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    const size_t at = static_cast<size_t>(game) * a->t.cap + node;
+    uint2 st, kd;
+    float pr;
+    uint32_t par;
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    GMK_HIP_CHECK(hipMemcpy(&st, a->t.stat + at, 8, hipMemcpyDeviceToHost));
+    GMK_HIP_CHECK(hipMemcpy(&kd, a->t.kids + at, 8, hipMemcpyDeviceToHost));
+    GMK_HIP_CHECK(hipMemcpy(&pr, a->t.prior + at, 4, hipMemcpyDeviceToHost));
+    GMK_HIP_CHECK(hipMemcpy(&par, a->t.parent + at, 4, hipMemcpyDeviceToHost));
+    if (h_visits) *h_visits = st.x;
+    if (h_value) std::memcpy(h_value, &st.y, 4);
+    if (h_prior) *h_prior = pr;
+    if (h_cell) *h_cell = static_cast<int32_t>((kd.y >> 8) & 0xFFu);
+    if (h_parent) *h_parent = par;
+    if (h_first_child) *h_first_child = kd.x;
+    if (h_n_children) *h_n_children = static_cast<int32_t>(kd.y & 0xFFu);
+    return GMK_OK;
+}
+
+extern "C" int gmk_az_read_children_host(gmk_az* a, int game, uint32_t first_child, int n, int16_t* h_cells, uint32_t* h_visits, float* h_values, float* h_priors,
+                                         int32_t* h_n_children) {
+    if (!a || game < 0 || game >= a->t.n_games || n < 0 || n > 225 || static_cast<size_t>(first_child) + n > static_cast<size_t>(a->t.cap)) { gmk::set_error("gmk_az_read_children_host: bad arguments"); return GMK_ERR_ARG; }
+    if (n == 0) return GMK_OK;
+    const size_t at = static_cast<size_t>(game) * a->t.cap + first_child;
+    uint2 st[225], kd[225];
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    GMK_HIP_CHECK(hipMemcpy(st, a->t.stat + at, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost));
+    GMK_HIP_CHECK(hipMemcpy(kd, a->t.kids + at, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost));
+    if (h_priors) GMK_HIP_CHECK(hipMemcpy(h_priors, a->t.prior + at, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        if (h_cells) h_cells[i] = static_cast<int16_t>((kd[i].y >> 8) & 0xFFu);
+        if (h_visits) h_visits[i] = st[i].x;
+        if (h_values) std::memcpy(&h_values[i], &st[i].y, 4);
+        if (h_n_children) h_n_children[i] = static_cast<int32_t>(kd[i].y & 0xFFu);
+    }
+    return GMK_OK;
+}
+
+// the leaf the host's descent ended at: node `leaf`, reached from the root over h_path[0 .. depth): it becomes the pending leaf of the next
+// gmk_az_expand_stages_host / gmk_az_rollout_host (what az_select_kernel leaves behind for a device-side descent)
+extern "C" int gmk_az_set_leaf_host(gmk_az* a, int game, uint32_t leaf, const int16_t* h_path, int depth) {
+    if (!a || game < 0 || game >= a->t.n_games || depth < 0 || depth > 225 || (depth > 0 && !h_path) || leaf >= static_cast<uint32_t>(a->t.cap)) { gmk::set_error("gmk_az_set_leaf_host: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_set_leaf_host: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    AzHeader h;
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    GMK_HIP_CHECK(hipMemcpy(&h, a->t.hdr + game, sizeof h, hipMemcpyDeviceToHost));
+    for (int y = 0; y < 16; ++y) h.leaf_rows[y] = h.rows[y];
+    uint32_t stones = h.stones;
+    for (int i = 0; i < depth; ++i, ++stones) {
+        const int c = h_path[i];
+        if (c < 0 || c >= 225 || ((h.leaf_rows[c / 15] | (h.leaf_rows[c / 15] >> 16)) >> (c % 15)) & 1u) { gmk::set_error("gmk_az_set_leaf_host: the path is not a sequence of moves"); return GMK_ERR_ARG; }
+        h.leaf_rows[c / 15] |= 1u << (c % 15 + ((stones & 1u) ? 16 : 0));
+    }
+    h.leaf = leaf; h.leaf_pending = 1; h.leaf_stones = stones;
+    GMK_HIP_CHECK(hipMemcpy(a->t.hdr + game, &h, sizeof h, hipMemcpyHostToDevice));
+    return GMK_OK;
+}
+
+// gmk_az_expand_host with the two halves of az_expand_kernel switched separately: expand (children with h_probs, Default::Expand) and / or
+// back up (-h_values along the parent chain, Default::BackPropogate); the pending leaves are done either way
+extern "C" int gmk_az_expand_stages_host(gmk_az* a, const float* h_values, const float* h_probs, int do_expand, int do_backup) {
+    if (!a || (do_backup && !h_values) || (do_expand && !h_probs)) { gmk::set_error("gmk_az_expand_stages_host: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_expand_stages_host: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    if (!az_host_scratch(a)) { gmk::set_error("gmk_az_expand_stages_host: device allocation failed"); return GMK_ERR_HIP; }
+    if (h_values) GMK_HIP_CHECK(hipMemcpy(a->h_values, h_values, static_cast<size_t>(a->t.n_games) * 4, hipMemcpyHostToDevice));
+    if (h_probs) GMK_HIP_CHECK(hipMemcpy(a->h_probs, h_probs, static_cast<size_t>(a->t.n_games) * 225 * 4, hipMemcpyHostToDevice));
+    else GMK_HIP_CHECK(hipMemset(a->h_probs, 0, static_cast<size_t>(a->t.n_games) * 225 * 4));
+    hipLaunchKernelGGL(az_expand_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, a->h_values, a->h_probs, (do_expand ? 1 : 0) | (do_backup ? 2 : 0));
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    return GMK_OK;
+}
+
+// node statistics as a Python back_prop left them: h_nodes[i] gets {h_visits[i], h_values[i]}
+extern "C" int gmk_az_write_stats_host(gmk_az* a, int game, const uint32_t* h_nodes, const uint32_t* h_visits, const float* h_values, int n) {
+    if (!a || game < 0 || game >= a->t.n_games || n < 0 || (n > 0 && (!h_nodes || !h_visits || !h_values))) { gmk::set_error("gmk_az_write_stats_host: bad arguments"); return GMK_ERR_ARG; }
+    GMK_HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < n; ++i) {
+        if (h_nodes[i] >= static_cast<uint32_t>(a->t.cap)) { gmk::set_error("gmk_az_write_stats_host: node %u outside the arena", h_nodes[i]); return GMK_ERR_ARG; }
+        uint2 st;
+        st.x = h_visits[i];
+        std::memcpy(&st.y, &h_values[i], 4);
+        GMK_HIP_CHECK(hipMemcpy(a->t.stat + static_cast<size_t>(game) * a->t.cap + h_nodes[i], &st, 8, hipMemcpyHostToDevice));
+    }
+    return GMK_OK;
+}
+
+// Default::Simulate's random rollout from the pending leaf of `game` (one wavefront, the rollout of K3): the winner (+1 black, -1 white, 0 tie).
+// The cell draws are Philox(seed; counter0, counter1, counter2, block of eight plies): with (global game id, playout number, root stones << 8)
+// they are the draws of K3's first rollout lane, i.e. MCTS(RandomPolicy(c_puct, 1)) of gmk_mcts_*.
+extern "C" int gmk_az_rollout_host(gmk_az* a, int game, uint64_t seed, uint32_t counter0, uint32_t counter1, uint32_t counter2, int32_t* h_winner) {
+    if (!a || game < 0 || game >= a->t.n_games || !h_winner) { gmk::set_error("gmk_az_rollout_host: bad arguments"); return GMK_ERR_ARG; }
+    if (!a->rooted) { gmk::set_error("gmk_az_rollout_host: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
+    if (!a->d_unfinished) GMK_HIP_CHECK(gmk::device_malloc(&a->d_unfinished, 4));
+    hipLaunchKernelGGL(az_leaf_rollout_kernel, dim3(1), dim3(64), 0, nullptr, a->t, game, counter0, counter1, counter2, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), a->d_unfinished);
+    GMK_HIP_CHECK(hipGetLastError());
+    GMK_HIP_CHECK(hipMemcpy(h_winner, a->d_unfinished, 4, hipMemcpyDeviceToHost));
     return GMK_OK;
 }
 

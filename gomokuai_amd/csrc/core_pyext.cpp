@@ -288,10 +288,11 @@ private:
         auto* rave = dynamic_cast<PoolRAVEPolicy*>(policy_.get());
         if (trad && !trad->use_rave && !policy_->has_python_stages()) { run_first_child_tree(board, trad->c_puct, trad, start); return; }
         if (rave && !policy_->has_python_stages()) { run_first_child_tree(board, rave->c_puct, nullptr, start); return; }
-        if (!random && !trad && policy_->simulate && !policy_->select && !policy_->expand && !policy_->back_prop) { run_with_evaluator(board, start); return; }
+        if (!random && !trad && !rave && policy_->simulate && !policy_->select && !policy_->expand && !policy_->back_prop) { run_with_evaluator(board, start); return; }
+        if (!random && !trad && !rave && (policy_->select || policy_->expand || policy_->back_prop)) { run_with_stages(board, start); return; }
         if (!random || policy_->has_python_stages())
-            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy, PoolRAVEPolicy, TraditionalPolicy(use_rave=False) and Policy(eval_state=...) in this build; ") +
-                                     policy_->kind() + " with other host-side stages is not available (no CPU search path)");
+            throw std::runtime_error(std::string("CorePyExt (MI355X): MCTS runs on the GPU with RandomPolicy, PoolRAVEPolicy, TraditionalPolicy(use_rave=False) and Policy(select=, expand=, eval_state=, back_prop=) in this build; ") +
+                                     policy_->kind() + " is not one of them");
         throw_gmk(gmk_init(0));
         sync_with_board(board);
         policy_->prepare(board);
@@ -343,10 +344,8 @@ private:
         policy_->cleanup(board);
     }
 
-    // MCTS(policy = Policy(eval_state = f, c_puct)) (agents/alphazero.py:5-9): the tree search runs on the device (K7, gmk_az_*, one
-    // game), the evaluator is the Python callable, called once per playout with the leaf position like the reference's
-    // policy->simulate(board) (MCTS.cpp:164-166).  The tree is kept from move to move and root noise is added like in the other searchers.
-    void run_with_evaluator(Board& board, std::chrono::system_clock::time_point start) {
+    // the set-up of a search on the K7 tree (run_with_evaluator, run_with_stages): handle, MCTS::syncWithBoard, Default::AddNoise; returns the playout budget
+    int az_prepare(Board& board) {
         throw_gmk(gmk_init(0));
         sync_with_board(board);
         policy_->prepare(board);
@@ -363,6 +362,7 @@ private:
         const size_t have = az_record_.size(), len = board.record_.size();
         bool continues = az_valid_ && have <= len;
         for (size_t i = 0; continues && i < have; ++i) continues = az_record_[i] == board.record_[i];
+        if (!continues || have != len) az_playouts_done_ = 0;           // a new root: the playout numbers of Default::Simulate's streams start over (as GameHeader::playouts_done)
         if (continues) {
             for (size_t i = have; i < len; ++i) {
                 const int16_t mv = board.record_[i].id;
@@ -377,6 +377,37 @@ private:
         az_record_.assign(board.record_.begin(), board.record_.end());
         az_valid_ = true;
         if (g_root_noise_alpha > 0.0f) throw_gmk(gmk_az_add_root_noise(az_handle_, g_root_noise_alpha, g_root_noise_epsilon, g_search_seed, game_id_));
+        return budget;
+    }
+
+    // the root and its children as the search left them (value snapshots for MCTS.root); returns the tree's node count
+    int32_t az_finish(Board& board) {
+        std::vector<float> values(kN), priors(kN);
+        uint32_t root_visits = 0;
+        float q = 0.0f;
+        int32_t nodes = 1, status = 0;
+        visits_.assign(kN, 0);
+        throw_gmk(gmk_az_root_stats(az_handle_, visits_.data(), values.data(), priors.data(), &root_visits, &q, &nodes, &status));
+        if (status & 2)                                             // node arena full: playouts were dropped, the statistics are not those of the requested search
+            throw std::overflow_error("CorePyExt (MI355X): the search tree outgrew its node arena (" + std::to_string(az_capacity_) + " nodes); playouts were dropped");
+        root_->state_value = q;
+        root_->node_visits = root_visits;
+        root_->children.clear();
+        for (int i = 0; i < kN; ++i)
+            if (priors[i] != 0.0f && board.cell_[i] == Player::None) {
+                auto c = std::make_shared<Node>();
+                c->parent = root_; c->position = Position(i); c->player = -root_->player;
+                c->action_prob = priors[i]; c->state_value = values[i]; c->node_visits = visits_[i];
+                root_->children.push_back(c);
+            }
+        return nodes;
+    }
+
+    // MCTS(policy = Policy(eval_state = f, c_puct)) (agents/alphazero.py:5-9): the tree search runs on the device (K7, gmk_az_*, one
+    // game), the evaluator is the Python callable, called once per playout with the leaf position like the reference's
+    // policy->simulate(board) (MCTS.cpp:164-166).  The tree is kept from move to move and root noise is added like in the other searchers.
+    void run_with_evaluator(Board& board, std::chrono::system_clock::time_point start) {
+        const int budget = az_prepare(board);
         int32_t nodes_before = 1;
         throw_gmk(gmk_az_root_stats(az_handle_, nullptr, nullptr, nullptr, nullptr, nullptr, &nodes_before, nullptr));
         std::vector<int16_t> path(226);
@@ -403,25 +434,139 @@ private:
             for (auto end = start; end - start < duration_ && done < static_cast<size_t>(budget); end = std::chrono::system_clock::now()) playout();
             iterations_ = done;
         }
-        std::vector<float> values(kN), priors(kN);
-        uint32_t root_visits = 0;
-        float q = 0.0f;
-        int32_t nodes = 1, status = 0;
-        visits_.assign(kN, 0);
-        throw_gmk(gmk_az_root_stats(az_handle_, visits_.data(), values.data(), priors.data(), &root_visits, &q, &nodes, &status));
-        if (status & 2)                                             // node arena full: playouts were dropped, the statistics are not those of the requested search
-            throw std::overflow_error("CorePyExt (MI355X): the search tree outgrew its node arena (" + std::to_string(az_capacity_) + " nodes); playouts were dropped");
-        root_->state_value = q;
-        root_->node_visits = root_visits;
-        root_->children.clear();
-        for (int i = 0; i < kN; ++i)
-            if (priors[i] != 0.0f && board.cell_[i] == Player::None) {
-                auto c = std::make_shared<Node>();
-                c->parent = root_; c->position = Position(i); c->player = -root_->player;
-                c->action_prob = priors[i]; c->state_value = values[i]; c->node_visits = visits_[i];
-                root_->children.push_back(c);
-            }
+        const int32_t nodes = az_finish(board);
         size_ += static_cast<size_t>(nodes - nodes_before);
+        policy_->cleanup(board);
+    }
+
+    // MCTS(policy = Policy(select=, expand=, eval_state=, back_prop=)) with Python callables in the TREE stages (SURVEY 8 a18;
+    // core/py_ext/src/mcts_ext.hpp:43-61, MCTS::playout MCTS.cpp:149-177).  The callables run on the host, like every Python callable;
+    // the tree stays on the device (K7's arena): per level the host reads the node and its children (gmk_az_read_*_host), hands `select`
+    // value snapshots of them, tells the device which leaf the descent ended at, and the stages nobody replaced run where they always
+    // run -- Default::Expand and Default::BackPropogate as az_expand_kernel's two halves, Default::Simulate's random rollout as a
+    // one-wavefront kernel (its draws are those of gmk_mcts_*'s first rollout lane: Policy(select=Default::Select restated in Python) plays
+    // MCTS(RandomPolicy(c_puct, 1))'s game).  A Python `expand` cannot add children in the reference either (Node.children is a copy,
+    // create_node's result has no owner): it is called, its return value counts into MCTS.size, the node stays a leaf.
+    void run_with_stages(Board& board, std::chrono::system_clock::time_point start) {
+        const int budget = az_prepare(board);
+        int32_t nodes_before = 1;
+        throw_gmk(gmk_az_root_stats(az_handle_, nullptr, nullptr, nullptr, nullptr, nullptr, &nodes_before, nullptr));
+        const uint32_t root_stones = static_cast<uint32_t>(board.record_.size());
+        size_t done = 0, python_expanded = 0;
+        struct Info { uint32_t visits = 0, parent = 0, first = 0; float value = 0, prior = 0; int32_t cell = -1, n = 0; };
+        auto read_node = [&](uint32_t node) {
+            Info i;
+            throw_gmk(gmk_az_read_node_host(az_handle_, 0, node, &i.visits, &i.value, &i.prior, &i.cell, &i.parent, &i.first, &i.n));
+            return i;
+        };
+        auto snapshot = [&](const Info& i, Player player, std::shared_ptr<Node> parent) {
+            auto n = std::make_shared<Node>();
+            n->parent = parent; n->position = Position(i.cell == 255 ? -1 : i.cell); n->player = player;
+            n->state_value = i.value; n->action_prob = i.prior; n->node_visits = i.visits;
+            return n;
+        };
+        auto playout = [&]() {
+            // ---- select (MCTS.cpp:160-163) ----
+            uint32_t node = 0;
+            std::vector<int16_t> path;
+            std::vector<uint32_t> path_nodes{0u};
+            Board leaf = board;
+            Player player = root_->player;
+            for (;;) {
+                const Info here = read_node(node);
+                if (here.n == 0) break;                             // Node::isLeaf
+                int16_t cells[kN]; uint32_t visits[kN]; float values[kN], priors[kN]; int32_t grand[kN];
+                throw_gmk(gmk_az_read_children_host(az_handle_, 0, here.first, here.n, cells, visits, values, priors, grand));
+                int pick = -1;
+                if (policy_->select) {
+                    auto obj = snapshot(here, player, nullptr);
+                    for (int i = 0; i < here.n; ++i) {
+                        Info ci; ci.visits = visits[i]; ci.value = values[i]; ci.prior = priors[i]; ci.cell = cells[i];
+                        auto c = snapshot(ci, -player, obj);
+                        c->children.resize(static_cast<size_t>(grand[i]));                 // (is_leaf / len(children) of a child: placeholders)
+                        obj->children.push_back(c);
+                    }
+                    const py::object chosen = policy_->select(py::cast(obj));
+                    const auto chosen_node = chosen.cast<std::shared_ptr<Node>>();
+                    for (int i = 0; i < here.n && pick < 0; ++i) if (obj->children[static_cast<size_t>(i)] == chosen_node) pick = i;
+                    for (int i = 0; i < here.n && pick < 0 && chosen_node; ++i) if (chosen_node->position.id == cells[i]) pick = i;
+                    if (pick < 0) throw std::runtime_error("Policy.select must return one of the node's children");
+                } else {                                            // Default::Select (MonteCarlo.hpp:57-68), as az_select_kernel scores
+                    const double sqrt_n = std::sqrt(static_cast<double>(here.visits));
+                    double best = -1.0;
+                    pick = 0;
+                    for (int i = 0; i < here.n; ++i) {
+                        const double score = static_cast<double>(values[i]) + policy_->c_puct * static_cast<double>(priors[i]) * sqrt_n / static_cast<double>(visits[i] + 1u);
+                        if (score > best) { best = score; pick = i; }
+                    }
+                }
+                node = here.first + static_cast<uint32_t>(pick);
+                path.push_back(cells[pick]);
+                path_nodes.push_back(node);
+                leaf.apply_move(Position(cells[pick]), false);      // Policy::applyMove: no victory check
+                player = -player;
+            }
+            throw_gmk(gmk_az_set_leaf_host(az_handle_, 0, node, path.data(), static_cast<int>(path.size())));
+            // ---- the leaf: finished game, or simulate + expand (MCTS.cpp:164-172) ----
+            float state_value = 0.0f;                               // for the player to move at the leaf; the node's value is its negative
+            double node_value;
+            bool expand_on_device = false;
+            std::vector<float> probs(kN, 0.0f);
+            std::shared_ptr<Node> leaf_obj;
+            if (leaf.check_end()) {
+                node_value = calc_score(player, leaf.winner_);
+            } else {
+                if (policy_->simulate) {
+                    auto [value, arr] = policy_->simulate(leaf);
+                    auto flat = py::array_t<float, py::array::c_style | py::array::forcecast>(arr);
+                    if (flat.size() != kN) throw std::runtime_error("eval_state must return (value, probabilities of size 225)");
+                    std::memcpy(probs.data(), flat.data(), sizeof(float) * kN);
+                    state_value = value;
+                } else {                                            // Default::Simulate: one random rollout, uniform probabilities
+                    int32_t winner = 0;
+                    throw_gmk(gmk_az_rollout_host(az_handle_, 0, g_search_seed, game_id_, az_playouts_done_, root_stones << 8, &winner));
+                    state_value = calc_score(leaf.cur_, static_cast<Player>(winner));
+                    const float uniform = 1.0f / static_cast<float>(leaf.counts_[Board::idx(Player::None)]);
+                    for (int i = 0; i < kN; ++i) probs[static_cast<size_t>(i)] = leaf.cell_[static_cast<size_t>(i)] == Player::None ? uniform : 0.0f;
+                }
+                if (policy_->expand) {
+                    leaf_obj = snapshot(read_node(node), player, nullptr);
+                    py::array_t<float> arr(kN);
+                    std::memcpy(arr.mutable_data(), probs.data(), sizeof(float) * kN);
+                    python_expanded += policy_->expand(py::cast(leaf_obj), leaf, arr);
+                } else {
+                    expand_on_device = true;
+                }
+                node_value = -static_cast<double>(state_value);
+            }
+            // ---- back-propagate (MCTS.cpp:173) ----
+            if (policy_->back_prop) {
+                throw_gmk(gmk_az_expand_stages_host(az_handle_, nullptr, probs.data(), expand_on_device ? 1 : 0, 0));
+                std::vector<std::shared_ptr<Node>> chain;
+                Player p = root_->player;
+                for (size_t i = 0; i < path_nodes.size(); ++i, p = -p)
+                    chain.push_back(snapshot(read_node(path_nodes[i]), p, i ? chain[i - 1] : nullptr));
+                policy_->back_prop(py::cast(chain.back()), leaf, node_value);
+                std::vector<uint32_t> v(chain.size());
+                std::vector<float> q(chain.size());
+                for (size_t i = 0; i < chain.size(); ++i) { v[i] = static_cast<uint32_t>(chain[i]->node_visits); q[i] = chain[i]->state_value; }
+                throw_gmk(gmk_az_write_stats_host(az_handle_, 0, path_nodes.data(), v.data(), q.data(), static_cast<int>(chain.size())));
+            } else {
+                const float minus = static_cast<float>(-node_value);   // az_expand_kernel backs up the negative of what it is given
+                throw_gmk(gmk_az_expand_stages_host(az_handle_, &minus, probs.data(), expand_on_device ? 1 : 0, 1));
+            }
+            ++az_playouts_done_;
+            ++done;
+        };
+        if (by_iterations_) {
+            for (size_t i = 0; i < iterations_; ++i) playout();
+            duration_ = std::chrono::duration_cast<milliseconds>(std::chrono::system_clock::now() - start);
+        } else {
+            for (auto end = start; end - start < duration_ && done < static_cast<size_t>(budget); end = std::chrono::system_clock::now()) playout();
+            iterations_ = done;
+        }
+        const int32_t nodes = az_finish(board);
+        size_ += static_cast<size_t>(nodes - nodes_before) + python_expanded;
         policy_->cleanup(board);
     }
 
@@ -507,6 +652,7 @@ private:
     gmk_az* az_handle_ = nullptr;
     std::vector<Position> az_record_;                               // the moves that lead to the device tree's root (Policy(eval_state=...))
     bool az_valid_ = false;
+    uint32_t az_playouts_done_ = 0;                                 // playouts on the current root (the counter of Default::Simulate's draws)
     int az_capacity_ = 0;
     double az_c_puct_ = 0;
     int trad_capacity_ = 0, best_in_order_ = -1;

@@ -319,6 +319,23 @@ int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, 
  * -1 = nothing to evaluate); expand from host memory.  Synchronous. */
 int gmk_az_select_host(gmk_az* a, int16_t* h_paths, int32_t* h_lens);
 int gmk_az_expand_host(gmk_az* a, const float* h_values, const float* h_probs);
+/* Host-driven STAGES: `Policy(select=, expand=, eval_state=, back_prop=)` hands Python callables to the four stages of
+ * MCTS::playout (core/py_ext/src/mcts_ext.hpp:43-61, core/lib/include/MCTS.h:74-101).  The callables run on the host; the tree stays on the
+ * device, and the host reads what it is asked about and tells the device what was decided.  One game (`game`) of the handle; synchronous.
+ *   gmk_az_read_node_host / _read_children_host   a node (visits, value, prior, cell, parent, child range) and the nodes of a child range
+ *   gmk_az_set_leaf_host            the leaf a host-side descent ended at (node, the moves from the root): it becomes the pending leaf
+ *   gmk_az_rollout_host             Default::Simulate's random rollout (MonteCarlo.hpp:37-47, 83-88) from the pending leaf, on the device;
+ *                                   counters (global game id, playout number, root stones << 8) = the draws of gmk_mcts_*'s first rollout
+ *   gmk_az_expand_stages_host       gmk_az_expand_host with Default::Expand and Default::BackPropogate switched separately
+ *   gmk_az_write_stats_host         {visits, value} of nodes as a Python back_prop left them */
+int gmk_az_read_node_host(gmk_az* a, int game, uint32_t node, uint32_t* h_visits, float* h_value, float* h_prior, int32_t* h_cell, uint32_t* h_parent,
+                          uint32_t* h_first_child, int32_t* h_n_children);
+int gmk_az_read_children_host(gmk_az* a, int game, uint32_t first_child, int n, int16_t* h_cells, uint32_t* h_visits, float* h_values, float* h_priors,
+                              int32_t* h_n_children);
+int gmk_az_set_leaf_host(gmk_az* a, int game, uint32_t leaf, const int16_t* h_path, int depth);
+int gmk_az_rollout_host(gmk_az* a, int game, uint64_t seed, uint32_t counter0, uint32_t counter1, uint32_t counter2, int32_t* h_winner);
+int gmk_az_expand_stages_host(gmk_az* a, const float* h_values, const float* h_probs, int do_expand, int do_backup);
+int gmk_az_write_stats_host(gmk_az* a, int game, const uint32_t* h_nodes, const uint32_t* h_visits, const float* h_values, int n);
 /* host outputs, any may be NULL; status bit 0 = the game is over (gmk_az_advance), bit 1 = node arena full (playouts of that game were dropped) */
 int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_priors, uint32_t* h_root_visits,
                       float* h_root_value, int32_t* h_n_nodes, int32_t* h_status);

@@ -234,3 +234,111 @@ def test_py_conv_net_agent_plays():
     b = core.Board()
     q, pi, mv = agent.evaluate(b)
     assert abs(float(pi.sum()) - 1.0) < 1e-3 and 0 <= mv.id < 225 and -1.0 <= q <= 1.0
+
+
+def _children_of(m):
+    return [(c.position.id, c.node_visits, np.float32(c.state_value).tobytes(), np.float32(c.action_prob).tobytes()) for c in m.root.children]
+
+
+def _default_select(c_puct):
+    """Default::Select (core/lib/include/algorithms/MonteCarlo.hpp:23-28, 57-68) restated in Python: double arithmetic, first maximum."""
+    import math
+
+    def select(node):
+        best, best_child = -1.0, node.children[0]
+        root_n = math.sqrt(float(node.node_visits))
+        for child in node.children:
+            score = float(child.state_value) + c_puct * float(child.action_prob) * root_n / float(child.node_visits + 1)
+            if score > best:
+                best, best_child = score, child
+        return best_child
+    return select
+
+
+def _default_back_prop(node, board, value):
+    """Default::BackPropogate (MonteCarlo.hpp:90-95) restated in Python, in float32 like the reference's Node fields."""
+    v = np.float32(value)
+    while node is not None:
+        node.node_visits += 1
+        q = np.float32(node.state_value)
+        node.state_value = float(q + (v - q) / np.float32(node.node_visits))
+        node, v = node.parent, -v
+
+
+def test_python_select_plays_the_default_policys_game():
+    """SURVEY 8 a18: Policy(select=f) -- a Python callable in MCTS::playout's select stage (core/py_ext/src/mcts_ext.hpp:43-61).  With f =
+    Default::Select restated in Python and the other stages left to their defaults (Default::Simulate = one random rollout, which runs
+    on the device on the draws of gmk_mcts_*'s first rollout lane), the search must be MCTS(RandomPolicy(c_puct, 1))'s search, move after
+    move: the root's children (visits, value bits, priors), its value, the tree's size; the subtree is kept between the moves."""
+    core.set_root_noise(alpha=0.0)
+    try:
+        calls = [0]
+        inner = _default_select(5.0)
+
+        def counting_select(node):
+            calls[0] += 1
+            assert not node.is_leaf() and all(c.parent is node for c in node.children)
+            return inner(node)
+        results = []
+        for policy_of in (lambda: core.RandomPolicy(5.0, 1), lambda: core.Policy(select=counting_select, c_puct=5.0)):
+            core.set_seed(4242)                                     # the same seed and game number 0 for both searchers
+            m = core.MCTS(c_iterations=150, policy=policy_of())
+            b = core.Board()
+            for mv in (112, 113, 97):
+                b.apply_move(core.Position(mv))
+            trace = []
+            for _ in range(3):
+                q, pi = m.eval_state(b)
+                # (the RandomPolicy search reports its children's visits and priors, not their values: compared without them)
+                trace.append((np.float32(q).tobytes(), [(c[0], c[1], c[3]) for c in _children_of(m)], m.size, np.float32(m.root.state_value).tobytes(), m.root.node_visits))
+                m.step_forward()
+                b.apply_move(m.root.position)
+            results.append(trace)
+        for move, (x, y) in enumerate(zip(results[0], results[1])):
+            assert x[0] == y[0] and x[2:] == y[2:], "move %d: root value / size / visits %r against %r" % (move, (x[0], x[2:]), (y[0], y[2:]))
+            assert x[1] == y[1], "move %d: children differ, first at %r" % (move, next((a, b_) for a, b_ in zip(x[1], y[1]) if a != b_))
+        assert calls[0] > 300                                       # the callable really drove the descents
+    finally:
+        core.set_root_noise(alpha=0.05, epsilon=0.25)
+
+
+def test_python_back_prop_and_expand_stages():
+    """Policy(back_prop=f, eval_state=g): with f = Default::BackPropogate restated in Python (float32, walking Node.parent) the search equals
+    Policy(eval_state=g) whose backup runs on the device; select and back_prop together too.  Policy(expand=h): h is called once per
+    simulated leaf with (node, board, probabilities), its return value counts into MCTS.size, and -- as in the reference, where a Python
+    callable has no way to attach children -- the node stays a leaf."""
+    from test_az_gpu import surrogate
+    core.set_root_noise(alpha=0.0)
+    try:
+        def evaluator(board):
+            value, probs = surrogate(np.asarray(board.encoded_states(), dtype=np.float32))
+            return float(value), probs
+        traces = []
+        for kw in ({}, {"back_prop": _default_back_prop}, {"select": _default_select(4.0), "back_prop": _default_back_prop}):
+            core.set_seed(99)
+            m = core.MCTS(c_iterations=120, policy=core.Policy(eval_state=evaluator, c_puct=4.0, **kw))
+            b = core.Board()
+            for mv in (112, 98):
+                b.apply_move(core.Position(mv))
+            trace = []
+            for _ in range(2):
+                q, pi = m.eval_state(b)
+                trace.append((np.float32(q).tobytes(), _children_of(m), m.size, m.root.node_visits))
+                m.step_forward()
+                b.apply_move(m.root.position)
+            traces.append(trace)
+        assert traces[0] == traces[1] == traces[2]
+        seen = []
+
+        def expand(node, board, probs):
+            seen.append((node.position.id, len(board.move_record), float(np.asarray(probs).sum())))
+            return 7
+        core.set_seed(5)
+        m = core.MCTS(c_iterations=20, policy=core.Policy(expand=expand, eval_state=evaluator, c_puct=4.0))
+        b = core.Board()
+        b.apply_move(core.Position(112))
+        m.eval_state(b)
+        assert len(seen) == 20 and all(s[1] == 1 for s in seen) and m.size == 1 + 7 * 20
+        assert m.root.is_leaf() and m.root.node_visits == 20
+    finally:
+        core.set_root_noise(alpha=0.05, epsilon=0.25)
