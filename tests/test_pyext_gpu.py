@@ -342,3 +342,32 @@ def test_python_back_prop_and_expand_stages():
         assert m.root.is_leaf() and m.root.node_visits == 20
     finally:
         core.set_root_noise(alpha=0.05, epsilon=0.25)
+
+
+def test_python_select_on_a_nearly_full_board():
+    """The same equality from a position with 11 empty cells: the descents end at finished games (fives, full boards), whose values the
+    host-driven loop backs up itself (CalcScore(node.player, winner), MCTS.cpp:174), and at leaves whose rollouts fill the board."""
+    rng = np.random.RandomState(31)
+    cls = lambda c: ((c % 15) // 2 + c // 15) % 2             # two colour classes that never line up five
+    blacks, whites = [c for c in range(225) if cls(c) == 0], [c for c in range(225) if cls(c) == 1]
+    bl, wh = list(rng.permutation(blacks)), list(rng.permutation(whites))
+    seq = []
+    while bl or wh:
+        if bl:
+            seq.append(int(bl.pop()))
+        if wh:
+            seq.append(int(wh.pop()))
+    core.set_root_noise(alpha=0.0)
+    try:
+        results = []
+        for policy_of in (lambda: core.RandomPolicy(5.0, 1), lambda: core.Policy(select=_default_select(5.0), c_puct=5.0)):
+            core.set_seed(77)
+            m = core.MCTS(c_iterations=200, policy=policy_of())
+            b = core.Board()
+            for mv in seq[:214]:
+                b.apply_move(core.Position(mv))
+            q, pi = m.eval_state(b)
+            results.append((np.float32(q).tobytes(), [(c.position.id, c.node_visits) for c in m.root.children], m.size, m.root.node_visits))
+        assert results[0] == results[1] and len(results[0][1]) == 11
+    finally:
+        core.set_root_noise(alpha=0.05, epsilon=0.25)
