@@ -30,6 +30,7 @@
 #include "philox.h"
 #include "rollout_device.h"
 #include "root_noise.h"
+#include "noise_device.h"
 
 namespace {
 
@@ -54,7 +55,8 @@ struct GameHeader {                 // 128 B per game, in HBM
     uint32_t playouts_done;         // playouts already run from this root (RNG counter word 1 continues across launches)
     uint32_t noise;                 // 1: the root's children take their priors from root_prior[] (Default::AddNoise ran)
     uint32_t root_expanded;         // scratch for gmk_mcts_add_root_noise
-    uint32_t pad[5];
+    uint32_t pad[4];                // (diagnostic build: clock sums of the four phases)
+    uint32_t arena;                 // the persistent self-play loop with kept subtrees: which of the game's two arenas holds its tree (0 / 1); 0 everywhere else
 };
 static_assert(sizeof(GameHeader) == 128, "GameHeader layout");
 
@@ -95,11 +97,19 @@ struct SearchParams {
     int8_t* rec_winner;
     int32_t* unfinished;            // (written, never read, in this mode)
     SlotRefill slots;
+    // ... with the reference agent's per-move semantics (agents/mcts.py:17-21, MCTS.cpp:129-147, 179-183): the chosen child's subtree is kept --
+    // compacted into the game's OTHER arena (arena_stride nodes further on; GameHeader::arena says which one is live), per game, inside the launch --
+    // and Default::AddNoise runs before every search, drawn by the wavefront itself from the counter-based sampler of include/gomoku_noise.h
+    int reuse;
+    float noise_alpha, noise_epsilon;   // alpha == 0: no noise
+    size_t arena_stride;                // nodes between a game's two arenas (0: there is one arena)
 };
 
-__device__ void advance_one(int g, int lane, GameHeader* headers, uint2* stats, uint32_t* link, uint32_t* parent, uint2* stats2, uint32_t* link2,
+__device__ bool advance_one(int g, int lane, GameHeader* headers, uint2* stats, uint32_t* link, uint32_t* parent, uint2* stats2, uint32_t* link2,
                             uint32_t* parent2, size_t cap, uint8_t* rec_moves, uint16_t* rec_visits, int32_t* rec_lens, int8_t* rec_winner,
-                            int32_t* unfinished, int reuse, const int16_t* forced, const SlotRefill& slots);
+                            int32_t* unfinished, int reuse, int flip_all, const int16_t* forced, const SlotRefill& slots);
+__device__ void root_noise_one(int g, int lane, GameHeader* headers, const uint32_t* link, float* root_prior, size_t cap, size_t arena_stride,
+                               float alpha, float epsilon, uint32_t seed_lo, uint32_t seed_hi);
 
 __constant__ float c_prior[226];          // 1.0f / float(n) evaluated on the host (MonteCarlo.hpp:50-55)
 
@@ -136,6 +146,9 @@ __device__ __forceinline__ int row_scan(int v) {                        // inclu
     return v;
 }
 
+// kTurns = false: one search (gmk_mcts_run); true: the persistent self-play loop, search after search with the step (and the root noise) in between.
+// Two instantiations, so that the bare search does not carry the registers of the turn loop through its playouts.
+template <bool kTurns>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))      // two wavefronts per SIMD: at most 256 registers
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
                           uint32_t* __restrict__ parent, const float* __restrict__ root_prior, SearchParams prm) {
@@ -158,6 +171,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     __shared__ uint2 s_root_stats[kMaxGamesPerBlock];
     __shared__ uint32_t s_root_link[kMaxGamesPerBlock], s_leaf_link[kMaxGamesPerBlock];
     __shared__ uint32_t s_rng_game[kMaxGamesPerBlock], s_rng_playout[kMaxGamesPerBlock], s_rng_stones[kMaxGamesPerBlock];   // Philox counter words of a game's rollouts
+    __shared__ size_t s_arena[kMaxGamesPerBlock];                // first node of the game's LIVE arena (the persistent loop with kept subtrees flips it per game)
 
     const int lane = threadIdx.x, quarter = lane >> 4, l16 = lane & 15;
     const int G = prm.games_per_block, R = prm.c_rollouts;
@@ -177,12 +191,14 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         s_rng_playout[lane] = ok ? headers[game0 + lane].playouts_done : 0u;
         s_rng_stones[lane] = ok ? headers[game0 + lane].stones << 8 : 0u;
         const uint32_t root = ok ? headers[game0 + lane].root : 0u;
+        const size_t arena = static_cast<size_t>(game0 + lane) * cap + ((kTurns && ok && headers[game0 + lane].arena) ? prm.arena_stride : 0);
+        s_arena[lane] = arena;
         s_root[lane] = root;
         s_root_stones[lane] = ok ? headers[game0 + lane].stones : 0u;
         s_root_last[lane] = ok ? headers[game0 + lane].last_move : 255u;
         s_root_noise[lane] = ok ? headers[game0 + lane].noise : 0u;
-        s_root_stats[lane] = ok ? stats[static_cast<size_t>(game0 + lane) * cap + root] : make_uint2(0u, 0u);
-        s_root_link[lane] = ok ? link[static_cast<size_t>(game0 + lane) * cap + root] : 0u;
+        s_root_stats[lane] = ok ? stats[arena + root] : make_uint2(0u, 0u);
+        s_root_link[lane] = ok ? link[arena + root] : 0u;
     }
     for (int i = lane; i < kMaxGamesPerBlock * 16; i += 64) s_root_rows[i >> 4][i & 15] = (i >> 4) < games_here ? headers[game0 + (i >> 4)].rows[i & 15] : 0u;
     __syncthreads();
@@ -209,7 +225,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
             constexpr int W = decltype(width_tag)::value, kPerLane = (225 + W - 1) / W;
             const int lw = lane & (W - 1);
             {
-                const size_t base = static_cast<size_t>(game0 + gs) * cap;
+                const size_t base = s_arena[gs];
                 uint32_t row = s_root_rows[gs][l16];                 // lane y holds row y of the board
                 const uint32_t root = s_root[gs];
                 uint32_t cur = root, ply = s_root_stones[gs], last = s_root_last[gs];
@@ -402,7 +418,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         for (int round = 0; round < rounds; ++round) {
             const int gs = round * 4 + quarter;
             if (gs < games_here && s_active[gs]) {
-                const size_t base = static_cast<size_t>(game0 + gs) * cap;
+                const size_t base = s_arena[gs];
                 const uint32_t cur = s_cur[gs], ply = s_ply[gs];
                 float value;
                 unsigned long long bytes = 0;
@@ -477,7 +493,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         if (s_active[lane]) headers[game0 + lane].playouts_done += static_cast<uint32_t>(prm.playouts);
         if (gmk::kProfileBuild && prm.profile) for (int k = 0; k < 4; ++k) headers[game0 + lane].pad[k] = static_cast<uint32_t>(prof[k] >> 10);
     }
-    if (!prm.persistent) break;
+    if (!kTurns) break;
     // the step of every game of this wavefront (headers and trees were written by other lanes than the ones that read them now, and the
     // next turn reads what the step writes: an agent-scope release / acquire pair either side)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -490,13 +506,28 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         int first_ = game0, lane_ = lane;
         asm volatile("" : "+s"(h_), "+s"(st_), "+s"(lk_), "+s"(pa_), "+s"(first_), "+v"(lane_));
 #pragma unroll 1
-        for (int g = 0; g < games_here; ++g)
-            advance_one(first_ + g, lane_, h_, st_, lk_, pa_, nullptr, nullptr, nullptr, cap, prm.rec_moves, prm.rec_visits, prm.rec_lens, prm.rec_winner,
-                        prm.unfinished, 0, nullptr, prm.slots);
+        for (int g = 0; g < games_here; ++g) {
+            // the game's live arena and its other one (one and the same without kept subtrees: arena_stride = 0)
+            const size_t live = h_[first_ + g].arena ? prm.arena_stride : 0, other = prm.arena_stride - live;
+            const bool flipped = advance_one(first_ + g, lane_, h_, st_ + live, lk_ + live, pa_ + live, st_ + other, lk_ + other, pa_ + other, cap, prm.rec_moves, prm.rec_visits,
+                                             prm.rec_lens, prm.rec_winner, prm.unfinished, prm.reuse, 0, nullptr, prm.slots);
+            if (flipped && lane_ == 0) h_[first_ + g].arena ^= 1u;     // the kept subtree was compacted into the other arena: that one is the tree now
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (prm.noise_alpha > 0.0f) {                                   // Default::AddNoise before the next search (MCTS.cpp:182), on the roots that have children
+        GameHeader* h_ = headers; uint32_t* lk_ = link; float* rp_ = const_cast<float*>(root_prior);
+        int first_ = game0, lane_ = lane;
+        asm volatile("" : "+s"(h_), "+s"(lk_), "+s"(rp_), "+s"(first_), "+v"(lane_));
+#pragma unroll 1
+        for (int g = 0; g < games_here; ++g)
+            root_noise_one(first_ + g, lane_, h_, lk_, rp_, cap, prm.arena_stride, prm.noise_alpha, prm.noise_epsilon, prm.seed_lo, prm.seed_hi);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     bool any = false;
     for (int g = 0; g < games_here; ++g) any |= !(headers[game0 + g].status & 1u);
     if (!any) break;
@@ -517,14 +548,17 @@ __global__ void mcts_init_roots_kernel(const GameHeader* __restrict__ headers, u
 // One self-play move per unfinished game: MCTS::stepForward() (MCTS.cpp:129-134) + Board::applyMove with the
 // victory check (Game.cpp:37-47, 88-136) on the root position, the (move, visit counts) record of
 // agents/utils.py:29-41, and the new root.  One wavefront per game.
-__device__ void advance_one(int g, int lane, GameHeader* headers, uint2* stats, uint32_t* link, uint32_t* parent, uint2* stats2, uint32_t* link2,
+// reuse: the chosen child's subtree is kept (copied into arena 2); flip_all: the caller swaps the arenas of ALL games afterwards (the lock-step
+// loop: whatever a game's tree is after this step has to be in arena 2), otherwise only a game that kept a subtree moves, and the return value
+// says so (the persistent loop: GameHeader::arena).  Returns (wave-uniform) whether the game's tree is in arena 2 now.
+__device__ bool advance_one(int g, int lane, GameHeader* headers, uint2* stats, uint32_t* link, uint32_t* parent, uint2* stats2, uint32_t* link2,
                             uint32_t* parent2, size_t cap, uint8_t* rec_moves, uint16_t* rec_visits, int32_t* rec_lens, int8_t* rec_winner,
-                            int32_t* unfinished, int reuse,
+                            int32_t* unfinished, int reuse, int flip_all,
                             const int16_t* forced /* null, or per game: the move to step to (MCTS::stepForward(move)), -1 = the most visited child */,
                             const SlotRefill& slots) {
     GameHeader& hdr = headers[g];
     const int rec = slots.slot_game ? slots.slot_game[g] : g;      // the records' row of this slot's game
-    if (rec < 0) return;                                            // a slot that never got a game
+    if (rec < 0) return false;                                      // a slot that never got a game
     const size_t base = static_cast<size_t>(g) * cap;
     const uint32_t root = hdr.root, stones = hdr.stones;
     const uint32_t first = link[base + root] >> 8;
@@ -533,14 +567,14 @@ __device__ void advance_one(int g, int lane, GameHeader* headers, uint2* stats, 
     const bool can_force = want >= 0 && want < 225 && !(row_want & 0x10001u);
     if (want >= 0 && !can_force && lane == 0) hdr.status |= 4u;     // the move is not legal on the root position: nothing is played
     if ((hdr.status & 1u) || (!first && !can_force) || (want >= 0 && !can_force)) {     // already over, never searched, or an illegal request: nothing to play
-        if (reuse && lane == 0) {                                   // the live arena flips for every game: carry the root over
+        if (reuse && flip_all && lane == 0) {                       // the live arena flips for every game: carry the root over
             stats2[base] = stats[base + root];
             link2[base] = link[base + root] & 0xFFu;
             parent2[base] = kNone;
             hdr.root = 0;
             hdr.n_nodes = 1;
         }
-        return;
+        return reuse && flip_all;
     }
     const int n_child = 225 - static_cast<int>(stones);
     long long best = -1;
@@ -614,13 +648,13 @@ __device__ void advance_one(int g, int lane, GameHeader* headers, uint2* stats, 
         if (!keep || refilled) {                                    // MCTS::reset + syncWithBoard: a fresh one-node tree
             hdr.root = 0;
             hdr.n_nodes = 1;
-            (reuse ? stats2 : stats)[base] = make_uint2(0u, 0u);    // with reuse the live arena flips for every game
-            (reuse ? link2 : link)[base] = root_cell;
-            (reuse ? parent2 : parent)[base] = kNone;
+            ((reuse && flip_all) ? stats2 : stats)[base] = make_uint2(0u, 0u);    // in the lock-step loop with reuse the live arena flips for every game
+            ((reuse && flip_all) ? link2 : link)[base] = root_cell;
+            ((reuse && flip_all) ? parent2 : parent)[base] = kNone;
         }
     }
     refilled = __shfl(static_cast<int>(refilled), 0, 64) != 0;
-    if (!keep || refilled) return;
+    if (!keep || refilled) return reuse && flip_all;
 
     // The subtree of the move becomes the tree (updateRoot, MCTS.cpp:63-67); the reference frees the siblings, here
     // the kept subtree is copied level by level into the other arena so that node indices stay dense.  In the new
@@ -655,6 +689,46 @@ __device__ void advance_one(int g, int lane, GameHeader* headers, uint2* stats, 
         i0 += chunk;
     }
     if (lane == 0) { hdr.root = 0; hdr.n_nodes = next; }
+    return true;
+}
+
+// Default::AddNoise (MonteCarlo.hpp:97-108) on the root of game g, by one wavefront, with the counter-based sampler (noise_device.h): the root's
+// children are its empty cells in ascending order, every one with Default::UniformProbs' prior 1 / float(children); the mixed priors go to
+// root_prior[g][child] and GameHeader::noise tells select to read them.  A finished game or a root without children takes none (the loop
+// over node->children is empty there).  Draws are keyed by (seed; global game id, stones on the root board, cell).
+__device__ void root_noise_one(int g, int lane, GameHeader* headers, const uint32_t* link, float* root_prior, size_t cap, size_t arena_stride,
+                               float alpha, float epsilon, uint32_t seed_lo, uint32_t seed_hi) {
+    GameHeader& hdr = headers[g];
+    const size_t base = static_cast<size_t>(g) * cap + (hdr.arena ? arena_stride : 0);
+    const bool apply = !(hdr.status & 1u) && (link[base + hdr.root] >> 8) != 0u;
+    if (apply) {
+        const uint32_t stones = hdr.stones;
+        const float uniform = c_prior[225u - stones];
+        float p[4];
+        int rank[4];
+        bool child[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cell = lane + 64 * j, y = min(cell, 224) / 15, x = min(cell, 224) % 15;
+            int before = 0;                                         // empty cells in front of this one = the child's index
+            for (int yy = 0; yy < y; ++yy) { const uint32_t r = hdr.rows[yy]; before += __popc(~(r | (r >> 16)) & 0x7FFFu); }
+            const uint32_t r = hdr.rows[y], open = ~(r | (r >> 16)) & 0x7FFFu;
+            rank[j] = before + __popc(open & ((1u << x) - 1u));
+            child[j] = cell < 225 && ((open >> x) & 1u);
+            p[j] = child[j] ? uniform : 0.0f;
+        }
+        gmk::noise::mix_root_priors(p, lane, alpha, epsilon, hdr.game_id, stones, seed_lo, seed_hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (child[j]) root_prior[static_cast<size_t>(g) * 225 + rank[j]] = p[j];
+    }
+    if (lane == 0) hdr.noise = apply ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(64)
+void mcts_root_noise_kernel(GameHeader* __restrict__ headers, const uint32_t* __restrict__ link, float* __restrict__ root_prior, size_t cap, int n_games,
+                            float alpha, float epsilon, uint32_t seed_lo, uint32_t seed_hi) {
+    if (static_cast<int>(blockIdx.x) < n_games) root_noise_one(blockIdx.x, threadIdx.x, headers, link, root_prior, cap, 0, alpha, epsilon, seed_lo, seed_hi);
 }
 
 __global__ __launch_bounds__(64)
@@ -668,7 +742,7 @@ void mcts_advance_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ s
     // counters[0] counts the games that go on, counters[1] the workgroups that are through: the last one hands the count to the caller and
     // leaves both at zero for the next launch -- no memset in front of every step (a four-byte fill is a launch of its own, and beside a
     // second handle's search it waited milliseconds for a wavefront slot)
-    advance_one(blockIdx.x, threadIdx.x, headers, stats, link, parent, stats2, link2, parent2, cap, rec_moves, rec_visits, rec_lens, rec_winner, &counters[0], reuse, forced, slots);
+    advance_one(blockIdx.x, threadIdx.x, headers, stats, link, parent, stats2, link2, parent2, cap, rec_moves, rec_visits, rec_lens, rec_winner, &counters[0], reuse, 1, forced, slots);
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&counters[1], 1) == n_games - 1) {
@@ -686,13 +760,13 @@ __global__ void mcts_root_flags_kernel(GameHeader* __restrict__ headers, const u
 
 // children of the root -> visit counts by cell (MCTS::evalState, MCTS.cpp:104-110)
 __global__ void mcts_root_stats_kernel(const GameHeader* __restrict__ headers, const uint2* __restrict__ stats,
-                                       const uint32_t* __restrict__ link, size_t cap, int n_games,
+                                       const uint32_t* __restrict__ link, size_t cap, size_t arena_stride, int n_games,
                                        uint32_t* __restrict__ visits, float* __restrict__ root_value,
                                        uint32_t* __restrict__ root_visits, uint32_t* __restrict__ nodes, int32_t* __restrict__ status) {
     const int g = blockIdx.x;
     if (g >= n_games) return;
     const GameHeader& hdr = headers[g];
-    const size_t base = static_cast<size_t>(g) * cap;
+    const size_t base = static_cast<size_t>(g) * cap + (hdr.arena ? arena_stride : 0);
     for (int i = threadIdx.x; i < 225; i += blockDim.x) visits[static_cast<size_t>(g) * 225 + i] = 0;
     __syncthreads();
     const uint32_t first = link[base + hdr.root] >> 8;
@@ -726,7 +800,7 @@ struct gmk_mcts {
     float* d_root_prior = nullptr;     // [n_games][225] by child index, used while GameHeader::noise is set
     float* d_value = nullptr;          // [2 * c_rollouts + 1] rollout sum -> state value
     SlotRefill slots{};                // continuous batching (gmk_selfplay_run); all null otherwise
-    struct { uint8_t* moves; uint16_t* visits; int32_t* lens; int8_t* winner; int32_t* unfinished; } persistent_rec{};     // set while gmk_selfplay_run's ONE launch is issued
+    struct { uint8_t* moves; uint16_t* visits; int32_t* lens; int8_t* winner; int32_t* unfinished; int reuse; float noise_alpha, noise_epsilon; } persistent_rec{};     // set while gmk_selfplay_run's ONE launch is issued
     int32_t* d_slot_state = nullptr;   // [n_games + 1] slot_game, next_game
     int32_t* d_step_counters = nullptr; // [2] mcts_advance_kernel's own (zero between launches)
     uint8_t* d_open_moves = nullptr;
@@ -734,6 +808,14 @@ struct gmk_mcts {
     void* d_step_scratch = nullptr;    // record outputs of gmk_mcts_step_host
     hipStream_t last_stream = nullptr;
     bool rooted = false;               // gmk_mcts_set_roots has run: headers and arenas hold trees
+    // gmk_mcts_set_option
+    int noise_sampler = GMK_NOISE_SAMPLER_STD;   // where Default::AddNoise draws from
+    int lockstep = 0;                  // 1: gmk_selfplay_run alternates search and step launches even where ONE persistent launch could play the games
+    // the persistent loop with kept subtrees wants a game's two arenas a fixed distance apart: both halves of ONE allocation per array
+    bool paired = false;
+    uint2* block_stats = nullptr;
+    uint32_t *block_link = nullptr, *block_parent = nullptr;
+    size_t arena_stride() const { return (paired && d_stats2 > d_stats) ? static_cast<size_t>(d_stats2 - d_stats) : 0; }
 };
 
 extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, int c_rollouts, uint64_t seed, gmk_mcts** out) {
@@ -756,10 +838,10 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
     int gpb = std::min(4, (n_games + 2 * simds - 1) / (2 * simds));
     if (const char* env = gmk::profile_env("GMK_MCTS_GAMES_PER_BLOCK")) gpb = std::atoi(env);
     m->games_per_block = std::max(1, std::min(max_gpb, gpb));
-    const size_t nodes = static_cast<size_t>(n_games) * static_cast<size_t>(node_capacity);
-    if (gmk::device_malloc(&m->d_headers, sizeof(GameHeader) * n_games) != hipSuccess || gmk::device_malloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess ||
-        gmk::device_malloc(&m->d_link, nodes * 4) != hipSuccess || gmk::device_malloc(&m->d_parent, nodes * 4) != hipSuccess) {
-        gmk::set_error("gmk_mcts_create: hipMalloc of %zu nodes (%.1f GB) failed", nodes, nodes * 16.0 / 1e9);
+    // (the tree arenas -- tens of GB -- are allocated by the first gmk_mcts_set_roots, or by gmk_selfplay_run as the two halves of one block per array
+    // when it keeps subtrees inside its persistent launch: allocating them here only to replace them there costs seconds of driver time)
+    if (gmk::device_malloc(&m->d_headers, sizeof(GameHeader) * n_games) != hipSuccess) {
+        gmk::set_error("gmk_mcts_create: hipMalloc of the game headers failed");
         gmk_mcts_destroy(m);
         return GMK_ERR_HIP;
     }
@@ -786,6 +868,10 @@ extern "C" int gmk_mcts_create(int n_games, int node_capacity, double c_puct, in
 
 extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     if (!m) return GMK_OK;
+    if (m->paired) {                                                // both arenas are halves of the three blocks
+        (void)gmk::device_free(m->block_stats); (void)gmk::device_free(m->block_link); (void)gmk::device_free(m->block_parent);
+        m->d_stats = m->d_stats2 = nullptr; m->d_link = m->d_link2 = nullptr; m->d_parent = m->d_parent2 = nullptr;
+    }
     (void)gmk::device_free(m->d_headers); (void)gmk::device_free(m->d_stats); (void)gmk::device_free(m->d_link); (void)gmk::device_free(m->d_parent); (void)gmk::device_free(m->d_value);
     (void)gmk::device_free(m->d_slot_state); (void)gmk::device_free(m->d_open_moves); (void)gmk::device_free(m->d_open_lens); (void)gmk::device_free(m->d_step_counters);
     (void)gmk::device_free(m->d_stats2); (void)gmk::device_free(m->d_link2); (void)gmk::device_free(m->d_parent2); (void)gmk::device_free(m->d_root_prior); (void)gmk::device_free(m->d_step_scratch);
@@ -793,8 +879,54 @@ extern "C" int gmk_mcts_destroy(gmk_mcts* m) {
     return GMK_OK;
 }
 
+extern "C" int gmk_mcts_set_option(gmk_mcts* m, int option, int value) {
+    if (!m) { gmk::set_error("gmk_mcts_set_option: bad arguments"); return GMK_ERR_ARG; }
+    if (option == GMK_OPT_NOISE_SAMPLER && (value == GMK_NOISE_SAMPLER_STD || value == GMK_NOISE_SAMPLER_COUNTER)) { m->noise_sampler = value; return GMK_OK; }
+    if (option == GMK_OPT_LOCKSTEP && (value == 0 || value == 1)) { m->lockstep = value; return GMK_OK; }
+    gmk::set_error("gmk_mcts_set_option: unknown option %d or value %d", option, value);
+    return GMK_ERR_ARG;
+}
+
+// Both arenas of every game as the two halves of ONE block per array (the persistent loop with kept subtrees adds a fixed stride to a game's
+// node indices to reach its other arena).  The trees are lost: call before gmk_mcts_set_roots.
+static int pair_arenas(gmk_mcts* m) {
+    const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
+    if (m->paired) {
+        m->d_stats = m->block_stats; m->d_link = m->block_link; m->d_parent = m->block_parent;       // (the lock-step loop may have left them swapped)
+        m->d_stats2 = m->block_stats + nodes; m->d_link2 = m->block_link + nodes; m->d_parent2 = m->block_parent + nodes;
+        return GMK_OK;
+    }
+    (void)gmk::device_free(m->d_stats); (void)gmk::device_free(m->d_link); (void)gmk::device_free(m->d_parent);
+    (void)gmk::device_free(m->d_stats2); (void)gmk::device_free(m->d_link2); (void)gmk::device_free(m->d_parent2);
+    m->d_stats = m->d_stats2 = nullptr; m->d_link = m->d_link2 = nullptr; m->d_parent = m->d_parent2 = nullptr;
+    m->rooted = false;
+    if (gmk::device_malloc(&m->block_stats, 2 * nodes * sizeof(uint2)) != hipSuccess || gmk::device_malloc(&m->block_link, 2 * nodes * 4) != hipSuccess ||
+        gmk::device_malloc(&m->block_parent, 2 * nodes * 4) != hipSuccess) {
+        (void)gmk::device_free(m->block_stats); (void)gmk::device_free(m->block_link); (void)gmk::device_free(m->block_parent);
+        m->block_stats = nullptr; m->block_link = nullptr; m->block_parent = nullptr;
+        (void)hipGetLastError();
+        gmk::set_error("gmk_selfplay_run: hipMalloc of two arenas per game (%zu nodes, %.1f GB) failed", 2 * nodes, 2 * nodes * 16.0 / 1e9);
+        return GMK_ERR_HIP;
+    }
+    m->paired = true;
+    m->d_stats = m->block_stats; m->d_link = m->block_link; m->d_parent = m->block_parent;
+    m->d_stats2 = m->block_stats + nodes; m->d_link2 = m->block_link + nodes; m->d_parent2 = m->block_parent + nodes;
+    return GMK_OK;
+}
+
 extern "C" int gmk_mcts_set_roots(gmk_mcts* m, const uint16_t* h_planes, const int16_t* h_last_move, uint32_t first_game_id) {
     if (!m || !h_planes || !h_last_move) { gmk::set_error("gmk_mcts_set_roots: bad arguments"); return GMK_ERR_ARG; }
+    if (!m->d_stats) {                                              // the first roots of this handle: its tree arena
+        const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
+        if (gmk::device_malloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess || gmk::device_malloc(&m->d_link, nodes * 4) != hipSuccess ||
+            gmk::device_malloc(&m->d_parent, nodes * 4) != hipSuccess) {
+            (void)gmk::device_free(m->d_stats); (void)gmk::device_free(m->d_link); (void)gmk::device_free(m->d_parent);
+            m->d_stats = nullptr; m->d_link = nullptr; m->d_parent = nullptr;
+            (void)hipGetLastError();
+            gmk::set_error("gmk_mcts_set_roots: hipMalloc of %zu nodes (%.1f GB) failed", nodes, nodes * 16.0 / 1e9);
+            return GMK_ERR_HIP;
+        }
+    }
     std::vector<GameHeader> hdr(static_cast<size_t>(m->n_games));
     for (int g = 0; g < m->n_games; ++g) {
         GameHeader& h = hdr[static_cast<size_t>(g)];
@@ -847,14 +979,20 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
     prm.profile = gmk::profile_env("GMK_MCTS_PROFILE") ? 1 : 0;
     prm.value_table = m->d_value;
     prm.persistent = 0; prm.rec_moves = nullptr; prm.rec_visits = nullptr; prm.rec_lens = nullptr; prm.rec_winner = nullptr; prm.unfinished = nullptr; prm.slots = SlotRefill{};
+    prm.reuse = 0; prm.noise_alpha = 0.0f; prm.noise_epsilon = 0.0f; prm.arena_stride = m->arena_stride();
     if (m->persistent_rec.moves) {                              // gmk_selfplay_run's persistent form: this launch plays the games to their end
         prm.persistent = 1;
         prm.rec_moves = m->persistent_rec.moves; prm.rec_visits = m->persistent_rec.visits; prm.rec_lens = m->persistent_rec.lens; prm.rec_winner = m->persistent_rec.winner;
         prm.unfinished = m->persistent_rec.unfinished; prm.slots = m->slots;
+        prm.reuse = m->persistent_rec.reuse; prm.noise_alpha = m->persistent_rec.noise_alpha; prm.noise_epsilon = m->persistent_rec.noise_epsilon;
     }
     m->last_stream = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mcts_playouts_kernel, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
-                       m->d_root_prior, prm);
+    if (prm.persistent)
+        hipLaunchKernelGGL(mcts_playouts_kernel<true>, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
+                           m->d_root_prior, prm);
+    else
+        hipLaunchKernelGGL(mcts_playouts_kernel<false>, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
+                           m->d_root_prior, prm);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }
@@ -932,8 +1070,16 @@ extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id
     const int started = std::min(n_slots, n_total);
     for (int g = 0; g < started; ++g) slot_state[static_cast<size_t>(g)] = g;
     slot_state[static_cast<size_t>(n_slots)] = started;                         // next_game
-    int rc = gmk_mcts_set_roots(m, planes.data(), last.data(), first_game_id);
+    // ONE launch (SearchParams::persistent) wherever nothing has to come from the host between two searches: every wavefront plays its slots'
+    // games turn by turn at its own pace; the records are the same bytes either way (a game's random streams are keyed by its global id).
+    const bool noisy = noise_alpha > 0.0f && reuse_subtree;                     // (a new root has no children: AddNoise is a no-op without kept subtrees)
+    const bool persistent = !m->lockstep && !(noisy && m->noise_sampler != GMK_NOISE_SAMPLER_COUNTER);
+    int rc = GMK_OK;
+    if (persistent && reuse_subtree) rc = pair_arenas(m);                       // a game's two arenas, a fixed stride apart
     if (rc != GMK_OK) return rc;
+    rc = gmk_mcts_set_roots(m, planes.data(), last.data(), first_game_id);
+    if (rc != GMK_OK) return rc;
+    if (noisy && !m->d_root_prior) GMK_HIP_CHECK(gmk::device_malloc(&m->d_root_prior, static_cast<size_t>(n_slots) * 225 * sizeof(float)));
     if (!m->d_slot_state) GMK_HIP_CHECK(gmk::device_malloc(&m->d_slot_state, (static_cast<size_t>(n_slots) + 1) * 4));
     (void)gmk::device_free(m->d_open_moves); (void)gmk::device_free(m->d_open_lens);
     m->d_open_moves = nullptr; m->d_open_lens = nullptr;
@@ -958,18 +1104,15 @@ extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id
     GMK_HIP_CHECK(gmk::device_malloc(&d_unfinished, 4));
     int32_t steps = 0;
     rc = GMK_OK;
-    // Without kept subtrees and root noise the whole run is ONE launch (SearchParams::persistent): every wavefront plays its slots' games
-    // turn by turn at its own pace; the records are the same bytes either way (a game's random streams are keyed by its global id).
-    const bool persistent = !reuse_subtree && !(noise_alpha > 0.0f);
     if (persistent) {
-        m->persistent_rec = {d_moves, d_visits, d_lens, d_winner, d_unfinished};
+        m->persistent_rec = {d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree ? 1 : 0, noisy ? noise_alpha : 0.0f, noise_epsilon};
         rc = gmk_mcts_run(m, playouts, s);
         m->persistent_rec = {};
         if (rc == GMK_OK && hipStreamSynchronize(s) != hipSuccess) { gmk::set_error("gmk_selfplay_run: the persistent launch failed"); rc = GMK_ERR_HIP; }
         steps = 1;
     }
     for (long long step = 0; step < 226ll * (n_total / n_slots + 2) && !persistent; ++step) {
-        if (noise_alpha > 0.0f && reuse_subtree) rc = gmk_mcts_add_root_noise(m, noise_alpha, noise_epsilon, s);      // Default::AddNoise at the start of every search (MCTS.cpp:182)
+        if (noisy) rc = gmk_mcts_add_root_noise(m, noise_alpha, noise_epsilon, s);      // Default::AddNoise at the start of every search (MCTS.cpp:182)
         if (rc == GMK_OK) rc = gmk_mcts_run(m, playouts, s);
         if (rc == GMK_OK) rc = gmk_mcts_step(m, nullptr, d_moves, d_visits, d_lens, d_winner, d_unfinished, reuse_subtree, s);
         if (rc != GMK_OK) break;
@@ -1013,6 +1156,12 @@ extern "C" int gmk_mcts_add_root_noise(gmk_mcts* m, float alpha, float epsilon, 
     m->last_stream = s;
     const size_t n = static_cast<size_t>(m->n_games);
     if (!m->d_root_prior) GMK_HIP_CHECK(gmk::device_malloc(&m->d_root_prior, n * 225 * sizeof(float)));
+    if (m->noise_sampler == GMK_NOISE_SAMPLER_COUNTER) {            // drawn on the device, one wavefront per game (noise_device.h): nothing comes back to the host
+        hipLaunchKernelGGL(mcts_root_noise_kernel, dim3(m->n_games), dim3(64), 0, s, m->d_headers, m->d_link, m->d_root_prior, static_cast<size_t>(m->node_capacity), m->n_games,
+                           alpha, epsilon, static_cast<uint32_t>(m->seed), static_cast<uint32_t>(m->seed >> 32));
+        GMK_HIP_CHECK(hipGetLastError());
+        return GMK_OK;
+    }
     hipLaunchKernelGGL(mcts_root_flags_kernel, dim3((m->n_games + 255) / 256), dim3(256), 0, s, m->d_headers, m->d_link,
                        static_cast<size_t>(m->node_capacity), m->n_games);
     GMK_HIP_CHECK(hipGetLastError());
@@ -1062,7 +1211,7 @@ extern "C" int gmk_mcts_root_stats(gmk_mcts* m, uint32_t* h_visits, float* h_roo
     GMK_TRY(gmk::device_malloc(&d_q, n * 4));
     GMK_TRY(gmk::device_malloc(&d_status, n * 4));
     hipLaunchKernelGGL(mcts_root_stats_kernel, dim3(m->n_games), dim3(64), 0, m->last_stream, m->d_headers, m->d_stats, m->d_link,
-                       static_cast<size_t>(m->node_capacity), m->n_games, d_visits, d_q, d_rv, d_nodes, d_status);
+                       static_cast<size_t>(m->node_capacity), m->arena_stride(), m->n_games, d_visits, d_q, d_rv, d_nodes, d_status);
     GMK_TRY(hipGetLastError());
     GMK_TRY(hipStreamSynchronize(m->last_stream));
     if (h_visits) GMK_TRY(hipMemcpy(h_visits, d_visits, n * 225 * 4, hipMemcpyDeviceToHost));

@@ -26,6 +26,7 @@
 #include "evalstate_device.h"
 #include "philox.h"
 #include "root_noise.h"
+#include "noise_device.h"
 #include "trad_tree.h"
 
 namespace {
@@ -72,24 +73,7 @@ struct TradParams {
     TradSelfPlay sp;
 };
 
-// lane i of a 16-lane row reads lane i + N of the same row (DPP row_shl; 0 beyond the row)
-template <int N>
-__device__ __forceinline__ float row_down(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
-}
-
-// the one summation order (oracle/go_trad.c: sum225): lane l first adds its cells l, l+64, l+128, l+192 in that order
-// (done by the caller into `p`), then a binary tree inside every row of 16 lanes (offsets 8, 4, 2, 1: four DPP adds), then
-// (row 0 + row 1) + (row 2 + row 3); every lane gets the result
-__device__ __forceinline__ float tree_sum(float p) {
-    p += row_down<8>(p);
-    p += row_down<4>(p);
-    p += row_down<2>(p);
-    p += row_down<1>(p);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), 48));
-    return (r0 + r1) + (r2 + r3);
-}
+using gmk::noise::tree_sum;                      // the one summation order of the float reductions (noise_device.h; oracle/go_trad.c: sum225)
 
 struct Cells {                                   // a per-cell float vector: lane l holds cells l + 64 j
     float v[4];
@@ -204,6 +188,43 @@ struct Game {
     unsigned long long updates;
 };
 
+// Default::AddNoise (MonteCarlo.hpp:97-108) on the root (node 0) of one game's tree by ONE wavefront, with the counter-based sampler
+// (noise_device.h): the children's priors travel through `cells` (>= 225 words of LDS) into by-cell order -- lane l mixes the cells l + 64 j --
+// and back.  A root without children takes none.  info / link: the game's arena.
+__device__ __forceinline__ void trad_root_noise(uint2* info, const uint32_t* link, uint32_t* cells, int lane, float alpha, float epsilon,
+                                                uint32_t game_id, uint32_t stones, uint32_t seed_lo, uint32_t seed_hi) {
+    const uint32_t lk = link[0], first = lk & 0xFFFFFFu, n = lk >> 24;
+    if (n == 0u) return;
+    for (int i = lane; i < kCells; i += 64) cells[i] = 0u;
+    wave_phase_fence();
+    uint2 inf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = lane + 64 * k;
+        inf[k] = i < n ? info[first + i] : make_uint2(0u, 0u);
+        if (i < n) cells[inf[k].x >> 24] = inf[k].y;
+    }
+    wave_phase_fence();
+    float p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = lane + 64 * j < kCells ? __uint_as_float(cells[lane + 64 * j]) : 0.0f;
+    gmk::noise::mix_root_priors(p, lane, alpha, epsilon, game_id, stones, seed_lo, seed_hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (lane + 64 * j < kCells) cells[lane + 64 * j] = __float_as_uint(p[j]);
+    wave_phase_fence();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = lane + 64 * k;
+        if (i < n) info[first + i] = make_uint2(inf[k].x, cells[inf[k].x >> 24]);
+    }
+}
+
+template <bool kWaveOnly> __device__ uint32_t copy_subtree(const TradArena& a, const TradArena& b, size_t base, uint32_t src_root, int lane);
+template <bool kWaveOnly> __device__ __forceinline__ void copy_sync();
+
+// kSelfPlay = false: one search per game (gmk_trad_run); true: the persistent self-play loop (gmk_trad_selfplay_run, persistent = 1).  Two
+// instantiations, so that the bare search does not carry the registers of the turn loop through its playouts.
+template <bool kSelfPlay>
 __global__ __launch_bounds__(kThreads)
 void trad_playouts_kernel(TradParams prm) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -230,11 +251,12 @@ void trad_playouts_kernel(TradParams prm) {
     g.path_spill = prm.path_spill + static_cast<size_t>(game) * kPathSpill;
     g.record_copy = reinterpret_cast<uint8_t*>(g.path_link + kLinkLds);
     const size_t arena = static_cast<size_t>(game) * prm.cap;
-    g.stat = prm.stat + arena;
-    g.info = prm.info + arena;
-    g.link = prm.link + arena;
-    g.front = prm.front + arena;
-    g.ord = prm.ord + arena;
+    uint32_t live = 0;                                          // which of the slot's two arenas holds its tree (the persistent loop with kept subtrees flips it)
+    auto use_arena = [&](uint32_t which) {
+        const size_t at = arena + ((kSelfPlay && which) ? prm.sp.arena_stride : 0);
+        g.stat = prm.stat + at; g.info = prm.info + at; g.link = prm.link + at; g.front = prm.front + at; g.ord = prm.ord + at;
+    };
+    use_arena(0);
     g.updates = 0;
     TradHeader* hdr = prm.hdr + game;
     int32_t* meta = reinterpret_cast<int32_t*>(g.c.st + oMeta);
@@ -246,7 +268,7 @@ void trad_playouts_kernel(TradParams prm) {
     // below = Policy::prepare + one search + MCTS::stepForward()'s move + the end-of-game check, a finished game's slot takes the next
     // unstarted game from a global counter (its evaluator starts from the empty board, so a game's record does not depend on the slot it
     // landed in) -- instead of every slot waiting at every move for the slowest search of the batch.  Otherwise: one turn.
-    int sp_game = prm.selfplay ? prm.sp.slot_game[game] : -1, cur_len = prm.lens[game];
+    int sp_game = kSelfPlay ? prm.sp.slot_game[game] : -1, cur_len = prm.lens[game];
     uint8_t* const slot_moves = prm.moves + static_cast<size_t>(game) * 225;
     unsigned long long playouts_run = hdr->playouts_done;
     unsigned long long prof_sel = 0, prof_sim = 0, prof_back = 0, prof_t0 = 0, prof_all = (gmk::kProfileBuild && prm.profile) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -528,7 +550,7 @@ void trad_playouts_kernel(TradParams prm) {
     wave_phase_fence();
     if (meta[3]) status |= 2u;
     playouts_run = (fresh ? 0ull : playouts_run) + static_cast<unsigned long long>(prm.playouts);
-    if (!prm.selfplay || sp_game < 0) break;
+    if (!kSelfPlay || sp_game < 0) break;
 
     // ---- the move: MCTS::stepForward()'s choice (the most visited child, first in the current order), the root's visit counts into the
     //      game's record, Board::applyMove with its victory check (Game.cpp:37-49, 88-136); as trad_advance_kernel, inside the wavefront ----
@@ -574,6 +596,22 @@ void trad_playouts_kernel(TradParams prm) {
             winner = five ? (shift ? -1 : 1) : 0;
             ++cur_len;
         }
+        bool kept = false;
+        if (!over && sp.reuse) {
+            // MCTS::stepForward (MCTS.cpp:129-134): the chosen child's subtree is the next search's tree -- compacted into the slot's other arena
+            const TradArena a{g.stat, g.info, g.link, g.front, g.ord, nullptr};
+            use_arena(live ^ 1u);
+            const TradArena b{g.stat, g.info, g.link, g.front, g.ord, nullptr};
+            n_nodes = copy_subtree<true>(a, b, 0, best_id, lane);
+            live ^= 1u;
+            root_black ^= 1;
+            kept = true;
+            if (sp.noise_alpha > 0.0f) {                        // Default::AddNoise before the next search (MCTS.cpp:182); the path buffer is idle between two searches
+                copy_sync<true>();
+                trad_root_noise(g.info, g.link, g.path_node, lane, sp.noise_alpha, sp.noise_epsilon, sp.first_game_id + static_cast<uint32_t>(sp_game),
+                                static_cast<uint32_t>(cur_len), sp.seed_lo, sp.seed_hi);
+            }
+        }
         if (over) {
             int next = 0;
             if (lane == 0) {
@@ -597,15 +635,15 @@ void trad_playouts_kernel(TradParams prm) {
         // the slot's move list is read again by the next turn's syncWithBoard, by other lanes than the one that wrote it
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        fresh_mode = 1u;
+        fresh_mode = kept ? 2u : 1u;                            // 2: the tree stays, the evaluator follows the move (gmk_trad_step's state)
     }
     }
     if (lane == 0) {
-        if (prm.selfplay) prm.lens[game] = cur_len;
+        if (kSelfPlay) prm.lens[game] = cur_len;
         hdr->n_nodes = n_nodes;
         hdr->init_acts = static_cast<uint32_t>(g.init);
         hdr->status = status;
-        hdr->fresh = prm.selfplay ? 1u : 0u;
+        hdr->fresh = kSelfPlay ? 1u : 0u;
         hdr->root_black = static_cast<uint32_t>(root_black);
         hdr->playouts_done = static_cast<uint32_t>(playouts_run);
         hdr->evaluator_updates += g.updates;
@@ -625,7 +663,21 @@ void trad_playouts_kernel(TradParams prm) {
 // scan reaches it, copies its children and rewrites both.  One wavefront per game.
 
 // The subtree of node src_root of arena a becomes the tree of arena b, level by level (see above); one wavefront.
-__device__ void copy_subtree(const TradArena& a, const TradArena& b, size_t base, uint32_t src_root, int lane, TradHeader& hdr) {
+// kWaveOnly: the caller is one wavefront of a larger workgroup (the persistent self-play loop of trad_playouts_kernel): its lanes meet at a
+// wavefront barrier with workgroup-scope fences (the CU's L1 is shared by the workgroup) instead of __syncthreads().  Returns the node count.
+template <bool kWaveOnly>
+__device__ __forceinline__ void copy_sync() {
+    if constexpr (kWaveOnly) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <bool kWaveOnly>
+__device__ uint32_t copy_subtree(const TradArena& a, const TradArena& b, size_t base, uint32_t src_root, int lane) {
     if (lane == 0) {
         b.stat[base] = a.stat[base + src_root];
         b.info[base] = make_uint2(kNoParent | (a.info[base + src_root].x & 0xFF000000u), a.info[base + src_root].y);
@@ -634,7 +686,7 @@ __device__ void copy_subtree(const TradArena& a, const TradArena& b, size_t base
         b.ord[base] = 0;
         if (a.amaf) b.amaf[base] = a.amaf[base + src_root];
     }
-    __syncthreads();
+    copy_sync<kWaveOnly>();
     uint32_t next = 1;
     for (uint32_t i0 = 0, chunk = 0; i0 < next; i0 += chunk) {
         chunk = min(64u, next - i0);                            // nodes appended while this chunk is handled come after it
@@ -665,11 +717,11 @@ __device__ void copy_subtree(const TradArena& a, const TradArena& b, size_t base
                 }
             }
             next += nk;
-            __syncthreads();
+            copy_sync<kWaveOnly>();
         }
-        __syncthreads();                                        // children written above are scanned below
+        copy_sync<kWaveOnly>();                                        // children written above are scanned below
     }
-    if (lane == 0) hdr.n_nodes = next;
+    return next;
 }
 
 
@@ -732,7 +784,8 @@ void trad_step_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, int n
         }
         return;
     }
-    copy_subtree(a, b, base, src_root, lane, hdr);
+    const uint32_t kept = copy_subtree<false>(a, b, base, src_root, lane);
+    if (lane == 0) hdr.n_nodes = kept;
 }
 
 // The step of the device-resident self-play loop (gmk_trad_selfplay_run): what play_supervisor_games does on the host after every search --
@@ -797,7 +850,10 @@ void trad_advance_kernel(TradArena a, TradArena b, TradHeader* hdrs, int cap, in
                 if (!reuse) { hdr.fresh = 1; hdr.playouts_done = 0; }          // a new root at the next search (gmk_trad_set_positions)
                 else { hdr.fresh = 2; hdr.root_black ^= 1u; }                  // the subtree is kept (gmk_trad_step)
             }
-            if (reuse) copy_subtree(a, b, base, best_id, lane, hdr);
+            if (reuse) {
+                const uint32_t kept = copy_subtree<false>(a, b, base, best_id, lane);
+                if (lane == 0) hdr.n_nodes = kept;
+            }
             return;
         }
     }
@@ -855,6 +911,17 @@ void trad_set_root_priors_kernel(TradArena a, const TradHeader* hdrs, int cap, c
     }
 }
 
+// Default::AddNoise with the counter-based sampler, one wavefront per game (the lock-step form of what the persistent loop does inside its launch)
+__global__ __launch_bounds__(64)
+void trad_root_noise_kernel(TradArena a, const TradHeader* hdrs, int cap, const int32_t* lens, const uint32_t* game_ids, uint32_t first_game_id,
+                            float alpha, float epsilon, uint32_t seed_lo, uint32_t seed_hi) {
+    __shared__ uint32_t s_cells[kCells];
+    const int game = blockIdx.x, lane = threadIdx.x;
+    if (hdrs[game].fresh == 1u || (hdrs[game].status & kStatusIdleSlot)) return;       // no root node yet / no game: nothing to mix noise into
+    const size_t base = static_cast<size_t>(game) * cap;
+    trad_root_noise(a.info + base, a.link + base, s_cells, lane, alpha, epsilon, first_game_id + game_ids[game], static_cast<uint32_t>(lens[game]), seed_lo, seed_hi);
+}
+
 // root statistics by cell and the child MCTS::stepForward would pick (most visited, first in the CURRENT order)
 __global__ __launch_bounds__(64)
 void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t* link, const uint8_t* ord, const TradHeader* hdrs, int cap,
@@ -888,6 +955,10 @@ void trad_root_stats_kernel(const uint2* stat, const uint2* info, const uint32_t
 
 extern "C" int gmk_trad_destroy(gmk_trad* t) {
     if (!t) return GMK_OK;
+    if (t->paired) {                                            // both arenas are halves of the five blocks
+        (void)gmk::device_free(t->block_stat); (void)gmk::device_free(t->block_info); (void)gmk::device_free(t->block_link); (void)gmk::device_free(t->block_front); (void)gmk::device_free(t->block_ord);
+        t->d_stat = t->d_stat2 = t->d_info = t->d_info2 = t->d_front = t->d_front2 = nullptr; t->d_link = t->d_link2 = nullptr; t->d_ord = t->d_ord2 = nullptr;
+    }
     (void)gmk::device_free(t->d_states); (void)gmk::device_free(t->d_stat); (void)gmk::device_free(t->d_info); (void)gmk::device_free(t->d_link);
     (void)gmk::device_free(t->d_front); (void)gmk::device_free(t->d_ord); (void)gmk::device_free(t->d_stat2); (void)gmk::device_free(t->d_info2); (void)gmk::device_free(t->d_front2);
     (void)gmk::device_free(t->d_link2); (void)gmk::device_free(t->d_ord2); (void)gmk::device_free(t->d_amaf); (void)gmk::device_free(t->d_amaf2); (void)gmk::device_free(t->d_forced); (void)gmk::device_free(t->d_priors); (void)gmk::device_free(t->d_hdr); (void)gmk::device_free(t->d_moves); (void)gmk::device_free(t->d_lens); (void)gmk::device_free(t->d_game_ids); (void)gmk::device_free(t->d_path_spill);
@@ -927,6 +998,52 @@ extern "C" int gmk_trad_create(int n_games, int node_capacity, gmk_trad** out) {
     }
     if (!ok || gmk_trad_reset_evaluators(t) != GMK_OK) { gmk_trad_destroy(t); gmk::set_error("gmk_trad_create: device allocation failed"); return GMK_ERR_HIP; }
     *out = t;
+    return GMK_OK;
+}
+
+extern "C" int gmk_trad_set_option(gmk_trad* t, int option, int value) {
+    if (!t) { gmk::set_error("gmk_trad_set_option: bad arguments"); return GMK_ERR_ARG; }
+    if (option == GMK_OPT_NOISE_SAMPLER && (value == GMK_NOISE_SAMPLER_STD || value == GMK_NOISE_SAMPLER_COUNTER)) { t->noise_sampler = value; return GMK_OK; }
+    if (option == GMK_OPT_LOCKSTEP && (value == 0 || value == 1)) { t->lockstep = value; return GMK_OK; }
+    gmk::set_error("gmk_trad_set_option: unknown option %d or value %d", option, value);
+    return GMK_ERR_ARG;
+}
+
+// Both arenas of every slot as the two halves of ONE block per array (the persistent loop with kept subtrees reaches a slot's other arena by a
+// fixed node stride).  The trees are lost (the evaluators are not): the caller positions the games afterwards.
+static int pair_arenas(gmk_trad* t) {
+    const size_t nodes = static_cast<size_t>(t->n_games) * static_cast<size_t>(t->cap);
+    auto point = [&]() {
+        t->d_stat = t->block_stat; t->d_info = t->block_info; t->d_link = t->block_link; t->d_front = t->block_front; t->d_ord = t->block_ord;
+        t->d_stat2 = t->block_stat + nodes; t->d_info2 = t->block_info + nodes; t->d_link2 = t->block_link + nodes; t->d_front2 = t->block_front + nodes; t->d_ord2 = t->block_ord + nodes;
+    };
+    if (t->paired) { point(); return GMK_OK; }                  // (the lock-step loop may have left the halves swapped)
+    if (t->d_amaf) { gmk::set_error("gmk_trad_selfplay_run: the persistent loop keeps subtrees for TraditionalPolicy handles only"); return GMK_ERR_STATE; }
+    uint2 *bs = nullptr, *bi = nullptr, *bf = nullptr;
+    uint32_t* bl = nullptr;
+    uint8_t* bo = nullptr;
+    (void)gmk::device_free(t->d_stat); (void)gmk::device_free(t->d_info); (void)gmk::device_free(t->d_link); (void)gmk::device_free(t->d_front); (void)gmk::device_free(t->d_ord);
+    (void)gmk::device_free(t->d_stat2); (void)gmk::device_free(t->d_info2); (void)gmk::device_free(t->d_link2); (void)gmk::device_free(t->d_front2); (void)gmk::device_free(t->d_ord2);
+    t->d_stat = t->d_stat2 = t->d_info = t->d_info2 = t->d_front = t->d_front2 = nullptr; t->d_link = t->d_link2 = nullptr; t->d_ord = t->d_ord2 = nullptr;
+    t->second_arena = false;
+    t->positioned = false;
+    const bool ok = gmk::device_malloc(&bs, 2 * nodes * 8) == hipSuccess && gmk::device_malloc(&bi, 2 * nodes * 8) == hipSuccess && gmk::device_malloc(&bl, 2 * nodes * 4) == hipSuccess &&
+                    gmk::device_malloc(&bf, 2 * nodes * 8) == hipSuccess && gmk::device_malloc(&bo, 2 * nodes) == hipSuccess;
+    if (!ok) {
+        (void)gmk::device_free(bs); (void)gmk::device_free(bi); (void)gmk::device_free(bl); (void)gmk::device_free(bf); (void)gmk::device_free(bo);
+        (void)hipGetLastError();
+        // the handle must stay usable: one arena, as gmk_trad_create leaves it
+        if (gmk::device_malloc(&t->d_stat, nodes * 8) != hipSuccess || gmk::device_malloc(&t->d_info, nodes * 8) != hipSuccess || gmk::device_malloc(&t->d_link, nodes * 4) != hipSuccess ||
+            gmk::device_malloc(&t->d_front, nodes * 8) != hipSuccess || gmk::device_malloc(&t->d_ord, nodes) != hipSuccess)
+            (void)hipGetLastError();
+        gmk::set_error("gmk_trad_selfplay_run: hipMalloc of two arenas per slot (%zu nodes, %.1f GB) failed", 2 * nodes, 2 * nodes * 29.0 / 1e9);
+        return GMK_ERR_HIP;
+    }
+    t->block_stat = bs; t->block_info = bi; t->block_link = bl; t->block_front = bf; t->block_ord = bo;
+    t->paired = true;
+    t->second_arena = true;
+    if (!t->d_forced && gmk::device_malloc(&t->d_forced, static_cast<size_t>(t->n_games) * 2) != hipSuccess) { (void)hipGetLastError(); gmk::set_error("gmk_trad_selfplay_run: hipMalloc failed"); return GMK_ERR_HIP; }
+    point();
     return GMK_OK;
 }
 
@@ -982,7 +1099,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4 + gmk::kPrefixWords) * 4;
     if (lds > 160u * 1024u) { gmk::set_error("gmk_trad_run: tables do not fit in LDS (%zu bytes)", lds); return GMK_ERR_CAPACITY; }
     if (!t->attr_set) {
-        GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         t->attr_set = true;
     }
     TradParams prm;
@@ -994,7 +1111,7 @@ extern "C" int gmk_trad_run(gmk_trad* t, int playouts, double c_puct, void* stre
     static const bool profile = gmk::profile_env("GMK_TRAD_PROFILE") != nullptr;
     prm.profile = profile ? 1 : 0;
     const int grid = (t->n_games + kGamesPerBlock - 1) / kGamesPerBlock;
-    hipLaunchKernelGGL(trad_playouts_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), prm);
+    hipLaunchKernelGGL(trad_playouts_kernel<false>, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), prm);
     GMK_HIP_CHECK(hipGetLastError());
     if (profile) {                                              // share of a search spent per stage, mean over games
         std::vector<TradHeader> hdr(static_cast<size_t>(t->n_games));
@@ -1047,6 +1164,14 @@ extern "C" int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, 
     if (!t || !(alpha > 0.0f)) { gmk::set_error("gmk_trad_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
     if (!t->positioned) { gmk::set_error("gmk_trad_add_root_noise: gmk_trad_set_positions has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(t->n_games);
+    if (t->noise_sampler == GMK_NOISE_SAMPLER_COUNTER) {        // drawn on the device, one wavefront per game: nothing comes back to the host
+        GMK_HIP_CHECK(hipMemcpy(t->d_game_ids, t->game_ids.data(), n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(trad_root_noise_kernel, dim3(t->n_games), dim3(64), 0, nullptr, t->arena(), t->d_hdr, t->cap, t->d_lens, t->d_game_ids, first_game_id,
+                           alpha, epsilon, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+        GMK_HIP_CHECK(hipGetLastError());
+        GMK_HIP_CHECK(hipDeviceSynchronize());
+        return GMK_OK;
+    }
     std::vector<float> priors(n * 225);
     std::vector<int32_t> lens(n);
     int rc = gmk_trad_root_stats(t, nullptr, nullptr, priors.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -1129,8 +1254,10 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
                                      int reuse_subtree, float noise_alpha, float noise_epsilon,
                                      const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens,
                                      uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int persistent, int max_steps, int32_t* h_overflow, int32_t* h_steps, void* stream) {
-    if (persistent && (poolrave || reuse_subtree || noise_alpha > 0.0f || max_steps > 0)) {
-        gmk::set_error("gmk_trad_selfplay_run: the persistent loop plays TraditionalPolicy games from a new root every move, without root noise, to their end");
+    const bool noisy = noise_alpha > 0.0f && reuse_subtree;     // (a new root has no children: AddNoise is a no-op without kept subtrees)
+    if (t && t->lockstep) persistent = 0;
+    if (persistent && (poolrave || max_steps > 0 || (noisy && t && t->noise_sampler != GMK_NOISE_SAMPLER_COUNTER))) {
+        gmk::set_error("gmk_trad_selfplay_run: the persistent loop plays TraditionalPolicy games to their end; root noise inside it comes from the counter-based sampler (GMK_OPT_NOISE_SAMPLER)");
         return GMK_ERR_ARG;
     }
     if (!t || n_total <= 0 || playouts < 0 || max_steps < 0 || !d_moves || !d_lens || !d_winner || (h_open_moves && (!h_open_lens || open_stride <= 0))) {
@@ -1163,8 +1290,10 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
     state[ns] = started;                                        // next_game
     state[ns + 1] = 0;                                          // unfinished
     state[ns + 2] = 0;                                          // overflow
-    int rc = gmk_trad_set_game_ids(t, ids.data());
-    if (rc == GMK_OK) rc = gmk_trad_set_positions(t, slot_moves.data(), slot_lens.data());
+    int rc = GMK_OK;
+    if (persistent && reuse_subtree) rc = pair_arenas(t);       // a slot's two arenas, a fixed stride apart
+    if (rc == GMK_OK) rc = gmk_trad_set_game_ids(t, ids.data());
+    if (rc == GMK_OK) { t->positioned = true; rc = gmk_trad_set_positions(t, slot_moves.data(), slot_lens.data()); }     // (every slot is positioned anew)
     if (rc != GMK_OK) return rc;
     if (n_slots > n_total) {                                    // slots without a game: idle from the start
         std::vector<TradHeader> hdr(ns);
@@ -1208,6 +1337,9 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
     sp.n_total = n_total; sp.open_moves = d_open_moves; sp.open_lens = d_open_lens; sp.open_stride = open_stride;
     sp.game_ids = t->d_game_ids;
     sp.rec_moves = d_moves; sp.rec_lens = d_lens; sp.rec_visits = d_visits; sp.rec_winner = d_winner;
+    sp.reuse = (persistent && reuse_subtree) ? 1 : 0; sp.noise_alpha = (persistent && noisy) ? noise_alpha : 0.0f; sp.noise_epsilon = noise_epsilon;
+    sp.arena_stride = (persistent && reuse_subtree) ? t->arena_stride() : 0;
+    sp.seed_lo = static_cast<uint32_t>(seed); sp.seed_hi = static_cast<uint32_t>(seed >> 32); sp.first_game_id = first_game_id;
     int32_t steps = 0;
     if (persistent) {
         // ONE launch: every wavefront plays game after game at its own pace (trad_playouts_kernel, prm.selfplay)
@@ -1215,9 +1347,9 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
         if (t->policy == 2) { gmk::set_error("gmk_trad_selfplay_run: this handle searches with PoolRAVEPolicy"); cleanup(); return GMK_ERR_STATE; }
         t->policy = 1;
         const size_t lds = static_cast<size_t>(kGamesPerBlock * kPerGame + st.n_states * 4 + st.n_records * 4 + gmk::kPrefixWords) * 4;
-        if (!t->attr_set) {
-            GMK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            t->attr_set = true;
+        if (!t->attr_set_selfplay) {
+            GMK_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(trad_playouts_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            t->attr_set_selfplay = true;
         }
         TradParams prm;
         prm.states = t->d_states; prm.stat = t->d_stat; prm.info = t->d_info; prm.link = t->d_link; prm.front = t->d_front; prm.ord = t->d_ord; prm.hdr = t->d_hdr;
@@ -1225,7 +1357,7 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
         prm.g_trans = st.d_trans; prm.g_records = st.d_records; prm.trans_words = st.n_states * 4; prm.record_words = st.n_records * 4 + gmk::kPrefixWords; prm.path_spill = t->d_path_spill;
         prm.n_games = n_slots; prm.cap = t->cap; prm.playouts = playouts; prm.c_puct = c_puct;
         prm.profile = 0; prm.selfplay = 1; prm.sp = sp;
-        hipLaunchKernelGGL(trad_playouts_kernel, dim3((n_slots + kGamesPerBlock - 1) / kGamesPerBlock), dim3(kThreads), lds, s, prm);
+        hipLaunchKernelGGL(trad_playouts_kernel<true>, dim3((n_slots + kGamesPerBlock - 1) / kGamesPerBlock), dim3(kThreads), lds, s, prm);
         GMK_TRY(hipGetLastError());
         GMK_TRY(hipStreamSynchronize(s));
         steps = 1;
@@ -1233,7 +1365,11 @@ extern "C" int gmk_trad_selfplay_run(gmk_trad* t, int poolrave, int n_total, uin
     std::vector<int32_t> slot_game(ns);
     const long long step_limit = max_steps > 0 ? max_steps : 226ll * (n_total / n_slots + 2);
     for (long long step = 0; step < step_limit && !persistent; ++step) {
-        if (noise_alpha > 0.0f) {                               // Default::AddNoise at the start of every search (MCTS.cpp:182), keyed by the GAME a slot plays
+        if (noise_alpha > 0.0f && t->noise_sampler == GMK_NOISE_SAMPLER_COUNTER) {     // ... drawn on the device, keyed by the game a slot plays (d_game_ids: the refill kernel keeps it)
+            hipLaunchKernelGGL(trad_root_noise_kernel, dim3(n_slots), dim3(64), 0, s, t->arena(), t->d_hdr, t->cap, t->d_lens, t->d_game_ids, first_game_id,
+                               noise_alpha, noise_epsilon, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+            GMK_TRY(hipGetLastError());
+        } else if (noise_alpha > 0.0f) {                        // Default::AddNoise at the start of every search (MCTS.cpp:182), keyed by the GAME a slot plays
             GMK_TRY(hipMemcpy(slot_game.data(), d_state, ns * 4, hipMemcpyDeviceToHost));
             for (size_t g = 0; g < ns; ++g) t->game_ids[g] = slot_game[g] >= 0 ? static_cast<uint32_t>(slot_game[g]) : 0u;
             rc = gmk_trad_add_root_noise(t, noise_alpha, noise_epsilon, seed, first_game_id);

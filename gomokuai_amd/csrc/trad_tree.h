@@ -50,6 +50,13 @@ struct TradSelfPlay {
     int8_t* rec_winner;                          // [n_total]
     int32_t* unfinished;                         // slots that still have a game after this step
     int32_t* overflow;                           // set when a search stopped at its node capacity
+    // the persistent loop with the reference agent's per-move semantics (MCTS.cpp:129-147, 179-183): the chosen child's subtree is kept -- compacted
+    // into the slot's OTHER arena, arena_stride nodes further on, inside the launch -- and Default::AddNoise runs before every search, drawn by the
+    // wavefront itself from the counter-based sampler (include/gomoku_noise.h), keyed by (seed; first_game_id + game, stones, cell)
+    int reuse;
+    float noise_alpha, noise_epsilon;            // alpha == 0: no noise
+    size_t arena_stride;                         // nodes between a slot's two arenas (0: one arena)
+    uint32_t seed_lo, seed_hi, first_game_id;
 };
 
 // ---- wave-wide reductions without LDS round trips ----
@@ -102,7 +109,16 @@ struct gmk_trad {
     std::vector<uint32_t> game_ids;                                         // the game a slot is playing, relative to the callers' first_game_id (default: the slot number)
     uint32_t* d_game_ids = nullptr;
     uint32_t* d_path_spill = nullptr;            // [n_games][kPathSpill] K6: the child ranges of path levels the LDS copy has no room for
-    bool attr_set = false, positioned = false, second_arena = false;
+    bool attr_set = false, attr_set_selfplay = false, positioned = false, second_arena = false;
+    // gmk_trad_set_option
+    int noise_sampler = 0;                       // GMK_NOISE_SAMPLER_STD: where Default::AddNoise draws from
+    int lockstep = 0;
+    // the persistent loop with kept subtrees wants a slot's two arenas a fixed distance apart: both halves of ONE allocation per array
+    bool paired = false;
+    uint2 *block_stat = nullptr, *block_info = nullptr, *block_front = nullptr;
+    uint32_t* block_link = nullptr;
+    uint8_t* block_ord = nullptr;
+    size_t arena_stride() const { return (paired && d_stat2 > d_stat) ? static_cast<size_t>(d_stat2 - d_stat) : 0; }
     int policy = 0;                                                          // 0 not searched yet, 1 TraditionalPolicy (gmk_trad_run), 2 PoolRAVEPolicy (gmk_trad_run_poolrave): one per handle
 
     gmk::tree::TradArena arena() const { return {d_stat, d_info, d_link, d_front, d_ord, d_amaf}; }

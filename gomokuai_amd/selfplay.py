@@ -84,17 +84,22 @@ class GameRecords:
 # two handles x 8 192 slots 80, x 10 240 78, x 16 384 77; three x 6 144 79; four x 4 096 61.  4 096 games: one handle 29, two 28.
 SLOTS_PER_GPU = 16384
 HANDLES_FROM_GAMES = 8192
+# With kept subtrees a slot owns TWO arenas of three times the nodes (the kept subtree + the new search; 17 MB per slot at 800 playouts per move):
+# 8 192 slots are 142 GB of the 288, and they are ONE handle -- its persistent launch (four games per wavefront, two wavefronts per SIMD) fills the
+# chip by itself and stays resident until its games have run out, so a second handle's launch would only queue behind it.
+SLOTS_PER_GPU_KEPT = 8192
 
 
-def plan_games(n_games, slots="auto", handles="auto", opening_plies=0):
+def plan_games(n_games, slots="auto", handles="auto", opening_plies=0, reuse_subtree=False):
     """How play_games spreads n_games over search handles and slots: a list of (first game, one past the last game, slots) per handle,
     or None for the plain lock-step loop (one handle, every game in flight from the start).  Pure bookkeeping, no GPU."""
     if n_games <= 0:
         raise ValueError("play_games: n_games must be positive")
     if handles == "auto":
-        handles = 2 if n_games >= HANDLES_FROM_GAMES and opening_plies <= 8 else 1
+        handles = 2 if n_games >= HANDLES_FROM_GAMES and opening_plies <= 8 and not reuse_subtree else 1
     if slots == "auto":
-        slots = SLOTS_PER_GPU if n_games > SLOTS_PER_GPU and opening_plies <= 8 else None
+        per_gpu = SLOTS_PER_GPU_KEPT if reuse_subtree else SLOTS_PER_GPU
+        slots = per_gpu if n_games > per_gpu and opening_plies <= 8 else None
     handles = max(1, min(int(handles), n_games))
     if not ((slots is not None and slots < n_games) or handles > 1):
         return None
@@ -107,7 +112,7 @@ def plan_games(n_games, slots="auto", handles="auto", opening_plies=0):
 
 def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5.0, c_rollouts=5,
                opening_plies=0, record_visits=True, reuse_subtree=False, root_noise=None, max_moves=N, device=None,
-               node_capacity=None, slots="auto", handles="auto"):
+               node_capacity=None, slots="auto", handles="auto", noise_sampler="counter", lockstep=False):
     """Plays n_games complete games on the current GPU: every move = one K3 search of `playouts` playouts for all
     unfinished games, then `gmk_mcts_advance`.  Game g uses the global id first_game_id + g for its RNG streams, so
     the records do not depend on how games are spread over GPUs, slots or handles.
@@ -115,12 +120,19 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     the next unstarted game inside the step kernel, so the searches stay full instead of waiting for the longest game of the batch.
     "auto" = SLOTS_PER_GPU when there are more games than that, else all games at once; None = all games at once.
     handles: the games are split into that many contiguous blocks, each with its own search handle, HIP stream and host thread
-    (the slots are shared out between them); "auto" = 2 from HANDLES_FROM_GAMES games on, else 1."""
+    (the slots are shared out between them); "auto" = 2 from HANDLES_FROM_GAMES games on, else 1.
+    reuse_subtree + root_noise=(alpha, epsilon) are the reference agent's per-move semantics (agents/mcts.py:17-21: the chosen child's subtree is
+    the next search's tree, MCTS.cpp:129-147, and Default::AddNoise runs before every search, MCTS.cpp:182).  noise_sampler: "counter" = the
+    counter-based Dirichlet sampler of include/gomoku_noise.h, drawn inside the searching kernel, so that the whole run is ONE persistent launch
+    (slots / handles != None); "std" = std::gamma_distribution on the host, which needs a launch boundary per move (lock step).  lockstep=True
+    forces the search-by-search loop (the form the tests hold the persistent one to)."""
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
     # (the device-resident loop plays whole games: a cap on the moves per game takes the lock-step path below, which honours it)
-    plan = plan_games(n_games, slots, handles, opening_plies) if max_moves >= N else None
+    plan = plan_games(n_games, slots, handles, opening_plies, reuse_subtree) if max_moves >= N else None
+    if plan is None and max_moves >= N and opening_plies <= 8 and not lockstep:
+        plan = [(0, n_games, n_games)]                  # all games at once, the loop on the device all the same (gmk_selfplay_run: ONE launch where it can)
     if plan is not None:
         handles = len(plan)
         open_moves = open_lens = None
@@ -135,6 +147,9 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
         noise = root_noise if reuse_subtree else None
         blocks = [(lo, hi) for lo, hi, _ in plan]
         trees = [G.BatchedMCTS(n_slots, c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap) for _, _, n_slots in plan]
+        for tree in trees:
+            tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS[noise_sampler])
+            tree.set_option(G.OPT_LOCKSTEP, int(bool(lockstep)))
 
         def run_block(i, hip_stream):
             lo, hi = blocks[i]
@@ -183,6 +198,7 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
             last[g] = m[g, lens0[g] - 1] if lens0[g] > 0 else -1
     cap = node_capacity if node_capacity is not None else playouts * N * (3 if reuse_subtree else 1) + 1
     tree = G.BatchedMCTS(n_games, c_puct=c_puct, c_rollouts=c_rollouts, seed=seed, node_capacity=cap)
+    tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS[noise_sampler])
     tree.set_roots(planes, last, first_game_id)
     d_moves = torch.from_numpy(moves0).to(dev)
     d_lens = torch.from_numpy(lens0).to(dev)
@@ -259,7 +275,7 @@ class _HostGames:
 
 
 def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps=0,
-                               persistent=False):
+                               persistent=False, noise_sampler="std"):
     """play_supervisor_games with the loop resident on the device (gmk_trad_selfplay_run): the searches, MCTS::stepForward's move, the
     end-of-game check and the hand-over of a finished game's slot are kernels; the host reads four bytes per move.  Same games, same
     records as the host-driven loops below (tests/test_selfplay_gpu.py holds them to each other)."""
@@ -277,6 +293,7 @@ def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_g
         tree = G.TraditionalMCTS(n_slots, node_capacity=cap, c_puct=c_puct)
     else:
         raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
+    tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS[noise_sampler])
     d_moves = torch.zeros((n_games, N), dtype=torch.uint8, device=dev)
     d_lens = torch.zeros(n_games, dtype=torch.int32, device=dev)
     d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
@@ -291,7 +308,8 @@ def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_g
 
 
 def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional", slots=None, device_loop=True, max_steps=0):
+                          device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional", slots=None, device_loop=True, max_steps=0,
+                          noise_sampler="counter"):
     """n_games complete games of the reference's self-play SUPERVISOR against itself (config.py:9-12: "traditional_mcts",
     MCTS(TraditionalPolicy) on both sides), all games side by side on the current GPU: every move = one K6 search of
     `playouts` playouts per unfinished game (the games' evaluators are kept and synchronised like the policy objects of
@@ -306,25 +324,32 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
     device_loop (default): the loop runs on the device (gmk_trad_selfplay_run; whole games only, so a max_moves cap takes the host loop);
     device_loop=False: the host drives it ply by ply with numpy boards (root_stats down, positions up every ply) -- the same games.
     max_steps > 0 (device loop only): stop after that many moves per slot, whatever is unfinished (throughput measurements with every slot busy).
+    noise_sampler: "counter" (default) = the counter-based Dirichlet sampler of include/gomoku_noise.h, drawn on the device -- inside the ONE launch of the
+    persistent loop, so that the reference agent's semantics (reuse_subtree + root_noise) run at the pace of the plain loop; "std" = std::gamma_distribution
+    over std::mt19937 on the host (lock step).  PoolRAVE games draw "std" whatever is asked (their loop is lock step anyway).
     Returns the same GameRecords as play_games (moves, per-move root visit counts, winner), so to_samples() / gather_records() apply."""
     if policy not in ("traditional", "poolrave"):
         raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
     if device_loop and max_moves >= N:
         n_slots = n_games if slots is None else max(1, min(int(slots), n_games))
-        # "persistent": one launch, every slot plays game after game at its own pace (TraditionalPolicy, new root every move, no noise, whole
-        # games); each game on a fresh evaluator, so the records equal the all-at-once loop's whatever the slots.  Chosen by itself when games
-        # outnumber slots and the configuration allows it; device_loop="lockstep" keeps the search-by-search loop (a slot's evaluator carries over).
-        can_persist = policy == "traditional" and not reuse_subtree and root_noise is None and not max_steps
+        # "persistent": one launch, every slot plays game after game at its own pace (TraditionalPolicy, whole games; kept subtrees are compacted
+        # inside the launch, root noise comes from the counter-based sampler); each game on a fresh evaluator, so the records equal the all-at-once
+        # loop's whatever the slots.  Chosen by itself when games outnumber slots or the reference agent's semantics are asked for and the
+        # configuration allows it; device_loop="lockstep" keeps the search-by-search loop (a slot's evaluator carries over).
+        if policy == "poolrave":
+            noise_sampler = "std"
+        noisy = root_noise is not None and reuse_subtree
+        can_persist = policy == "traditional" and not max_steps and not (noisy and noise_sampler != "counter")
         if device_loop == "persistent" and not can_persist:
-            raise ValueError("play_supervisor_games: the persistent loop plays TraditionalPolicy games from a new root every move, without root noise, to their end")
-        persistent = can_persist and (device_loop == "persistent" or (device_loop is True and n_slots < n_games))
+            raise ValueError("play_supervisor_games: the persistent loop plays TraditionalPolicy games to their end, with root noise from the counter-based sampler only")
+        persistent = can_persist and (device_loop == "persistent" or (device_loop is True and (n_slots < n_games or reuse_subtree)))
         return _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id,
-                                          opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps, persistent)
+                                          opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps, persistent, noise_sampler)
     if max_steps:
         raise ValueError("play_supervisor_games: max_steps is a switch of the device-resident loop")
     if slots is not None and slots < n_games:
         return _play_supervisor_slots(n_games, int(slots), playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy,
-                                      reuse_subtree, root_noise)
+                                      reuse_subtree, root_noise, noise_sampler)
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -340,6 +365,7 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
         tree = G.TraditionalMCTS(n_games, node_capacity=cap, c_puct=c_puct)
     else:
         raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
+    tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS["std" if policy == "poolrave" else noise_sampler])
     overflow = False
     for ply in range(max_moves):
         if games.over.all():
@@ -364,7 +390,7 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
 
 
 def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy,
-                           reuse_subtree=False, root_noise=None):
+                           reuse_subtree=False, root_noise=None, noise_sampler="std"):
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -380,6 +406,7 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
         tree = G.TraditionalMCTS(slots, node_capacity=cap, c_puct=c_puct)
     else:
         raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
+    tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS["std" if policy == "poolrave" else noise_sampler])
     active = np.arange(slots)                                    # the game in each slot
     next_game = slots
     overflow = False

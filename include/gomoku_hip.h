@@ -166,7 +166,10 @@ int gmk_mcts_advance(gmk_mcts *m, uint8_t *d_moves, uint16_t *d_visits, int32_t 
  * h_open_moves uint8[n_total][open_stride] / h_open_lens int32[n_total]: opening moves per game, black first, 0 .. 8 of them (NULL: empty boards).
  * Device outputs, indexed by GAME: d_moves uint8[n_total][225] (openings included), d_visits uint16[n_total][225][225] or NULL,
  * d_lens int32[n_total], d_winner int8[n_total].  noise_alpha > 0 with reuse_subtree applies Default::AddNoise before every search.
- * Synchronous; *h_steps (optional) = search launches it took (each one move for every busy slot). */
+ * ONE persistent launch plays all games (every wavefront searches and steps its slots' games turn by turn at its own pace; with
+ * reuse_subtree the chosen child's subtree is compacted into the game's second arena inside the launch) unless the noise has to be drawn
+ * on the host (GMK_NOISE_SAMPLER_STD with noise_alpha > 0) or GMK_OPT_LOCKSTEP is set; the records are the same bytes either way.
+ * Synchronous; *h_steps (optional) = search launches it took (lock step: each one move for every busy slot; persistent: 1). */
 int gmk_selfplay_run(gmk_mcts *m, int n_total, uint32_t first_game_id, int playouts, int reuse_subtree, float noise_alpha, float noise_epsilon,
                      const uint8_t *h_open_moves, int open_stride, const int32_t *h_open_lens,
                      uint8_t *d_moves, uint16_t *d_visits, int32_t *d_lens, int8_t *d_winner, int32_t *h_steps, void *stream);
@@ -183,6 +186,19 @@ int gmk_mcts_step_host(gmk_mcts* m, const int16_t* h_moves, int reuse_subtree);
  * (MCTS.cpp:182) with alpha 0.05, epsilon 0.25.  No-op for childless (fresh) roots.  The priors stay in force until the
  * next gmk_mcts_advance / gmk_mcts_set_roots.  Synchronises `stream`. */
 int gmk_mcts_add_root_noise(gmk_mcts *m, float alpha, float epsilon, void *stream);
+/* Handle options (K3 gmk_mcts_set_option, K6 / K8 gmk_trad_set_option).
+ * GMK_OPT_NOISE_SAMPLER: where Default::AddNoise draws its gamma variates from (the reference: std::gamma_distribution<float> over a
+ *   random_device-seeded std::mt19937, Statistical.hpp:22-34 -- a stream without a seed API, unpinned by construction):
+ *     GMK_NOISE_SAMPLER_STD (default)  the toolchain's std::gamma_distribution<float> over std::mt19937, seeded per (game, stones) through
+ *                                      Philox; drawn on the HOST, so the self-play loops run in lock step (search, step, noise, search ...);
+ *     GMK_NOISE_SAMPLER_COUNTER        the counter-based sampler of include/gomoku_noise.h (Philox-keyed Marsaglia-Tsang, one stream per
+ *                                      (game, stones, cell)), drawn by the searching wavefront itself: the reference agent's per-move
+ *                                      semantics -- kept subtree + noise before every search -- then run inside ONE persistent launch.
+ * GMK_OPT_LOCKSTEP: 1 = gmk_selfplay_run / gmk_trad_selfplay_run alternate search and step launches even where one persistent launch could play
+ *   the games (the second form the tests hold the persistent one to); 0 (default) = persistent wherever the configuration allows. */
+enum { GMK_OPT_NOISE_SAMPLER = 1, GMK_OPT_LOCKSTEP = 2 };
+enum { GMK_NOISE_SAMPLER_STD = 0, GMK_NOISE_SAMPLER_COUNTER = 1 };
+int gmk_mcts_set_option(gmk_mcts *m, int option, int value);
 /* Root statistics after a run (synchronises the stream used by the last run):
  *   h_visits uint32[n][225] child visit counts by cell (MCTS::evalState, MCTS.cpp:104-110),
  *   h_root_value float[n], h_root_visits uint32[n], h_nodes uint32[n] (MCTS::m_size), h_status int32[n] (bit1: arena full). */
@@ -237,6 +253,8 @@ int gmk_trad_root_stats(gmk_trad* t, uint32_t* h_visits, float* h_values, float*
 int gmk_trad_step(gmk_trad* t, const int16_t* h_moves);
 /* Default::AddNoise on every root with children (the reference does this at the start of every search, MCTS.cpp:182) */
 int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id);
+/* GMK_OPT_NOISE_SAMPLER / GMK_OPT_LOCKSTEP for a K6 / K8 handle (see gmk_mcts_set_option) */
+int gmk_trad_set_option(gmk_trad* t, int option, int value);
 /* The self-play loop of the pattern-guided searchers, resident on the device (replaces the host loop of network/data_helper.py:56-83
  * around agents/mcts.py:17-21 for config.py:9-12's supervisor): n_total games (global ids first_game_id ..) are played through the
  * handle's n_games SLOTS with continuous batching -- every move = Default::AddNoise (noise_alpha > 0; MCTS.cpp:182) + one search of
@@ -245,11 +263,14 @@ int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t se
  * unstarted game (reuse_subtree = 1 keeps the chosen child's subtree as gmk_trad_step does, 0 starts every search from a new root as
  * gmk_trad_set_positions does).  Records by GAME, on the device: d_moves uint8[n_total][225], d_lens int32[n_total], d_winner
  * int8[n_total], d_visits uint16[n_total][225][225] (may be NULL).  h_open_moves / h_open_lens: the games' openings, or NULL.
- * persistent = 1 (TraditionalPolicy, a new root every move, no root noise, whole games): ONE launch in which every slot's wavefront
- * plays game after game at its own pace -- a search no longer waits for the slowest one of the batch -- taking the next unstarted game
- * from a counter when its game ends; a game then starts on a fresh evaluator (Evaluator::reset), so its record does not depend on the
- * slot it landed in and equals the one the all-games-at-once loop plays.  persistent = 0: the lock-step loop described above (a slot's
- * evaluator carries over from game to game, as the reference's policy object does within a worker).
+ * persistent = 1 (TraditionalPolicy, whole games): ONE launch in which every slot's wavefront plays game after game at its own pace -- a
+ * search no longer waits for the slowest one of the batch -- taking the next unstarted game from a counter when its game ends; a game then
+ * starts on a fresh evaluator (Evaluator::reset), so its record does not depend on the slot it landed in and equals the one the
+ * all-games-at-once loop plays.  With reuse_subtree the chosen child's subtree is compacted into the slot's second arena inside the launch
+ * (MCTS::stepForward, MCTS.cpp:129-134); root noise inside the launch is drawn by the wavefront from the counter-based sampler
+ * (gmk_trad_set_option(GMK_OPT_NOISE_SAMPLER, GMK_NOISE_SAMPLER_COUNTER); with the host-drawn std sampler the call is refused).
+ * persistent = 0, or GMK_OPT_LOCKSTEP: the lock-step loop described above (a slot's evaluator carries over from game to game, as the
+ * reference's policy object does within a worker).
  * max_steps > 0 ends the loop after that many moves per slot (games still running keep the moves they have, winner 0): what a
  * throughput measurement with every slot busy needs; 0 = play every game to its end.
  * *h_overflow != 0: some search stopped at its node capacity.  Afterwards the handle must be positioned again before other use. */

@@ -8,6 +8,7 @@
  * Compile with -ffp-contract=off: PUCB is f64 from f32 operands, the running mean is f32.
  */
 #include "gomoku_oracle.h"
+#include "../include/gomoku_noise.h"   /* the counter-based Dirichlet sampler, written once for the kernels and for this file */
 #include <string.h>
 #include <stdlib.h>
 #include <math.h>
@@ -68,6 +69,7 @@ struct go_mcts {
     int      use_mt;
     go_mt19937 mt;
     float    noise_alpha, noise_epsilon;      /* alpha == 0: AddNoise disabled */
+    int      noise_sampler;                   /* 0: std::gamma_distribution over std::mt19937 (go_stdsort.cpp); 1: gomoku_noise.h */
     go_eval_state_fn eval_state;              /* Policy(eval_state = ...) (agents/alphazero.py:5-9): replaces the rollouts */
     void    *eval_user;
 };
@@ -276,16 +278,26 @@ static void add_noise(go_mcts *m, const go_board *b) {
     int k = 0;
     for (int i = 0; i < GO_N; ++i) prior[i] = 0.0f;
     for (int i = 0; i < root->n_children; ++i) prior[m->nodes[root->first_child + i].position] = m->nodes[root->first_child + i].action_prob;
-    for (int i = 0; i < GO_N; ++i) prior[i] *= 1 - m->noise_epsilon;
-    go_philox4x32(ctr, key, w);
-    go__gamma_draws(w[0], m->noise_alpha, root->n_children, draws);
-    for (int i = 0; i < GO_N; ++i) { noise[i] = prior[i] ? draws[k++] : 0.0f; sq += noise[i] * noise[i]; }
-    if (sq > 0.0f) { float nrm = sqrtf(sq); for (int i = 0; i < GO_N; ++i) noise[i] = noise[i] / nrm; }
-    for (int i = 0; i < GO_N; ++i) prior[i] += m->noise_epsilon * noise[i];
+    if (m->noise_sampler == 1) {                                 /* the stream the device-resident loops draw from (include/gomoku_noise.h) */
+        gmk_noise_mix225(prior, m->noise_alpha, m->noise_epsilon, m->game_id, (uint32_t)b->nrec, key[0], key[1]);
+    } else {
+        for (int i = 0; i < GO_N; ++i) prior[i] *= 1 - m->noise_epsilon;
+        go_philox4x32(ctr, key, w);
+        go__gamma_draws(w[0], m->noise_alpha, root->n_children, draws);
+        for (int i = 0; i < GO_N; ++i) { noise[i] = prior[i] ? draws[k++] : 0.0f; sq += noise[i] * noise[i]; }
+        if (sq > 0.0f) { float nrm = sqrtf(sq); for (int i = 0; i < GO_N; ++i) noise[i] = noise[i] / nrm; }
+        for (int i = 0; i < GO_N; ++i) prior[i] += m->noise_epsilon * noise[i];
+    }
     for (int i = 0; i < root->n_children; ++i) m->nodes[root->first_child + i].action_prob = prior[m->nodes[root->first_child + i].position];
 }
 
 void go_mcts_set_noise(go_mcts *m, float alpha, float epsilon) { m->noise_alpha = alpha; m->noise_epsilon = epsilon; }
+void go_mcts_set_noise_sampler(go_mcts *m, int sampler) { m->noise_sampler = sampler; }
+/* one draw of the counter-based sampler / the mix on a vector of priors by cell: what the KATs of tests/test_noise.py pin */
+float go_noise_gamma(float alpha, uint32_t game_id, uint32_t stones, uint32_t cell, uint64_t seed) { return gmk_noise_gamma(alpha, game_id, stones, cell, (uint32_t)seed, (uint32_t)(seed >> 32)); }
+void go_noise_mix225(float *p, float alpha, float epsilon, uint32_t game_id, uint32_t stones, uint64_t seed) { gmk_noise_mix225(p, alpha, epsilon, game_id, stones, (uint32_t)seed, (uint32_t)(seed >> 32)); }
+double go_noise_log(double x) { return gmk_noise_log(x); }
+double go_noise_exp(double x) { return gmk_noise_exp(x); }
 void go_mcts_set_evaluator(go_mcts *m, go_eval_state_fn fn, void *user) { m->eval_state = fn; m->eval_user = user; }
 
 void go_mcts_run_playouts(go_mcts *m, go_board *b) {

@@ -12,6 +12,7 @@
  * products and sums, the 0.6 / 0.4 literals taken as float (Eigen's promote_scalar_arg), PUCB and tanh in double.
  */
 #include "go_eval_internal.h"
+#include "../include/gomoku_noise.h"   /* the counter-based Dirichlet sampler, written once for the kernels and for this file */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +37,7 @@ struct go_trad {
     /* the MCTS object around the policy (MCTS.h:135-180) when the tree is kept from search to search */
     int      have_tree;
     float    noise_alpha, noise_epsilon;
+    int      noise_sampler;         /* 0: std::gamma_distribution over std::mt19937; 1: include/gomoku_noise.h */
     uint64_t seed; uint32_t game_id;
 };
 
@@ -317,6 +319,7 @@ int go_trad_root_children(const go_trad *t, uint32_t *visits, float *values, flo
 void go_trad_set_noise(go_trad *t, float alpha, float epsilon, uint64_t seed, uint32_t game_id) {
     t->noise_alpha = alpha; t->noise_epsilon = epsilon; t->seed = seed; t->game_id = game_id;
 }
+void go_trad_set_noise_sampler(go_trad *t, int sampler) { t->noise_sampler = sampler; }
 
 /* MCTS::stepForward(next_move) (MCTS.cpp:136-147): the child of that move becomes the root, or a new node does */
 static void step_forward_move(go_trad *t, int move) {
@@ -351,14 +354,18 @@ static void add_noise(go_trad *t, int stones) {
     int k = 0;
     for (int i = 0; i < GO_N; ++i) prior[i] = 0.0f;
     for (int i = 0; i < root->n; ++i) prior[t->nodes[t->kids[root->first + i]].pos] = t->nodes[t->kids[root->first + i]].prior;
-    for (int i = 0; i < GO_N; ++i) prior[i] *= 1 - t->noise_epsilon;
-    go_philox4x32(ctr, key, w);
-    go__gamma_draws(w[0], t->noise_alpha, root->n, draws);
-    for (int i = 0; i < GO_N; ++i) { noise[i] = prior[i] ? draws[k++] : 0.0f; sq[i] = noise[i] * noise[i]; }
-    float z = 0.0f;
-    for (int i = 0; i < GO_N; ++i) z += sq[i];                   /* sequential, like go_mcts.c and the product's host code */
-    if (z > 0.0f) { float nrm = sqrtf(z); for (int i = 0; i < GO_N; ++i) noise[i] = noise[i] / nrm; }
-    for (int i = 0; i < GO_N; ++i) prior[i] += t->noise_epsilon * noise[i];
+    if (t->noise_sampler == 1) {                                  /* the stream the device-resident loops draw from */
+        gmk_noise_mix225(prior, t->noise_alpha, t->noise_epsilon, t->game_id, (uint32_t)stones, key[0], key[1]);
+    } else {
+        for (int i = 0; i < GO_N; ++i) prior[i] *= 1 - t->noise_epsilon;
+        go_philox4x32(ctr, key, w);
+        go__gamma_draws(w[0], t->noise_alpha, root->n, draws);
+        for (int i = 0; i < GO_N; ++i) { noise[i] = prior[i] ? draws[k++] : 0.0f; sq[i] = noise[i] * noise[i]; }
+        float z = 0.0f;
+        for (int i = 0; i < GO_N; ++i) z += sq[i];               /* sequential, like go_mcts.c and the product's host code */
+        if (z > 0.0f) { float nrm = sqrtf(z); for (int i = 0; i < GO_N; ++i) noise[i] = noise[i] / nrm; }
+        for (int i = 0; i < GO_N; ++i) prior[i] += t->noise_epsilon * noise[i];
+    }
     for (int i = 0; i < root->n; ++i) t->nodes[t->kids[root->first + i]].prior = prior[t->nodes[t->kids[root->first + i]].pos];
 }
 

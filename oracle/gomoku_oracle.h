@@ -152,6 +152,13 @@ void go_mcts_root_children(const go_mcts *m, uint32_t *visits /*[225]*/, float *
 uint64_t go_mcts_alg_bytes(const go_mcts *m);
 /* Default::AddNoise at the start of every search (MCTS.cpp:182); alpha = 0 (default) disables it. */
 void go_mcts_set_noise(go_mcts *m, float alpha, float epsilon);
+/* which stream AddNoise draws from: 0 (default) std::gamma_distribution<float> over std::mt19937, seeded by Philox(game, stones, 'nois');
+   1 the counter-based sampler of include/gomoku_noise.h (what the device-resident self-play loops draw from, inside their kernels) */
+void go_mcts_set_noise_sampler(go_mcts *m, int sampler);
+float go_noise_gamma(float alpha, uint32_t game_id, uint32_t stones, uint32_t cell, uint64_t seed);
+void go_noise_mix225(float *p, float alpha, float epsilon, uint32_t game_id, uint32_t stones, uint64_t seed);
+double go_noise_log(double x);
+double go_noise_exp(double x);
 /* the search then calls fn at every new leaf instead of rolling out, and expands with Default::Expand(extraCheck = true) */
 void go_mcts_set_evaluator(go_mcts *m, go_eval_state_fn fn, void *user);
 /* KAT hook: draw rollout moves sequentially from std::mt19937(seed) (id = eng() % 225) instead of Philox,
@@ -174,6 +181,7 @@ void go_trad_search(go_trad *t, const uint8_t *moves, int n_moves, uint64_t play
 /* the same inside a persistent MCTS object: the tree is kept from call to call (syncWithBoard / stepForward(move)), noise is
    mixed into the root priors before every search when alpha > 0 (Default::AddNoise), go_trad_step_forward plays the best child */
 void go_trad_set_noise(go_trad *t, float alpha, float epsilon, uint64_t seed, uint32_t game_id);
+void go_trad_set_noise_sampler(go_trad *t, int sampler);
 void go_trad_run(go_trad *t, const uint8_t *moves, int n_moves, uint64_t playouts);
 int  go_trad_step_forward(go_trad *t);
 /* per-cell root child statistics; returns the move MCTS::stepForward() would play (-1 without children) */

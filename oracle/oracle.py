@@ -20,7 +20,8 @@ TYPE_NAMES = ["DeadOne", "LiveOne", "DeadTwo", "LiveTwo", "DeadThree", "LiveThre
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("go_board.c", "go_ac.c", "go_eval.c", "go_mcts.c", "go_scratch.c", "go_stdsort.cpp", "gomoku_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("go_board.c", "go_ac.c", "go_eval.c", "go_mcts.c", "go_scratch.c", "go_trad.c", "go_rave.c", "go_stdsort.cpp", "gomoku_oracle.h",
+                                             "go_eval_internal.h", os.path.join("..", "include", "gomoku_noise.h"))]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -153,6 +154,18 @@ def lib():
     L.go_mcts_alg_bytes.restype = C.c_uint64
     L.go_mcts_set_noise.argtypes = [C.c_void_p, C.c_float, C.c_float]
     L.go_mcts_set_noise.restype = None
+    L.go_mcts_set_noise_sampler.argtypes = [C.c_void_p, C.c_int]
+    L.go_mcts_set_noise_sampler.restype = None
+    L.go_trad_set_noise_sampler.argtypes = [C.c_void_p, C.c_int]
+    L.go_trad_set_noise_sampler.restype = None
+    L.go_noise_gamma.argtypes = [C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.go_noise_gamma.restype = C.c_float
+    L.go_noise_mix225.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.go_noise_mix225.restype = None
+    L.go_noise_log.argtypes = [C.c_double]
+    L.go_noise_log.restype = C.c_double
+    L.go_noise_exp.argtypes = [C.c_double]
+    L.go_noise_exp.restype = C.c_double
     L.go_visits_to_pi.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.go_visits_to_pi.restype = None
     _lib = L
@@ -302,8 +315,10 @@ class MCTS:
             self.L.go_mcts_free(self.h)
             self.h = None
 
-    def set_noise(self, alpha, epsilon):
+    def set_noise(self, alpha, epsilon, sampler=0):
+        """sampler 0: std::gamma_distribution over std::mt19937 (host); 1: the counter-based sampler of include/gomoku_noise.h"""
         self.L.go_mcts_set_noise(self.h, alpha, epsilon)
+        self.L.go_mcts_set_noise_sampler(self.h, int(sampler))
 
     def set_evaluator(self, fn):
         """fn(states uint8[6,15,15]) -> (value, probs float32[225]): Policy(eval_state=fn) of the reference (agents/alphazero.py:5-9)."""
@@ -393,8 +408,9 @@ class TraditionalMCTS:
         m = np.ascontiguousarray(moves, dtype=np.uint8)
         self.L.go_trad_search(self.h, m.ctypes.data, len(m), int(playouts))
 
-    def set_noise(self, alpha, epsilon, seed, game_id=0):
+    def set_noise(self, alpha, epsilon, seed, game_id=0, sampler=0):
         self.L.go_trad_set_noise(self.h, alpha, epsilon, seed, game_id)
+        self.L.go_trad_set_noise_sampler(self.h, int(sampler))
 
     def run(self, moves, playouts):
         """runPlayouts on the kept tree (syncWithBoard, AddNoise, playouts)."""

@@ -60,7 +60,7 @@ def test_continuous_batching_gives_the_same_games(opening_plies, reuse, noise):
     == the same 23 games played side by side in lock step: moves, winners, lengths and every recorded visit count.  A game's random
     streams (rollouts, root noise) are keyed by the game's global id, not by the slot it runs in."""
     n, playouts = 23, 30
-    a = selfplay.play_games(n, playouts, seed=77, first_game_id=900, opening_plies=opening_plies, reuse_subtree=reuse, root_noise=noise).cpu()
+    a = selfplay.play_games(n, playouts, seed=77, first_game_id=900, opening_plies=opening_plies, reuse_subtree=reuse, root_noise=noise, lockstep=True).cpu()      # the host-driven loop
     b = selfplay.play_games(n, playouts, seed=77, first_game_id=900, opening_plies=opening_plies, reuse_subtree=reuse, root_noise=noise, slots=5).cpu()
     assert not a.overflow and not b.overflow
     assert (a.lens == b.lens).all() and (a.winner == b.winner).all() and (a.moves == b.moves).all()
@@ -75,14 +75,16 @@ def test_continuous_batching_gives_the_same_games(opening_plies, reuse, noise):
         assert (a.lens == d.lens).all() and (a.winner == d.winner).all() and (a.moves == d.moves).all() and (a.visits == d.visits).all()
 
 
-def _oracle_game_reuse(O, game_id, playouts, seed, noise=None):
+def _oracle_game_reuse(O, game_id, playouts, seed, noise=None, sampler=0, opening=()):
     """One MCTS object for the whole game, as agents/mcts.py:17-21 drives it: sync, search, step_forward()."""
     L = O.lib()
     b = O.new_board()
+    for mv in opening:
+        L.go_board_apply(C.byref(b), int(mv), 1)
     m = O.MCTS(playouts, 5.0, 5, seed, game_id)
     if noise:
-        m.set_noise(*noise)
-    moves, visits = [], []
+        m.set_noise(*noise, sampler=sampler)
+    moves, visits = list(opening), []
     while b.cur_player != 0:
         m.sync_with_board(b)
         _, _, v = m.eval_state(b)
@@ -112,7 +114,7 @@ def test_root_noise_matches_oracle(oracle):
     """The reference's self-play configuration: subtree reuse + Default::AddNoise(alpha 0.05, epsilon 0.25) at the
     start of every search (MCTS.cpp:182).  Same std::gamma_distribution<float> on both sides, Philox-derived seeds."""
     n, playouts, seed, first = 3, 50, 77, 900
-    rec = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, reuse_subtree=True, root_noise=(0.05, 0.25)).cpu()
+    rec = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, reuse_subtree=True, root_noise=(0.05, 0.25), noise_sampler="std").cpu()
     plain = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, reuse_subtree=True).cpu()
     assert not rec.overflow
     differs = False
@@ -125,6 +127,42 @@ def test_root_noise_matches_oracle(oracle):
             assert (rec.visits[g, t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all()
         differs |= [int(x) for x in plain.moves[g, :int(plain.lens[g])]] != moves
     assert differs                      # the noise does change the games
+
+
+@pytest.mark.parametrize("slots", [None, 5, 23, 40])
+def test_reference_semantics_in_one_launch(oracle, slots):
+    """The reference agent's per-move semantics -- the chosen child's subtree is the next search's tree (MCTS.cpp:129-147) and Default::AddNoise
+    (0.05, 0.25) runs before every search (MCTS.cpp:179-183) -- inside ONE persistent launch (per-game arena flip, noise drawn by the wavefront
+    from the counter-based sampler of include/gomoku_noise.h) == the lock-step loop with the same sampler == the oracle's game loop with it:
+    moves, lengths, winners and every recorded visit count, for 23 games through 5 / 23 / 40 slots and all at once."""
+    n, playouts, seed, first, noise, plies = 23, 30, 4242, 700, (0.05, 0.25), 3
+    one = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, opening_plies=plies, reuse_subtree=True, root_noise=noise, slots=slots).cpu()
+    step = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, opening_plies=plies, reuse_subtree=True, root_noise=noise, slots=slots, lockstep=True).cpu()
+    assert not one.overflow and not step.overflow
+    assert (one.lens == step.lens).all() and (one.winner == step.winner).all() and (one.moves == step.moves).all() and (one.visits == step.visits).all()
+    m, l, _ = G.synth_boards(n, 0, seed=seed, first_board=first)
+    for g in range(n):
+        opening = [int(x) for x in m[g, :min(int(l[g]), plies)]]
+        moves, visits, winner = _oracle_game_reuse(oracle, first + g, playouts, seed, noise=noise, sampler=1, opening=opening)
+        L = int(one.lens[g])
+        assert [int(x) for x in one.moves[g, :L]] == moves, "game %d" % g
+        assert int(one.winner[g]) == winner
+        for t, v in enumerate(visits):
+            assert (one.visits[g, len(opening) + t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all(), "game %d move %d" % (g, t)
+
+
+def test_kept_subtrees_in_one_launch_without_noise(oracle):
+    """reuse_subtree alone inside the persistent launch == the oracle's kept-tree game loop."""
+    n, playouts, seed, first = 6, 50, 1234, 40
+    rec = selfplay.play_games(n, playouts, seed=seed, first_game_id=first, reuse_subtree=True, slots=4).cpu()
+    assert not rec.overflow
+    for g in range(n):
+        moves, visits, winner = _oracle_game_reuse(oracle, first + g, playouts, seed)
+        L = int(rec.lens[g])
+        assert [int(x) for x in rec.moves[g, :L]] == moves, "game %d" % g
+        assert int(rec.winner[g]) == winner
+        for t, v in enumerate(visits):
+            assert (rec.visits[g, t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all()
 
 
 def test_device_tuples_match_the_reference_loop():
@@ -479,8 +517,55 @@ def test_persistent_supervisor_loop_plays_the_games_of_the_all_at_once_loop(orac
         assert (a.moves == host.moves).all() and (a.visits == host.visits).all(), slots
     legal, end_ply, winner = oracle.replay_games(a.moves.numpy(), a.lens.numpy())
     assert legal.all() and (end_ply == a.lens.numpy()).all() and (winner == a.winner.numpy()).all()
-    with pytest.raises(ValueError):
-        selfplay.play_supervisor_games(4, 10, device_loop="persistent", reuse_subtree=True)
+    with pytest.raises(ValueError):          # host-drawn noise cannot come inside the one launch
+        selfplay.play_supervisor_games(4, 10, device_loop="persistent", reuse_subtree=True, root_noise=(0.05, 0.25), noise_sampler="std")
+
+
+def _oracle_supervisor_game(O, game_id, playouts, seed, opening, noise=None, c_puct=5.0):
+    """One MCTS(TraditionalPolicy) object for the whole game, as agents/mcts.py:17-21 drives it: runPlayouts on the kept tree (syncWithBoard,
+    AddNoise with the counter-based sampler, the playouts), then stepForward()'s move on the board."""
+    L = O.lib()
+    b = O.new_board()
+    for mv in opening:
+        L.go_board_apply(C.byref(b), int(mv), 1)
+    t = O.TraditionalMCTS(c_puct)
+    if noise:
+        t.set_noise(noise[0], noise[1], seed, game_id, sampler=1)
+    moves, visits = [int(x) for x in opening], []
+    while b.cur_player != 0:
+        t.run(moves, playouts)
+        visits.append(t.root_children()[0].copy())
+        mv = t.step_forward()
+        moves.append(mv)
+        L.go_board_apply(C.byref(b), mv, 1)
+    return moves, visits, b.winner
+
+
+@pytest.mark.parametrize("noise", [None, (0.05, 0.25)])
+def test_supervisor_reference_semantics_in_one_launch(oracle, noise):
+    """K6 with the reference agent's per-move semantics -- the chosen child's subtree kept (MCTS.cpp:129-147), Default::AddNoise before every search
+    (MCTS.cpp:179-183) -- inside ONE persistent launch (the subtree compacted into the slot's other arena by the wavefront, the noise drawn by it
+    from the counter-based sampler) == the host-driven loop with the same sampler (all games side by side) == the oracle's kept-tree game loop:
+    moves, lengths, winners, per-ply root visit counts; 23 games through 5, 23 and 40 slots."""
+    n, playouts, seed, first = 23, 60, 7, 61
+    kw = dict(c_puct=5.0, policy="traditional", opening_plies=2, first_game_id=first, seed=seed, reuse_subtree=True, root_noise=noise)
+    host = selfplay.play_supervisor_games(n, playouts, device_loop=False, **kw).cpu()
+    assert not host.overflow
+    for slots in (5, 23, 40):
+        a = selfplay.play_supervisor_games(n, playouts, slots=slots, device_loop="persistent", **kw)
+        assert not a.overflow
+        a = a.cpu()
+        assert (a.lens == host.lens).all() and (a.winner == host.winner).all(), slots
+        assert (a.moves == host.moves).all() and (a.visits == host.visits).all(), slots
+    m, l, _ = G.synth_boards(n, 0, seed=seed, first_board=first)
+    for g in range(0, n, 3):
+        opening = [int(x) for x in m[g, :min(int(l[g]), 2)]]
+        moves, visits, winner = _oracle_supervisor_game(oracle, first + g, playouts, seed, opening, noise)
+        L = int(a.lens[g])
+        assert [int(x) for x in a.moves[g, :L]] == moves, "game %d" % g
+        assert int(a.winner[g]) == winner
+        for t, v in enumerate(visits):
+            assert (a.visits[g, len(opening) + t].numpy().astype(np.uint32) == np.minimum(v, 65535)).all(), "game %d move %d" % (g, t)
 
 
 def test_supervisor_loop_stops_after_max_steps():

@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--reuse", action="store_true", help="keep the subtree of the played move (MCTS::stepForward)")
     ap.add_argument("--noise", action="store_true", help="Default::AddNoise(0.05, 0.25) before every search (needs --reuse)")
     ap.add_argument("--augment", action="store_true")
+    ap.add_argument("--lockstep", action="store_true", help="random: search-by-search launches instead of ONE persistent launch")
+    ap.add_argument("--sampler", default="counter", choices=["counter", "std"], help="random: where the root noise is drawn (std: on the host, which forces lock step)")
+    ap.add_argument("--handles", default="auto")
     ap.add_argument("--host-loop", action="store_true", help="traditional / poolrave / network: drive the games from the host ply by ply (the loop the device-resident one replaced)")
     ap.add_argument("--slots", default=None, help="games in flight: a finished game hands its slot to the next one (random: on the device, gmk_selfplay_run; default there: "
                     "selfplay.SLOTS_PER_GPU when a rank has more games than that); 0 = all games at once")
@@ -40,7 +43,8 @@ def main():
     noise = (0.05, 0.25) if args.noise else None
     slots = None if args.slots in ("0", 0) else int(args.slots) if args.slots is not None else ("auto" if args.policy == "random" else None)
     if args.policy == "random":
-        rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse, root_noise=noise, slots=slots)
+        rec = selfplay.play_games(n, args.playouts, first_game_id=first, reuse_subtree=args.reuse, root_noise=noise, slots=slots, lockstep=args.lockstep,
+                                  noise_sampler=args.sampler, handles=args.handles if args.handles == "auto" else int(args.handles))
     elif args.policy == "network":
         from gomokuai_amd.network import FusedPolicyValueNetwork, PolicyValueNetwork
         net = FusedPolicyValueNetwork(PolicyValueNetwork(seed=1).cuda().eval())
