@@ -290,53 +290,45 @@ def bench_trad(args, G, torch, dev, rank, world, distributed):
 def bench_supervisor_pipeline(args, G, torch, dev, rank, world, distributed, bare_playouts_per_s):
     """The supervisor's self-play loop (network/data_helper.py:56-83 with config.py:9-12's "traditional_mcts" on both sides) resident on
     the device: --sup-games games per GPU through --trad-games slots (gmk_trad_selfplay_run, persistent: ONE launch in which every slot's
-    wavefront plays game after game at its own pace), every move one K6 search of --trad-playouts playouts.  Weak scaling (games per GPU
-    fixed); the time is the slowest rank's.  Beside it the lock-step form of the loop (search by search for all slots) with every slot busy."""
+    wavefront plays game after game at its own pace), every move one K6 search of --trad-playouts playouts -- from a new root every move, and
+    (reference_semantics) as the reference's agent plays them: the chosen child's subtree kept (MCTS.cpp:129-147) and Default::AddNoise(0.05, 0.25)
+    before every search (MCTS.cpp:179-183), both inside the same one launch.  Weak scaling (games per GPU fixed); the time is the slowest
+    rank's.  Beside it the lock-step form of the loop (search by search for all slots) with every slot busy."""
     import time
     from gomokuai_amd import selfplay
     n, slots, P = args.sup_games, args.trad_games, args.trad_playouts
-    def play():
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = selfplay.play_supervisor_games(n, P, first_game_id=rank * n, opening_plies=2, slots=slots, node_capacity=args.trad_nodes)
-        torch.cuda.synchronize()
-        return r, time.perf_counter() - t0
-    if distributed:
-        torch.distributed.barrier()
-    rec, seconds = local_stage("supervisor self-play", play, torch, dev, distributed)
-    moves = int(rec.lens.sum()) - 2 * n                          # searched plies (the two opening plies are given)
-    if distributed:
-        t = torch.tensor([seconds], dtype=torch.float64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        seconds = float(t[0])
-        c = torch.tensor([moves, int(rec.overflow)], dtype=torch.int64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
-        moves, overflow = int(c[0]), bool(int(c[1]))
-    else:
-        overflow = bool(rec.overflow)
+    def run(what, **kw):
+        def play():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = selfplay.play_supervisor_games(first_game_id=rank * n, opening_plies=2, slots=slots, **kw)
+            torch.cuda.synchronize()
+            return r, time.perf_counter() - t0
+        if distributed:
+            torch.distributed.barrier()
+        rec, seconds = local_stage(what, play, torch, dev, distributed)
+        searched = int(rec.lens.sum()) - int(torch.clamp(rec.lens, max=2).sum())      # searched plies (the two opening plies are given)
+        (seconds,), (searched, overflow) = reduce_leg(torch, dev, distributed, [seconds], [searched, int(bool(rec.overflow))])
+        return seconds, searched, bool(overflow)
+    seconds, moves, overflow = run("supervisor self-play", n_games=n, playouts=P, node_capacity=args.trad_nodes)
     rate = moves * P / seconds
-    # ... and the lock-step form of the loop (one search launch per move for all slots, then the step kernels; what kept subtrees, root noise
+    # the same games as the reference's agent plays them (a kept subtree is searched on top of: three times the nodes, in each of a slot's two arenas)
+    ref_seconds, ref_moves, ref_overflow = run("supervisor self-play (reference semantics)", n_games=n, playouts=P, node_capacity=min(3 * args.trad_nodes, (1 << 24) - 1),
+                                               reuse_subtree=True, root_noise=REFERENCE_NOISE)
+    ref_rate = ref_moves * P / ref_seconds
+    # ... and the lock-step form of the loop (one search launch per move for all slots, then the step kernels; what host-drawn root noise
     # and PoolRAVE use) while every slot is busy (eight games queued per slot, stopped after 40 moves per slot): what that loop's step
     # kernels, slot hand-over and four bytes to the host per move take from the bare search rate
     steady_steps = 40
-    def steady():
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = selfplay.play_supervisor_games(8 * slots, P, first_game_id=(world + rank) * n, opening_plies=2, slots=slots, node_capacity=args.trad_nodes, max_steps=steady_steps)
-        torch.cuda.synchronize()
-        return r, time.perf_counter() - t0
-    rec2, seconds2 = local_stage("supervisor self-play (busy slots)", steady, torch, dev, distributed)
-    moves2 = int(rec2.lens.sum()) - int(torch.clamp(rec2.lens, max=2).sum())
-    if distributed:
-        t = torch.tensor([seconds2], dtype=torch.float64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        seconds2 = float(t[0])
-        c = torch.tensor([moves2], dtype=torch.int64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
-        moves2 = int(c[0])
+    seconds2, moves2, _ = run("supervisor self-play (busy slots)", n_games=8 * slots, playouts=P, node_capacity=args.trad_nodes, max_steps=steady_steps)
     busy_rate = moves2 * P / seconds2
     return {"metric": "supervisor self-play playouts/s", "value": rate, "unit": "playouts/s", "seconds": seconds, "games": n * world, "searched_moves": moves,
             "games_per_s": n * world / seconds, "arena_overflow": overflow,
+            "reference_semantics": {"value": ref_rate, "unit": "playouts/s", "seconds": ref_seconds, "searched_moves": ref_moves, "games_per_s": n * world / ref_seconds,
+                                    "arena_overflow": ref_overflow, "share_of_new_root_playouts_per_s": ref_rate / rate,
+                                    "config": {"workload": "the same %d games per GPU through %d slots in ONE persistent launch, as the reference's agent plays them: kept subtree (MCTS.cpp:129-147) + "
+                                                           "Default::AddNoise(0.05, 0.25) before every search (MCTS.cpp:179-183), drawn by the searching wavefront from the counter-based "
+                                                           "sampler (include/gomoku_noise.h)" % (n, slots)}},
             "busy_slots": {"value": busy_rate, "unit": "playouts/s", "steps": steady_steps, "searched_moves": moves2, "seconds": seconds2,
                            "share_of_bare_search_rate": busy_rate / bare_playouts_per_s if bare_playouts_per_s else None,
                            "note": "includes the setup of %d queued games (records, openings) and the first search's evaluator syncs" % (8 * slots)},
@@ -449,19 +441,14 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
         torch.cuda.synchronize()
         if distributed:
             torch.distributed.barrier()
-        t0 = time.perf_counter()
-        rec = selfplay.play_network_games(args.az_selfplay_games, fused, args.az_selfplay_playouts, first_game_id=rank * args.az_selfplay_games, opening_plies=2,
-                                          slots=max(1, args.az_selfplay_games // 4), reuse_subtree=True, root_noise=(0.05, 0.25))
-        torch.cuda.synchronize()
-        pipe_s = time.perf_counter() - t0
-        pipe_moves = int(rec.lens.sum()) - 2 * args.az_selfplay_games
-    if distributed:
-        t = torch.tensor([ms, pipe_s], dtype=torch.float64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        ms, pipe_s = float(t[0]), float(t[1])
-        t = torch.tensor([float(pipe_moves)], dtype=torch.float64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        pipe_moves = int(t[0])
+        def play():                                              # (gigabytes of records, activations and gather buffers: local work that can fail on one rank alone)
+            t0 = time.perf_counter()
+            rec = selfplay.play_network_games(args.az_selfplay_games, fused, args.az_selfplay_playouts, first_game_id=rank * args.az_selfplay_games, opening_plies=2,
+                                              slots=max(1, args.az_selfplay_games // 4), reuse_subtree=True, root_noise=(0.05, 0.25))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, int(rec.lens.sum()) - 2 * args.az_selfplay_games
+        pipe_s, pipe_moves = local_stage("az self-play", play, torch, dev, distributed)
+    (ms, pipe_s), (pipe_moves,) = reduce_leg(torch, dev, distributed, [ms, pipe_s], [pipe_moves])
     fused.close()
     pipeline = None
     if args.az_selfplay_games > 0:
@@ -481,14 +468,19 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
                     "the select and expand kernels take the remainder"}
 
 
-def bench_selfplay(args, torch, dev, rank, world, distributed):
-    """BASELINE configs[3], the self-play data pipeline (network/data_helper.py:58-113): --selfplay-games games IN TOTAL, sharded by global
-    game id; every rank plays its shard to the end (K3 with continuous batching on the device, gmk_selfplay_run), builds the training
-    tuples on the device (K4 + K5), and the compact records travel to rank 0 (selfplay.gather_records: one batch of point-to-point
-    transfers, RCCL over xGMI).  The total is fixed, so this leg scales STRONGLY; its time is the slowest rank's, barrier to barrier."""
+REFERENCE_NOISE = (0.05, 0.25)      # Default::AddNoise's defaults (MonteCarlo.hpp:97), what MCTS::runPlayouts calls it with (MCTS.cpp:182)
+
+
+def selfplay_leg(args, torch, dev, rank, world, distributed, total_games, reference, scaling):
+    """One run of the self-play data pipeline (network/data_helper.py:58-113): total_games IN TOTAL, sharded by global game id; every rank plays
+    its shard to the end (K3, the loop resident on the device: gmk_selfplay_run), builds the training tuples on the device (K4 + K5), and the
+    compact records travel to rank 0 (selfplay.gather_records: one batch of point-to-point transfers, RCCL over xGMI).  reference: the
+    reference agent's per-move semantics (agents/mcts.py:17-21) -- the chosen child's subtree is the next search's tree (MCTS.cpp:129-147) and
+    Default::AddNoise(0.05, 0.25) runs before every search (MCTS.cpp:179-183) -- instead of a new root every move without noise.  The time
+    is the slowest rank's, barrier to barrier.  Returns the result object on rank 0, None elsewhere."""
     import time
     from gomokuai_amd import selfplay
-    first, n = selfplay.shard(args.selfplay_games, rank, world)
+    first, n = selfplay.shard(total_games, rank, world)
     P = args.mcts_playouts
     torch.cuda.synchronize()
     if distributed:
@@ -496,7 +488,7 @@ def bench_selfplay(args, torch, dev, rank, world, distributed):
     t0 = time.perf_counter()
     # (the local stages -- they allocate gigabytes -- end in an agreement of the ranks: see local_stage)
     def play():
-        r = selfplay.play_games(n, P, first_game_id=first)
+        r = selfplay.play_games(n, P, first_game_id=first, reuse_subtree=reference, root_noise=REFERENCE_NOISE if reference else None)
         torch.cuda.synchronize()
         return r
     rec = local_stage("self-play", play, torch, dev, distributed)
@@ -513,28 +505,82 @@ def bench_selfplay(args, torch, dev, rank, world, distributed):
     if distributed:
         torch.distributed.barrier()
     t3 = time.perf_counter()
+    # everything that can fail is above (inside local_stage / the gather's own agreement); from here on: packing numbers, then the reductions
     moves = int(rec.lens.sum())
     n_tuples = int(states.shape[0])
-    times = [t1 - t0, t2 - t1, t3 - t2, t3 - t0]
-    if distributed:
-        t = torch.tensor(times, dtype=torch.float64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        times = [float(v) for v in t]
-        c = torch.tensor([moves, n_tuples, int(rec.overflow)], dtype=torch.int64, device=REDUCE_DEVICE or dev)
-        torch.distributed.all_reduce(c, op=torch.distributed.ReduceOp.SUM)
-        moves, n_tuples, overflow = int(c[0]), int(c[1]), bool(int(c[2]))
-    else:
-        overflow = bool(rec.overflow)
+    overflow = bool(rec.overflow)
+    times = [t1 - t0, t2 - t1, t3 - t2, t3 - t0, float(rec.lens.max())]
+    times, (moves, n_tuples, n_overflow) = reduce_leg(torch, dev, distributed, times, [moves, n_tuples, int(overflow)])
     if rank != 0:
         return None
-    return {"metric": "self-play games/s", "value": args.selfplay_games / times[3], "unit": "games/s", "scaling": "strong",
+    plan = selfplay.plan_games(n, reuse_subtree=reference) or [(0, n, n)]
+    return {"metric": "self-play games/s", "value": total_games / times[3], "unit": "games/s", "scaling": scaling,
             "playouts_per_s": moves * P / times[0], "seconds": times[3], "play_s": times[0], "tuples_s": times[1], "gather_s": times[2],
             "moves": moves, "training_tuples": n_tuples, "gathered_games": len(gathered), "gathered_first_game_id": int(gathered.first_game_id),
-            "arena_overflow": overflow,
+            "arena_overflow": bool(n_overflow), "mean_game_moves": moves / total_games, "longest_game_moves": int(times[4]),
             "config": {"workload": "self-play data pipeline (K3 -> K4 + K5 -> gather), %d games in total x %d playouts per move, RandomPolicy c_puct=5 "
-                                   "c_rollouts=5, empty openings, visit counts recorded" % (args.selfplay_games, P),
-                       "games_per_gpu": n, "slots_per_gpu": min(n, selfplay.SLOTS_PER_GPU), "search_handles_per_gpu": 2 if n >= selfplay.HANDLES_FROM_GAMES else 1,
+                                   "c_rollouts=5, empty openings, visit counts recorded; %s" % (total_games, P,
+                                   "the reference agent's per-move semantics: kept subtree (MCTS.cpp:129-147) + Default::AddNoise(0.05, 0.25) before every search (MCTS.cpp:179-183), "
+                                   "drawn inside the ONE persistent launch from the counter-based sampler (include/gomoku_noise.h)" if reference else "a new root every move, no root noise (ONE persistent launch per handle)"),
+                       "games_per_gpu": n, "slots_per_gpu": sum(sl for _, _, sl in plan), "search_handles_per_gpu": len(plan),
                        "parallelism": "games sharded by global id, one gather of the compact records to rank 0"}}
+
+
+def reduce_leg(torch, dev, distributed, times, counts):
+    """The reductions at the end of a leg: MAX of the times, SUM of the counts -- ONE collective (a float64 vector, the counts are far below 2^53), so
+    that ranks cannot meet in different collectives; nothing between the leg's last agreement and this call may raise."""
+    if not distributed:
+        return list(times), list(counts)
+    k = len(times)
+    t = torch.tensor(list(times) + [float(c) for c in counts], dtype=torch.float64, device=REDUCE_DEVICE or dev)
+    gathered = [torch.zeros_like(t) for _ in range(torch.distributed.get_world_size())]
+    torch.distributed.all_gather(gathered, t)
+    stacked = torch.stack(gathered)
+    return [float(v) for v in stacked[:, :k].max(0).values], [int(round(float(v))) for v in stacked[:, k:].sum(0)]
+
+
+def bench_selfplay(args, torch, dev, rank, world, distributed):
+    """BASELINE configs[3].  (a) The STRONG form north_star states: --selfplay-games games IN TOTAL over the ranks -- with its reference_semantics
+    twin (the same games as the reference's agent plays them: kept subtree + root noise before every search).  (b) The WEAK form:
+    --selfplay-games-per-gpu games per rank (on one GPU with the defaults it is the same run as (a), which is then not repeated).
+    (c) On one GPU, a REHEARSAL of the shard a rank gets at N = 8 in the strong form (total / 8 games): what "near-linear scaling to 8 GPUs"
+    will read on that leg, before a node shows up."""
+    strong = selfplay_leg(args, torch, dev, rank, world, distributed, args.selfplay_games, False, "strong")
+    strong_ref = selfplay_leg(args, torch, dev, rank, world, distributed, args.selfplay_games, True, "strong")
+    weak_total = args.selfplay_games_per_gpu * world
+    weak = weak_ref = None
+    if args.selfplay_games_per_gpu > 0 and weak_total != args.selfplay_games:
+        weak = selfplay_leg(args, torch, dev, rank, world, distributed, weak_total, False, "weak")
+        weak_ref = selfplay_leg(args, torch, dev, rank, world, distributed, weak_total, True, "weak")
+    rehearsal = None
+    if world == 1 and args.selfplay_rehearsal_ranks > 1 and args.selfplay_games >= args.selfplay_rehearsal_ranks:
+        shard_games = args.selfplay_games // args.selfplay_rehearsal_ranks
+        small = selfplay_leg(args, torch, dev, rank, world, distributed, shard_games, False, "strong")
+        small_ref = selfplay_leg(args, torch, dev, rank, world, distributed, shard_games, True, "strong")
+        rehearsal = {"ranks_rehearsed": args.selfplay_rehearsal_ranks, "games": shard_games,
+                     "new_roots": {k: small[k] for k in ("value", "playouts_per_s", "seconds", "play_s", "moves", "mean_game_moves", "longest_game_moves")},
+                     "reference_semantics": {k: small_ref[k] for k in ("value", "playouts_per_s", "seconds", "play_s", "moves", "mean_game_moves", "longest_game_moves")},
+                     "tail": {"slots_busy_share": {"new_roots": small["mean_game_moves"] / small["longest_game_moves"], "reference_semantics": small_ref["mean_game_moves"] / small_ref["longest_game_moves"]},
+                              "note": "every game of the shard has a slot of its own and starts at once, a search is a serial chain of %d playouts, and the launch ends with the longest game: "
+                                      "mean game length / longest game length is the share of slot-time that plays.  Game lengths are not known in advance (no longest-first)" % args.mcts_playouts},
+                     "predicted_strong_efficiency_at_%d" % args.selfplay_rehearsal_ranks: {"new_roots": small["value"] / strong["value"], "reference_semantics": small_ref["value"] / strong_ref["value"]},
+                     "note": "one GPU playing the shard a rank gets when the strong form's %d games are split over %d ranks: its games/s over the full batch's games/s on the same GPU "
+                             "= the strong-scaling efficiency that leg can reach at that N before any gather cost (a shard is ONE persistent launch: it ends with its longest game, "
+                             "and %d games leave the chip's %d wavefront slots half empty from the start)" % (args.selfplay_games, args.selfplay_rehearsal_ranks, shard_games, 2048)}
+    if rank != 0:
+        return None
+    out = strong
+    ref_keys = ("value", "unit", "playouts_per_s", "seconds", "play_s", "tuples_s", "gather_s", "moves", "training_tuples", "arena_overflow", "mean_game_moves", "longest_game_moves", "config")
+    out["reference_semantics"] = {k: strong_ref[k] for k in ref_keys}
+    out["reference_semantics"]["share_of_new_root_playouts_per_s"] = strong_ref["playouts_per_s"] / strong["playouts_per_s"]
+    if weak is not None:
+        out["weak_scaling"] = {k: weak[k] for k in ref_keys + ("scaling",)}
+        out["weak_scaling"]["reference_semantics"] = {k: weak_ref[k] for k in ref_keys}
+    else:
+        out["weak_scaling"] = {"note": "--selfplay-games-per-gpu x ranks = --selfplay-games: on this run the weak form IS the strong form above (games per GPU %d)" % args.selfplay_games_per_gpu}
+    if rehearsal is not None:
+        out["shard_rehearsal"] = rehearsal
+    return out
 
 
 def cpu_baseline_trad(G, playouts):
@@ -591,6 +637,10 @@ def parse_args(argv=None):
     ap.add_argument("--mcts-saturated-games", type=int, default=16384, help="games per GPU for the saturated-batch K3 figure beside configs[2]; 0 = skip")
     ap.add_argument("--selfplay-games", type=int, default=32768,
                     help="games IN TOTAL (over all GPUs) for the self-play pipeline measurement (BASELINE configs[3]); 0 = skip")
+    ap.add_argument("--selfplay-games-per-gpu", type=int, default=32768,
+                    help="games PER GPU for the weak-scaling form of the self-play pipeline (skipped where it coincides with --selfplay-games); 0 = skip")
+    ap.add_argument("--selfplay-rehearsal-ranks", type=int, default=8,
+                    help="one-GPU runs only: also play --selfplay-games / this many games, the shard a rank gets at that N (shard_rehearsal); 0 = skip")
     ap.add_argument("--evalstate-games", type=int, default=2304, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
     ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
     ap.add_argument("--az-playouts", type=int, default=60)
@@ -600,7 +650,8 @@ def parse_args(argv=None):
     ap.add_argument("--trad-playouts", type=int, default=1000)
     ap.add_argument("--trad-nodes", type=int, default=1 << 18, help="node capacity per game")
     ap.add_argument("--trad-saturated-games", type=int, default=8192, help="games per GPU for the saturated-batch K6 figure beside the 2 048-game one; 0 = skip")
-    ap.add_argument("--sup-games", type=int, default=8192, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots); 0 = skip")
+    ap.add_argument("--sup-games", type=int, default=16384, help="games per GPU for the supervisor self-play measurement (played through --trad-games slots; 8 192 until round 4: one game in a hundred is a "
+                         "225-move draw, i.e. ~9 s of searches in a row, and with four games per slot the whole run lasted no longer than that -- the rate measured the tail); 0 = skip")
     ap.add_argument("--rave-games", type=int, default=4096, help="games per GPU for the PoolRAVE search measurement (K8); 0 = skip")
     ap.add_argument("--rave-playouts", type=int, default=400)
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds after which `--gpus N` without a launcher stops its rank processes")
@@ -682,10 +733,20 @@ def stub_rank(args, world, rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
         dist.barrier()
+    # the legs' end-of-leg reduction (MAX of times, SUM of counts in ONE collective) and the self-play shards of both scaling forms, as the ranks see them
+    from gomokuai_amd.selfplay import shard
+    times, counts = reduce_leg(torch, torch.device("cpu"), world > 1, [1.0 + rank, 0.25], [rank + 1, 10])
+    weak_total = args.selfplay_games_per_gpu * world
+    mine = {"strong": shard(args.selfplay_games, rank, world), "weak": shard(weak_total, rank, world)}
+    _, shard_games = reduce_leg(torch, torch.device("cpu"), world > 1, [], [mine["strong"][1], mine["weak"][1]])
     if rank == 0:
         print(json.dumps({"metric": "board-evals/s", "value": args.boards * world * args.steps / elapsed, "unit": "board-evals/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "stub",
+                          "reduce_leg": {"times_max": times, "counts_sum": counts},
+                          "selfplay_pipeline": {"strong_total": args.selfplay_games, "weak_total": weak_total, "games_over_all_shards": {"strong": shard_games[0], "weak": shard_games[1]},
+                                                "rank0_shard": {"strong": list(mine["strong"]), "weak": list(mine["weak"])},
+                                                "rehearsal_games": args.selfplay_games // args.selfplay_rehearsal_ranks if world == 1 and args.selfplay_rehearsal_ranks > 1 else None},
                           "config": {"workload": "launcher self-test (--stub): no kernel ran"}}))
     if world > 1:
         dist.destroy_process_group()
@@ -843,9 +904,14 @@ def main():
     if args.rave_games > 0:
         rave = bench_rave(args, G, torch, dev, rank, world, distributed)
 
-    az = None
+    az = az_error = None
     if args.az_games > 0:
-        az = bench_az(args, G, torch, dev, rank, world, distributed)
+        try:
+            az = bench_az(args, G, torch, dev, rank, world, distributed)
+        except Exception as exc:                                  # noqa: BLE001
+            az_error = "%s: %s" % (type(exc).__name__, exc)
+        if not all_ranks_ok(az_error is None, torch, dev, distributed) and az_error is None:
+            az, az_error = None, "LegFailed: the leg failed on another rank"
 
     pipeline = pipeline_error = None
     if args.selfplay_games >= world:                            # every rank needs a game (the same decision on all ranks: the leg has barriers)
@@ -867,6 +933,10 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            # every untimed launch of the step ahead of the timed region: the table upload (1), with --settle-ms > 0 the cold measurement (W, the graph's
+            # upload replay K, its K timed steps -- reported as roofline.without_settling) and the settle launches, then the W warm-up steps and the graph's upload replay
+            "warmup_effective": 1 + (args.warmup + (args.steps if graph is not None else 0) + args.steps + settle["launches"] if args.settle_ms > 0 else 0)
+                                + args.warmup + (args.steps if graph is not None else 0),
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -903,8 +973,8 @@ def main():
             out["supervisor_pipeline"] = sup_pipeline if sup_pipeline is not None else {"error": sup_error}
         if rave is not None:
             out["poolrave"] = rave
-        if az is not None:
-            out["network_guided"] = az
+        if az is not None or az_error is not None:
+            out["network_guided"] = az if az is not None else {"error": az_error}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.kind)
             if mcts is not None:

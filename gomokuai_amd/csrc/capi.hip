@@ -1,4 +1,5 @@
 // capi.hip -- library lifecycle + pattern-table accessors of the C-ABI (include/gomoku_hip.h).
+#include <algorithm>
 #include <mutex>
 #include <cstring>
 #include <string>
@@ -35,6 +36,17 @@ struct PoolBlock { void* p; size_t bytes; bool used; };
 std::mutex g_pool_mutex;
 std::vector<PoolBlock> g_pool;
 constexpr size_t kPoolMinBytes = size_t(16) << 20, kPoolCapBytes = size_t(160) << 30;
+bool g_pool_poison = false;                                        // gmk_pool_poison: a block that is handed out again is filled with 0xA5 first
+// What may stay idle: at most kPoolCapBytes, and at most three quarters of what the device could hand out if the pool gave everything back
+// (free + idle) -- the idle blocks are invisible to every other allocator of the process (torch's caching allocator only sees "out of memory"),
+// so a quarter of the reclaimable memory (tens of GB) always stays with the driver.  (Not less: a block that goes back to the driver is cleared
+// by it when it is handed out again, 1.5 s per 24 GB, to whoever allocates next -- measured: 3.9 s on the training tuples' 2.7 GB right after
+// the pool had dropped a 70 GB arena.)
+size_t pool_idle_cap(size_t idle) {
+    size_t free_bytes = 0, total = 0;
+    if (hipMemGetInfo(&free_bytes, &total) != hipSuccess) { (void)hipGetLastError(); return kPoolCapBytes; }
+    return std::min(kPoolCapBytes, (free_bytes + idle) / 4 * 3);
+}
 size_t pool_idle_bytes() { size_t t = 0; for (const PoolBlock& b : g_pool) if (!b.used) t += b.bytes; return t; }
 void pool_drop_idle(size_t keep) {                                 // gives idle blocks back to the driver, largest first, until at most `keep` bytes idle
     while (pool_idle_bytes() > keep) {
@@ -56,7 +68,7 @@ hipError_t device_malloc_bytes(void** p, size_t bytes) {
     if (best != g_pool.size()) {
         g_pool[best].used = true;
         *p = g_pool[best].p;
-        if (kProfileBuild && profile_env("GMK_POOL_POISON")) return hipMemset(*p, 0xA5, g_pool[best].bytes);      // diagnostic: a reused block is NOT zero
+        if (g_pool_poison || (kProfileBuild && profile_env("GMK_POOL_POISON"))) return hipMemset(*p, 0xA5, g_pool[best].bytes);      // diagnostic: a reused block is NOT zero
         return hipSuccess;
     }
     hipError_t e = hipMalloc(p, bytes);
@@ -77,7 +89,7 @@ hipError_t device_free(void* p) {
             if (b.p == p) {
                 (void)hipDeviceSynchronize();                      // as hipFree would: nothing may still be running on the block when the next handle gets it
                 b.used = false;
-                pool_drop_idle(kPoolCapBytes);
+                pool_drop_idle(pool_idle_cap(pool_idle_bytes()));
                 return hipSuccess;
             }
     }
@@ -87,6 +99,10 @@ hipError_t device_free(void* p) {
 void device_pool_release() {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     pool_drop_idle(0);
+}
+void device_pool_poison(bool on) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool_poison = on;
 }
 }  // namespace gmk
 
@@ -120,6 +136,11 @@ extern "C" int gmk_init(int device) {
 
 extern "C" int gmk_pool_release(void) {
     gmk::device_pool_release();
+    return GMK_OK;
+}
+
+extern "C" int gmk_pool_poison(int on) {
+    gmk::device_pool_poison(on != 0);
     return GMK_OK;
 }
 

@@ -43,6 +43,7 @@ constexpr bool kProfileBuild = false;
 hipError_t device_malloc_bytes(void** p, size_t bytes);
 hipError_t device_free(void* p);
 void device_pool_release();
+void device_pool_poison(bool on);
 template <class T>
 inline hipError_t device_malloc(T** p, size_t bytes) { return device_malloc_bytes(reinterpret_cast<void**>(p), bytes); }
 

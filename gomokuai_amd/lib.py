@@ -34,7 +34,7 @@ NOISE_SAMPLERS = {"std": 0, "counter": 1}      # std::gamma_distribution on the 
 
 # every symbol include/gomoku_hip.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
-    "gmk_init", "gmk_shutdown", "gmk_pool_release", "gmk_last_error", "gmk_device_info",
+    "gmk_init", "gmk_shutdown", "gmk_pool_release", "gmk_pool_poison", "gmk_last_error", "gmk_device_info",
     "gmk_tables_info", "gmk_tables_pattern", "gmk_tables_copy", "gmk_tables_copy_dat", "gmk_tables_scan",
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
@@ -149,6 +149,11 @@ def _check(rc):
 
 def init(device=0):
     _check(load().gmk_init(device))
+
+
+def pool_poison(on=True):
+    """Diagnostic: reused device blocks of the library's pool are filled with 0xA5 before the next handle gets them (gmk_pool_poison)."""
+    _check(load().gmk_pool_poison(1 if on else 0))
 
 
 def release_pool():

@@ -42,9 +42,14 @@ enum { GMK_BOARD_CELLS = 225, GMK_PLANE_WORDS = 16, GMK_TOTALS = 11 };
 int gmk_init(int device);                 /* builds the pattern automaton on the host and uploads it */
 int gmk_shutdown(void);
 /* Large device blocks (the tree arenas: tens of GB per handle) that a destroyed handle gives up are kept by the library for the next handle
- * (the driver clears memory before it hands it out again: seconds per 24 GB); at most 160 GB idle.  This returns the idle ones to the
+ * (the driver clears memory before it hands it out again: seconds per 24 GB); at most 160 GB idle, and never more than three quarters of what the
+ * device could hand out if the pool gave everything back (the idle blocks are invisible to other allocators of the process).  This returns the idle ones to the
  * driver, e.g. before another allocator in the process needs the memory; gmk_shutdown does it too. */
 int gmk_pool_release(void);
+/* Diagnostic switch of that pool (off by default): a block that is handed out again is first filled with 0xA5, so that a kernel which reads a
+ * node nobody wrote since meets garbage instead of the previous handle's (plausible) tree.  The pool never clears a block otherwise: the driver's
+ * clear is 1.5 s per 24 GB, and no kernel reads what it has not written -- tests/test_pool_gpu.py searches on poisoned blocks to hold that. */
+int gmk_pool_poison(int on);
 const char *gmk_last_error(void);
 int gmk_device_info(int *cu_count, size_t *hbm_bytes, char *name, int name_cap);
 

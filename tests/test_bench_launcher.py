@@ -27,6 +27,21 @@ def test_gpus_flag_starts_that_many_ranks(n):
     assert out["n_gpus"] == n and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_selfplay_scaling_flags_and_leg_reduction_over_gloo(n):
+    """--selfplay-games (the strong form: games IN TOTAL), --selfplay-games-per-gpu (the weak form) and --selfplay-rehearsal-ranks (one GPU: the shard a
+    rank gets at that N), as n ranks see them, and the one-collective reduction that ends a leg (MAX of the times, SUM of the counts) over gloo."""
+    r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--stub", "--selfplay-games", "1000", "--selfplay-games-per-gpu", "300", "--selfplay-rehearsal-ranks", "8"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["reduce_leg"] == {"times_max": [float(n), 0.25], "counts_sum": [n * (n + 1) // 2, 10 * n]}
+    sp = out["selfplay_pipeline"]
+    assert sp["strong_total"] == 1000 and sp["weak_total"] == 300 * n
+    assert sp["games_over_all_shards"] == {"strong": 1000, "weak": 300 * n}          # every game on exactly one rank, in both forms
+    assert sp["rank0_shard"]["strong"] == [0, 1000 // n] and sp["rank0_shard"]["weak"] == [0, 300]
+    assert sp["rehearsal_games"] == (125 if n == 1 else None)
+
+
 def test_launcher_world_size_must_match_gpus():
     r = _run(["--gpus", "2", "--stub"], env={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
