@@ -87,6 +87,14 @@ __device__ __forceinline__ __attribute__((address_space(3))) uint32_t* lds_word_
     return reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(byte_address));
 }
 
+// (table word & 0x3FF3) | (four & 12) for four < 16: the lookup address of a DFA step as ONE v_bfi_b32 (written out: the compiler turns the
+// expression back into a shift, a mask and an and-or)
+__device__ __forceinline__ uint32_t dfa_address(uint32_t table_word, uint32_t four) {
+    uint32_t addr;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr) : "s"(0x3FF3u), "v"(table_word), "v"(four));
+    return addr;
+}
+
 __device__ __forceinline__ void wave_phase_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -95,12 +103,13 @@ __device__ __forceinline__ void wave_phase_fence() {
 
 // Score deposits of one match (Evaluator::Updater::updatePatterns, Pattern.cpp:138-165).  w0 / w1: emission
 // record words (pattern_tables.h).  cell_at = cell of the symbol the transition consumed.
-__device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell_at, int dir, int stride,
+// back_step = -stride: the cells of a match lie behind the symbol that ended it, one multiply-add each.
+__device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell_at, int dir, int back_step,
                                               uint32_t* s_scores, uint32_t* s_cnt, uint32_t* s_misc) {
     const int type = w0 & 15, fav = (w0 >> 4) & 1;
     if (type == 8) { atomicOr(&s_misc[1], fav ? 1u : 2u); return; }                 // Five: winner only (Pattern.cpp:140-145)
     atomicAdd(&s_misc[4 + type], fav ? 0x10000u : 1u);                              // totals row (Pattern.cpp:147, 390-393)
-    const int endcell = cell_at - static_cast<int>((w0 >> 27) & 1u) * stride;
+    const int endcell = cell_at + static_cast<int>((w0 >> 27) & 1u) * back_step;
     const uint32_t score = dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu);                  // int(1.2 * score) on diagonals (Pattern.cpp:151-152)
     // Group(favour, favour) is the owner's view, Group(favour, -favour) the opponent's (Pattern.h:159-161): '_' adds the score to both,
     // '^' to the opponent's only.  The two views of a cell are one 64-bit word of the block (white: own low / opp high, black: opp low /
@@ -116,7 +125,7 @@ __device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell
     for (int d = 0; d < 4; ++d) {
         if (d >= n_dep) break;
         const uint32_t f = (w0 >> (11 + 4 * d)) & 15u;
-        const int c = endcell - static_cast<int>(f & 7u) * stride;
+        const int c = endcell + static_cast<int>(f & 7u) * back_step;
         const bool both = (f & 8u) != 0u;                                           // '_'
         atomicAdd(&pair[2 * c], (static_cast<unsigned long long>(both ? score : hi_opp) << 32) | (both ? score : lo_opp));
         if (both && feeds) atomicAdd(&cnt[c], one);
@@ -450,8 +459,10 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 uint64_t syms = line_symbols(s_lines[(job_a >> 20) & 127u], len_a);
                 syms |= line_symbols(s_lines[(job_b >> 20) & 127u], len_b) << (2 * len_a + 6);
                 syms |= 0xAAAAAAAAAAAAAAAAull << (2 * (len_a + len_b) + 12);
-                uint32_t cur = static_cast<uint32_t>(syms) << 2;    // symbols 0..14 at bits 2..31
-                const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2..
+                // The stream is kept shifted left by 2: symbol s at bits 2 s + 2, so that the four bits from 2 s up are (symbol s - 1, symbol s) and
+                // one v_bfe + one v_bfi make the lookup address: (table word & 0x3FF3) | (those four bits & 12) -- the row offsets are multiples of 16.
+                const uint32_t cur = static_cast<uint32_t>(syms) << 2;        // symbols 0..14 at bits 2..31
+                const uint32_t rest = static_cast<uint32_t>(syms >> 28);      // symbols 15.. at bits 2.. (bits 0, 1: symbol 14)
                 uint32_t tw = 0;                                    // the previous step's table word (row 0 = root)
                 // The emission of step s is queued BEHIND the lookup of step s + 1 (the next address needs the table word only): the
                 // prefix count and the queue write then run in the shadow of that lookup's LDS round trip.  A queue entry is the table
@@ -459,7 +470,9 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 // Where the queue stands is a byte address kept by the scalar unit; a lane adds its prefix count (the vector unit is
                 // what this kernel is bound by: 4 cycles per wave-instruction on a SIMD whatever the lanes do).
                 const uint32_t q_base = static_cast<uint32_t>(s_queue - lds) * 4u;     // (the kernel's LDS starts at address 0)
-                const uint32_t q_last = q_base + 4u * (kQueueCap - 1);
+                // The scalar unit keeps the fill level at most 64 entries below the capacity: a step's (at most 64) entries then fit whatever the
+                // lanes add, without a per-lane clamp (a vector instruction per step); a board that gets there is flagged below.
+                const uint32_t q_full = q_base + 4u * (kQueueCap - 64);
                 uint32_t q_at = q_base;                             // wave-uniform
                 auto push = [&](uint32_t word, int step) {
                     const bool emits = word > 0x1FFFFu;
@@ -467,24 +480,22 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     if (emitters) {
                         if (emits) {
                             const uint32_t ahead = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(emitters >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(emitters), 0u));
-                            // (beyond the capacity every entry lands on the last slot: the board is flagged below)
-                            *lds_word_rw(min(q_at + 4u * ahead, q_last)) = (word & ~0x1FFFFu) | (static_cast<uint32_t>(lane) | static_cast<uint32_t>(step) << 6);
+                            *lds_word_rw(q_at + 4u * ahead) = (word & ~0x1FFFFu) | (static_cast<uint32_t>(lane) | static_cast<uint32_t>(step) << 6);
                         }
-                        q_at += 4u * static_cast<uint32_t>(__popcll(emitters));
+                        q_at = min(q_at + 4u * static_cast<uint32_t>(__popcll(emitters)), q_full);
                     }
                 };
 #pragma unroll
                 for (int step = 0; step < kScanSteps; ++step) {
-                    if (step == 15) cur = rest;
-                    const uint32_t addr = (tw & 0x3FFFu) | (cur & 12u);
-                    cur >>= 2;
+                    const uint32_t four = step < 15 ? __builtin_amdgcn_ubfe(cur, 2 * step, 4) : __builtin_amdgcn_ubfe(rest, 2 * (step - 15), 4);
+                    const uint32_t addr = dfa_address(tw, four);
                     const uint32_t before = tw;
                     tw = *lds_word(addr);                       // (the table is at LDS address 0: the address is used as it is)
                     if (step > 0) push(before, step - 1);
                 }
                 push(tw, kScanSteps - 1);
                 n_queued = static_cast<int>((q_at - q_base) >> 2);
-                if (n_queued > kQueueCap) { s_misc[2] = 1; n_queued = kQueueCap; }
+                if (q_at >= q_full) s_misc[2] = 1;                  // (flagged at kQueueCap - 64 entries: 2.5 x the most a board of the test sets queues)
             }
             wave_phase_fence();
             GMK_STAMP(2);
@@ -506,8 +517,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     const int pos = src_step - 1 - (second ? seg_a : 0);
                     const int dir = (job >> 5) & 3, stride = (job >> 7) & 31;
                     const int cell_at = static_cast<int>((job >> 12) & 255u) + pos * stride;
-                    deposit_match(rec_now.x, rec_now.y, cell_at, dir, stride, s_scores, s_cnt, s_misc);
-                    if (rec_now.z) deposit_match(rec_now.z, rec_now.w, cell_at, dir, stride, s_scores, s_cnt, s_misc);
+                    deposit_match(rec_now.x, rec_now.y, cell_at, dir, -stride, s_scores, s_cnt, s_misc);
+                    if (rec_now.z) deposit_match(rec_now.z, rec_now.w, cell_at, dir, -stride, s_scores, s_cnt, s_misc);
                 }
             }
             wave_phase_fence();
@@ -632,12 +643,11 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                         // six '?' | cells | six '?', then the 13 symbols starting six before q
                         const uint64_t syms = (0xAAAull | (static_cast<uint64_t>(s_lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
                         const int start = k > 7 ? k - 7 : 0;
-                        uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2, tw = 0;      // kept shifted left by 2 as in phase 1
+                        const uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2;      // kept shifted left by 2 as in phase 1
+                        uint32_t tw = 0;
     #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            if (start + i <= k) tw = *lds_word((tw & 0x3FFFu) | (cur & 12u));
-                            cur >>= 2;
-                        }
+                        for (int i = 0; i < 8; ++i)
+                            if (start + i <= k) tw = *lds_word(dfa_address(tw, __builtin_amdgcn_ubfe(cur, 2 * i, 4)));      // v_bfe + v_bfi, as in phase 1
                         if ((gmk::dev_trans_kinds(tw) >> tslot) & 1u) {                     // the record holds the wanted type
                             const uint4 rec = s_rec[gmk::dev_trans_record(tw)];
                             hit_back = counter_match(rec.x, k, want);
@@ -688,10 +698,13 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
 #else
 #define GMK_STORE(p, v) __builtin_nontemporal_store(v, p)       // (non-temporal: 0.1575 -> 0.1543 ms)
 #endif
-                GMK_STORE(dst, v0.x); GMK_STORE(dst + kCells, v0.y); GMK_STORE(dst + 2 * kCells, v0.z); GMK_STORE(dst + 3 * kCells, v0.w);
-                GMK_STORE(dst + 64, v1.x); GMK_STORE(dst + 64 + kCells, v1.y); GMK_STORE(dst + 64 + 2 * kCells, v1.z); GMK_STORE(dst + 64 + 3 * kCells, v1.w);
-                GMK_STORE(dst + 128, v2.x); GMK_STORE(dst + 128 + kCells, v2.y); GMK_STORE(dst + 128 + 2 * kCells, v2.z); GMK_STORE(dst + 128 + 3 * kCells, v2.w);
-                if (lane_b + 192 < kCells) { GMK_STORE(dst + 192, v3.x); GMK_STORE(dst + 192 + kCells, v3.y); GMK_STORE(dst + 192 + 2 * kCells, v3.z); GMK_STORE(dst + 192 + 3 * kCells, v3.w); }
+                // in ADDRESS order (the board's 3 600 bytes are one contiguous run: piece after piece, so that the two parts of a cache line that two
+                // pieces share reach the L2 back to back)
+                const bool tail = lane_b + 192 < kCells;
+                GMK_STORE(dst, v0.x); GMK_STORE(dst + 64, v1.x); GMK_STORE(dst + 128, v2.x); if (tail) GMK_STORE(dst + 192, v3.x);
+                GMK_STORE(dst + kCells, v0.y); GMK_STORE(dst + kCells + 64, v1.y); GMK_STORE(dst + kCells + 128, v2.y); if (tail) GMK_STORE(dst + kCells + 192, v3.y);
+                GMK_STORE(dst + 2 * kCells, v0.z); GMK_STORE(dst + 2 * kCells + 64, v1.z); GMK_STORE(dst + 2 * kCells + 128, v2.z); if (tail) GMK_STORE(dst + 2 * kCells + 192, v3.z);
+                GMK_STORE(dst + 3 * kCells, v0.w); GMK_STORE(dst + 3 * kCells + 64, v1.w); GMK_STORE(dst + 3 * kCells + 128, v2.w); if (tail) GMK_STORE(dst + 3 * kCells + 192, v3.w);
 #undef GMK_STORE
             }
             if (out_totals && lane_b < 11) out_totals[static_cast<size_t>(board) * 11 + lane_b] = s_misc[4 + lane_b];
