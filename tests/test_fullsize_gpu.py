@@ -225,23 +225,26 @@ def test_k1_8192_dense_boards(oracle):
     assert _mismatching_boards(ref, got) == {"scores": 0, "density": 0, "totals": 0, "status": 0}
 
 
-# ---- extended sweeps (GMK_EXTENDED=1): more of the same differential runs on other boards, games and seeds; not part of the default
-#      suite (minutes of oracle time), run by hand on the GPU box after a kernel change ----
+# ---- extended sweeps: more of the same differential runs on other boards, games and seeds.  The FIRST case of every sweep is part of the default
+#      suite (one more set of 65 536 boards, one more K3 / K6 / K8 batch); the others (minutes of oracle time) run with GMK_EXTENDED=1, by hand on
+#      the GPU box after a kernel change ----
 import os
 
 extended = pytest.mark.skipif(not os.environ.get("GMK_EXTENDED"), reason="extended sweep: set GMK_EXTENDED=1")
 
 
-@extended
-@pytest.mark.parametrize("kind,first", [(0, 65536), (1, 65536), (0, 1 << 20), (1, 1 << 20), (0, 7777777), (1, 7777777)])
+def _first_by_default(cases):
+    return [cases[0]] + [pytest.param(*c, marks=extended) for c in cases[1:]]
+
+
+@pytest.mark.parametrize("kind,first", _first_by_default([(0, 65536), (1, 65536), (0, 1 << 20), (1, 1 << 20), (0, 7777777), (1, 7777777)]))
 def test_extended_k1_other_boards(oracle, kind, first):
     n = 65536
     moves, lens, planes = G.synth_boards(n, kind, first_board=first)
     assert _mismatching_boards(oracle.replay_batch(moves, lens), G.eval_batch_host(planes)) == {"scores": 0, "density": 0, "totals": 0, "status": 0}
 
 
-@extended
-@pytest.mark.parametrize("seed,first,plies,playouts", [(1, 100000, 0, 800), (2, 5000000, 9, 500), (0xDEADBEEF, 31, 30, 300), (77, 1 << 30, 60, 200)])
+@pytest.mark.parametrize("seed,first,plies,playouts", _first_by_default([(1, 100000, 0, 800), (2, 5000000, 9, 500), (0xDEADBEEF, 31, 30, 300), (77, 1 << 30, 60, 200)]))
 def test_extended_k3_other_games_and_seeds(oracle, seed, first, plies, playouts):
     n = 128
     moves, lens, _ = G.synth_boards(n, 0, first_board=first)
@@ -264,8 +267,7 @@ def test_extended_k3_other_games_and_seeds(oracle, seed, first, plies, playouts)
     tree.close()
 
 
-@extended
-@pytest.mark.parametrize("first,kind,playouts", [(9000, 1, 2500), (123456, 0, 2500), (424242, 1, 4000)])
+@pytest.mark.parametrize("first,kind,playouts", _first_by_default([(9000, 1, 2500), (123456, 0, 2500), (424242, 1, 4000)]))
 def test_extended_k6_other_positions(oracle, first, kind, playouts):
     n = 28
     moves, lens, _ = G.synth_boards(n, kind, first_board=first)
@@ -283,8 +285,7 @@ def test_extended_k6_other_positions(oracle, first, kind, playouts):
     t.close()
 
 
-@extended
-@pytest.mark.parametrize("first,gid", [(1000, 0), (888888, 70000)])
+@pytest.mark.parametrize("first,gid", _first_by_default([(1000, 0), (888888, 70000)]))
 def test_extended_k8_other_games(oracle, first, gid):
     n, P = 64, 2000
     moves, lens, _ = G.synth_boards(n, 0, first_board=first)
