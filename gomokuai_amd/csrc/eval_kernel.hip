@@ -5,25 +5,32 @@
 // scores[4][225], density[2][2][225], pattern / compound totals and winner.  The formulation is the one
 // validated against in-order replay in tests/test_formulation.py.
 //
-// The binding resources are the SIMDs' issue slots and the LDS round trips of a board's dependent chains (rocprofv3 PMC: a wavefront
-// issues 37 %, waits 42 % and is issue-stalled 21 % of its time; HBM traffic = 1.06 x the algorithmic bytes), with 16 boards of LDS
-// per CU.  So: few wave-instructions per board, few dependent LDS round trips, and the one dense piece on the matrix cores:
+// What binds it (rocprofv3 PMC of the round-4 build, profiles/r04_k1_*): 842 vector, 356 scalar and 142 LDS wave-instructions per board; a wave64
+// vector instruction occupies its SIMD for 4 cycles whatever it does (tools/valu_probe.hip), so the vector units are ~75 % and the LDS pipe ~60 % busy
+// (41 % of its cycles bank conflicts) with sixteen boards of LDS per CU; HBM traffic = 1.05 x the algorithmic bytes.  Neither the store path nor
+// HBM bandwidth is the limit (tools/store_probe.hip): instructions and dependent LDS round trips are.  So: few wave-instructions per board, few
+// dependent round trips, and the one dense piece on the matrix cores:
 //   * one 64-lane wavefront per board, sixteen boards in flight per 1024-thread workgroup (one workgroup per CU); the automaton
 //     (dense DFA 556x4 words + emission records, ~14 KB) is staged at LDS address 0 ONCE per workgroup, so a DFA step's address is
-//     just (next-row offset | symbol * 4); after that single barrier the waves never wait for each other (phases of one board are
-//     ordered by wavefront-scope fences only).  A wavefront takes groups of SIXTEEN consecutive boards;
+//     just (next-row offset | symbol * 4): one v_bfe + one v_bfi; after that single barrier the waves never wait for each other (phases of one
+//     board are ordered by wavefront-scope fences only).  A workgroup owns a contiguous run of groups of SIXTEEN boards and hands its boards
+//     (and the density bursts of its groups) out one at a time from counters in LDS;
 //   * phase 0: the two bit-planes become 88 "line words" (rows, columns, both diagonals) that already hold the 2-bit
 //     DFA symbols of their cells (one LDS XOR per stone and line); where a colour's density count is positive (the area
-//     bonus) comes from the rows dilated by the three row patterns of the 7x7 mask, with DPP row shifts;
+//     bonus) comes from the rows dilated by the three row patterns of the 7x7 mask, with DPP row shifts; the score block -- [cell][4 groups] in
+//     LDS -- is written ONCE, with the bonus in it;
 //   * phase 1: the 72 lines that can hold a pattern (>= 5 cells) are spread over the 64 lanes (the 8 shortest ride
 //     behind the shortest primaries: 19 steps per lane, fully unrolled); a lane's lines are one stream of 2-bit symbols,
-//     a step is one LDS lookup; emitting transitions are queued by ballot prefix, in the shadow of the next step's lookup;
+//     a step is one LDS lookup; emitting transitions are queued by ballot prefix, in the shadow of the next step's lookup (the queue's fill
+//     level lives on the scalar unit, clamped there: no per-lane bounds check);
 //   * phase 2: one lane per queued transition: one 16-byte record read gives the (<= 2) matches, each with a
-//     compact list of <= 4 score deposits (ds_add_u32) and 4-bit per-(cell, colour, direction, type) counters;
-//   * phase 3: one lane per cell: area bonus, compound candidates from the counters; phase 3b: one lane per (candidate, colour):
-//     the density gate "count >= 2" from seven row popcounts, the compound state machine, +-600 deposits;
+//     compact list of <= 4 score deposits -- a colour's own and opponent view of a cell are the halves of one 64-bit word, so a deposit is ONE
+//     ds_add_u64 whose value decides -- and 4-bit per-(cell, colour, direction, type) counters;
+//   * phase 3: one lane per cell: compound candidates from the counters; phase 3b: one lane per (candidate, colour):
+//     the density gate "count >= 2" from seven row popcounts, the compound decision in closed form (components n, threes s), +-600 deposits;
 //   * phase 4: eight lanes per compound component: its counter-move cells from the 13-symbol window around it;
-//   * phase 5: the 3.6 KB score block leaves LDS as coalesced 16-byte stores;
+//   * phase 5: the 3.6 KB score block leaves LDS transposed to [group][cell]: sixteen non-temporal dword stores of 256 contiguous bytes, in
+//     ADDRESS order (the two parts of a cache line that two pieces share reach the L2 back to back);
 //   * phase D, once per group, in the board iteration that is the wavefront's turn within its workgroup: the density planes of the
 //     sixteen boards on the matrix cores -- Out[board, colour][cell] = Stone[board, colour][cell'] * W[cell'][cell], the stones as
 //     the A operand and the constant banded weight matrix (rows of a 6 KB table in LDS) as the B operand of

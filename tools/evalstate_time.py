@@ -21,4 +21,5 @@ for _ in range(reps):
     L.gmk_evalstate_update(e.h, d.data_ptr(), k, 0); L.gmk_evalstate_update(e.h, back.data_ptr(), k, 0)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
 ups = 2 * (scr >= 0).sum(1).mean()
+print("K2-UPDATES-PER-LAUNCH %d" % int((scr >= 0).sum()))                     # (apply or revert: what tools/pmc_k2_phases.sh normalises its counters by)
 print("K2: %d games x %.1f updates (apply, then revert) in %.3f ms -> %.2f us per update per game (%d games per launch), %.1f M updates/s" % (n, ups, dt * 1e3, dt * 1e6 / ups, n, n * ups / dt / 1e6))

@@ -16,7 +16,11 @@ for p in glob.glob("gpurun_out/pmc_k2p/m_%s/**/*counter_collection.csv" % m, rec
     for r in csv.DictReader(open(p)):
         if "evalstate_update" in r["Kernel_Name"]:
             v[r["Counter_Name"]].append(float(r["Counter_Value"]))
-upd = 2048 * 59.5 / 2          # updates per launch of tools/evalstate_time.py (apply or revert)
+upd = None                      # updates per launch (apply or revert), as tools/evalstate_time.py printed it for THIS run (its game count has changed before)
+for line in open("gpurun_out/pmc_k2p/run_%s.log" % m):
+    if line.startswith("K2-UPDATES-PER-LAUNCH"):
+        upd = float(line.split()[1])
+assert upd, "tools/evalstate_time.py did not print its update count"
 print("mask %3s  %s | per update: " % (m, sys.argv[2]) + " ".join("%s %.1f" % (k[3:], sum(x) / len(x) / upd) for k, x in sorted(v.items())))
 PY
   rm -rf $out/m_$m
