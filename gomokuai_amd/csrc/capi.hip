@@ -32,10 +32,11 @@ extern "C" const char* gmk_last_error(void) { return gmk::g_error; }
 
 namespace gmk {
 namespace {
-struct PoolBlock { void* p; size_t bytes; bool used; };
+struct PoolBlock { void* p; size_t bytes; bool used; unsigned long long freed_at; };      // freed_at: a tick of the pool's clock when the block went idle
+unsigned long long g_pool_clock = 0;
 std::mutex g_pool_mutex;
 std::vector<PoolBlock> g_pool;
-constexpr size_t kPoolMinBytes = size_t(16) << 20, kPoolCapBytes = size_t(160) << 30;
+constexpr size_t kPoolMinBytes = size_t(16) << 20, kPoolCapBytes = size_t(224) << 30;
 bool g_pool_poison = false;                                        // gmk_pool_poison: a block that is handed out again is filled with 0xA5 first
 // What may stay idle: at most kPoolCapBytes, and at most three quarters of what the device could hand out if the pool gave everything back
 // (free + idle) -- the idle blocks are invisible to every other allocator of the process (torch's caching allocator only sees "out of memory"),
@@ -48,10 +49,10 @@ size_t pool_idle_cap(size_t idle) {
     return std::min(kPoolCapBytes, (free_bytes + idle) / 4 * 3);
 }
 size_t pool_idle_bytes() { size_t t = 0; for (const PoolBlock& b : g_pool) if (!b.used) t += b.bytes; return t; }
-void pool_drop_idle(size_t keep) {                                 // gives idle blocks back to the driver, largest first, until at most `keep` bytes idle
-    while (pool_idle_bytes() > keep) {
+void pool_drop_idle(size_t keep) {                                 // gives idle blocks back to the driver, the longest-idle first, until at most `keep` bytes idle
+    while (pool_idle_bytes() > keep) {                             // (what was freed last is what the next handle is most likely to ask for again)
         size_t at = g_pool.size();
-        for (size_t i = 0; i < g_pool.size(); ++i) if (!g_pool[i].used && (at == g_pool.size() || g_pool[i].bytes > g_pool[at].bytes)) at = i;
+        for (size_t i = 0; i < g_pool.size(); ++i) if (!g_pool[i].used && (at == g_pool.size() || g_pool[i].freed_at < g_pool[at].freed_at)) at = i;
         if (at == g_pool.size()) return;
         (void)hipFree(g_pool[at].p);
         g_pool.erase(g_pool.begin() + static_cast<long>(at));
@@ -77,7 +78,7 @@ hipError_t device_malloc_bytes(void** p, size_t bytes) {
         pool_drop_idle(0);
         e = hipMalloc(p, bytes);
     }
-    if (e == hipSuccess) g_pool.push_back(PoolBlock{*p, bytes, true});
+    if (e == hipSuccess) g_pool.push_back(PoolBlock{*p, bytes, true, 0ull});
     return e;
 }
 
@@ -89,6 +90,7 @@ hipError_t device_free(void* p) {
             if (b.p == p) {
                 (void)hipDeviceSynchronize();                      // as hipFree would: nothing may still be running on the block when the next handle gets it
                 b.used = false;
+                b.freed_at = ++g_pool_clock;
                 pool_drop_idle(pool_idle_cap(pool_idle_bytes()));
                 return hipSuccess;
             }

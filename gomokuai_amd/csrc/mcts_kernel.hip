@@ -914,19 +914,32 @@ static int pair_arenas(gmk_mcts* m) {
     return GMK_OK;
 }
 
+static int one_arena(gmk_mcts* m) {
+    if (m->d_stats) return GMK_OK;
+    const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
+    if (gmk::device_malloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess || gmk::device_malloc(&m->d_link, nodes * 4) != hipSuccess ||
+        gmk::device_malloc(&m->d_parent, nodes * 4) != hipSuccess) {
+        (void)gmk::device_free(m->d_stats); (void)gmk::device_free(m->d_link); (void)gmk::device_free(m->d_parent);
+        m->d_stats = nullptr; m->d_link = nullptr; m->d_parent = nullptr;
+        (void)hipGetLastError();
+        gmk::set_error("gmk_mcts: hipMalloc of %zu nodes (%.1f GB) failed", nodes, nodes * 16.0 / 1e9);
+        return GMK_ERR_HIP;
+    }
+    return GMK_OK;
+}
+
+// The handle's tree arenas, now: one arena per game (what gmk_mcts_set_roots would allocate at its first call) or, two_arenas != 0, the two
+// arenas per game of the persistent loop with kept subtrees (what gmk_selfplay_run would).  For callers that want the allocation -- tens of GB; the
+// driver clears memory it has handed out before, seconds per 24 GB -- outside a region they time, or want the blocks in the library's pool
+// before a batch starts (create, reserve, destroy: the next handle of that shape finds them there).
+extern "C" int gmk_mcts_reserve(gmk_mcts* m, int two_arenas) {
+    if (!m) { gmk::set_error("gmk_mcts_reserve: bad arguments"); return GMK_ERR_ARG; }
+    return two_arenas ? pair_arenas(m) : one_arena(m);
+}
+
 extern "C" int gmk_mcts_set_roots(gmk_mcts* m, const uint16_t* h_planes, const int16_t* h_last_move, uint32_t first_game_id) {
     if (!m || !h_planes || !h_last_move) { gmk::set_error("gmk_mcts_set_roots: bad arguments"); return GMK_ERR_ARG; }
-    if (!m->d_stats) {                                              // the first roots of this handle: its tree arena
-        const size_t nodes = static_cast<size_t>(m->n_games) * static_cast<size_t>(m->node_capacity);
-        if (gmk::device_malloc(&m->d_stats, nodes * sizeof(uint2)) != hipSuccess || gmk::device_malloc(&m->d_link, nodes * 4) != hipSuccess ||
-            gmk::device_malloc(&m->d_parent, nodes * 4) != hipSuccess) {
-            (void)gmk::device_free(m->d_stats); (void)gmk::device_free(m->d_link); (void)gmk::device_free(m->d_parent);
-            m->d_stats = nullptr; m->d_link = nullptr; m->d_parent = nullptr;
-            (void)hipGetLastError();
-            gmk::set_error("gmk_mcts_set_roots: hipMalloc of %zu nodes (%.1f GB) failed", nodes, nodes * 16.0 / 1e9);
-            return GMK_ERR_HIP;
-        }
-    }
+    if (const int rc = one_arena(m); rc != GMK_OK) return rc;       // the first roots of this handle: its tree arena
     std::vector<GameHeader> hdr(static_cast<size_t>(m->n_games));
     for (int g = 0; g < m->n_games; ++g) {
         GameHeader& h = hdr[static_cast<size_t>(g)];

@@ -1047,6 +1047,13 @@ static int pair_arenas(gmk_trad* t) {
     return GMK_OK;
 }
 
+// gmk_mcts_reserve for a K6 handle: two_arenas != 0 makes the two arenas per slot of the persistent loop with kept subtrees now (the handle must
+// be positioned again afterwards); 0 is a no-op (gmk_trad_create allocates the one arena).
+extern "C" int gmk_trad_reserve(gmk_trad* t, int two_arenas) {
+    if (!t) { gmk::set_error("gmk_trad_reserve: bad arguments"); return GMK_ERR_ARG; }
+    return two_arenas ? pair_arenas(t) : GMK_OK;
+}
+
 extern "C" int gmk_trad_set_game_ids(gmk_trad* t, const uint32_t* h_ids) {
     if (!t || !h_ids) { gmk::set_error("gmk_trad_set_game_ids: bad arguments"); return GMK_ERR_ARG; }
     GMK_HIP_CHECK(hipDeviceSynchronize());

@@ -39,10 +39,10 @@ EXPORTS = [
     "gmk_synth_boards", "gmk_moves_to_planes",
     "gmk_eval_batch", "gmk_eval_batch_host", "gmk_eval_launch_info",
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_set_game_ids", "gmk_mcts_run", "gmk_mcts_root_stats",
-    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_mcts_set_option", "gmk_selfplay_run", "gmk_samples_from_records",
+    "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_mcts_set_option", "gmk_mcts_reserve", "gmk_selfplay_run", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
     "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_read_node_host", "gmk_az_read_children_host", "gmk_az_set_leaf_host", "gmk_az_rollout_host", "gmk_az_expand_stages_host", "gmk_az_write_stats_host", "gmk_az_step", "gmk_az_advance", "gmk_az_set_slots", "gmk_az_live_games", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_root_stats",
-    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_set_option", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_trad_selfplay_run", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
+    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_set_option", "gmk_trad_reserve", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_trad_selfplay_run", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
 ]
 
 
@@ -100,6 +100,8 @@ def load():
     L.gmk_selfplay_run.argtypes = [vp, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
     L.gmk_mcts_add_root_noise.argtypes = [vp, C.c_float, C.c_float, vp]
     L.gmk_mcts_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.gmk_mcts_reserve.argtypes = [vp, C.c_int]
+    L.gmk_trad_reserve.argtypes = [vp, C.c_int]
     L.gmk_evalstate_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.gmk_evalstate_destroy.argtypes = [vp]
     L.gmk_evalstate_reset.argtypes = [vp]
@@ -157,7 +159,7 @@ def pool_poison(on=True):
 
 
 def release_pool():
-    """Returns the device blocks the library keeps from destroyed handles (up to 160 GB of tree arenas) to the driver."""
+    """Returns the device blocks the library keeps from destroyed handles (up to 224 GB of tree arenas) to the driver."""
     _check(load().gmk_pool_release())
 
 
@@ -318,6 +320,10 @@ class BatchedMCTS:
         """gmk_mcts_set_option: OPT_NOISE_SAMPLER -> NOISE_SAMPLERS["std" | "counter"], OPT_LOCKSTEP -> 0 / 1."""
         _check(load().gmk_mcts_set_option(self.h, int(option), int(value)))
 
+    def reserve(self, two_arenas=False):
+        """gmk_mcts_reserve: allocate the tree arenas now (two per game for the persistent loop with kept subtrees)."""
+        _check(load().gmk_mcts_reserve(self.h, int(bool(two_arenas))))
+
     def selfplay_run(self, n_total, first_game_id, playouts, d_moves, d_visits, d_lens, d_winner, open_moves=None, open_lens=None,
                      reuse_subtree=False, root_noise=None, stream=None):
         """gmk_selfplay_run: the handle's games are slots that play n_total whole games between them (continuous batching on the
@@ -468,6 +474,10 @@ class TraditionalMCTS:
     def set_option(self, option, value):
         """gmk_trad_set_option: OPT_NOISE_SAMPLER -> NOISE_SAMPLERS["std" | "counter"], OPT_LOCKSTEP -> 0 / 1."""
         _check(load().gmk_trad_set_option(self.h, int(option), int(value)))
+
+    def reserve(self, two_arenas=False):
+        """gmk_trad_reserve: the two arenas per slot of the persistent loop with kept subtrees, now."""
+        _check(load().gmk_trad_reserve(self.h, int(bool(two_arenas))))
 
     def selfplay_run(self, n_total, first_game_id, playouts, d_moves, d_visits, d_lens, d_winner, open_moves=None, open_lens=None,
                      reuse_subtree=False, root_noise=None, seed=DEFAULT_SEED, stream=None, max_steps=0, persistent=False):

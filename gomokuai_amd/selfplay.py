@@ -112,7 +112,7 @@ def plan_games(n_games, slots="auto", handles="auto", opening_plies=0, reuse_sub
 
 def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5.0, c_rollouts=5,
                opening_plies=0, record_visits=True, reuse_subtree=False, root_noise=None, max_moves=N, device=None,
-               node_capacity=None, slots="auto", handles="auto", noise_sampler="counter", lockstep=False):
+               node_capacity=None, slots="auto", handles="auto", noise_sampler="counter", lockstep=False, prepare_only=False):
     """Plays n_games complete games on the current GPU: every move = one K3 search of `playouts` playouts for all
     unfinished games, then `gmk_mcts_advance`.  Game g uses the global id first_game_id + g for its RNG streams, so
     the records do not depend on how games are spread over GPUs, slots or handles.
@@ -125,7 +125,10 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     the next search's tree, MCTS.cpp:129-147, and Default::AddNoise runs before every search, MCTS.cpp:182).  noise_sampler: "counter" = the
     counter-based Dirichlet sampler of include/gomoku_noise.h, drawn inside the searching kernel, so that the whole run is ONE persistent launch
     (slots / handles != None); "std" = std::gamma_distribution on the host, which needs a launch boundary per move (lock step).  lockstep=True
-    forces the search-by-search loop (the form the tests hold the persistent one to)."""
+    forces the search-by-search loop (the form the tests hold the persistent one to).
+    prepare_only: create the search handles this call would create, allocate their tree arenas and give them back -- to the library's block pool,
+    where the same call without prepare_only finds them (the arenas are tens of GB, and the driver clears memory it has handed out before at seconds
+    per 24 GB: a self-play job pays that once, not per batch; a measurement keeps it out of its timed region this way).  Returns None."""
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -150,6 +153,13 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
         for tree in trees:
             tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS[noise_sampler])
             tree.set_option(G.OPT_LOCKSTEP, int(bool(lockstep)))
+        if prepare_only:
+            persistent = not lockstep and not (reuse_subtree and root_noise is not None and noise_sampler != "counter")
+            for tree in trees:
+                tree.reserve(two_arenas=reuse_subtree and persistent)
+            for tree in trees:
+                tree.close()
+            return None
 
         def run_block(i, hip_stream):
             lo, hi = blocks[i]
@@ -185,6 +195,8 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
             overflow = overflow or bool((tree.root_stats()[4] & G.BatchedMCTS.STATUS_ARENA_FULL).any())
             tree.close()
         return GameRecords(d_moves, d_lens, d_winner, d_visits, first_game_id, overflow)
+    if prepare_only:
+        return None
     planes = np.zeros((n_games, 2, 16), dtype=np.uint16)
     last = np.full(n_games, -1, dtype=np.int16)
     moves0 = np.zeros((n_games, N), dtype=np.uint8)
@@ -275,7 +287,7 @@ class _HostGames:
 
 
 def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id, opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps=0,
-                               persistent=False, noise_sampler="std"):
+                               persistent=False, noise_sampler="std", prepare_only=False):
     """play_supervisor_games with the loop resident on the device (gmk_trad_selfplay_run): the searches, MCTS::stepForward's move, the
     end-of-game check and the hand-over of a finished game's slot are kernels; the host reads four bytes per move.  Same games, same
     records as the host-driven loops below (tests/test_selfplay_gpu.py holds them to each other)."""
@@ -294,6 +306,10 @@ def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_g
     else:
         raise ValueError("play_supervisor_games: policy must be 'traditional' or 'poolrave'")
     tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS[noise_sampler])
+    if prepare_only:                                             # the arenas this run would allocate go to the library's pool (see play_games)
+        tree.reserve(two_arenas=bool(reuse_subtree and persistent))
+        tree.close()
+        return None
     d_moves = torch.zeros((n_games, N), dtype=torch.uint8, device=dev)
     d_lens = torch.zeros(n_games, dtype=torch.int32, device=dev)
     d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
@@ -309,7 +325,7 @@ def _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_g
 
 def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
                           device=None, node_capacity=None, reuse_subtree=False, root_noise=None, policy="traditional", slots=None, device_loop=True, max_steps=0,
-                          noise_sampler="counter"):
+                          noise_sampler="counter", prepare_only=False):
     """n_games complete games of the reference's self-play SUPERVISOR against itself (config.py:9-12: "traditional_mcts",
     MCTS(TraditionalPolicy) on both sides), all games side by side on the current GPU: every move = one K6 search of
     `playouts` playouts per unfinished game (the games' evaluators are kept and synchronised like the policy objects of
@@ -344,7 +360,9 @@ def play_supervisor_games(n_games, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, fi
             raise ValueError("play_supervisor_games: the persistent loop plays TraditionalPolicy games to their end, with root noise from the counter-based sampler only")
         persistent = can_persist and (device_loop == "persistent" or (device_loop is True and (n_slots < n_games or reuse_subtree)))
         return _play_supervisor_on_device(n_games, n_slots, playouts, c_puct, seed, first_game_id,
-                                          opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps, persistent, noise_sampler)
+                                          opening_plies, device, node_capacity, policy, reuse_subtree, root_noise, max_steps, persistent, noise_sampler, prepare_only)
+    if prepare_only:
+        return None
     if max_steps:
         raise ValueError("play_supervisor_games: max_steps is a switch of the device-resident loop")
     if slots is not None and slots < n_games:

@@ -42,7 +42,7 @@ enum { GMK_BOARD_CELLS = 225, GMK_PLANE_WORDS = 16, GMK_TOTALS = 11 };
 int gmk_init(int device);                 /* builds the pattern automaton on the host and uploads it */
 int gmk_shutdown(void);
 /* Large device blocks (the tree arenas: tens of GB per handle) that a destroyed handle gives up are kept by the library for the next handle
- * (the driver clears memory before it hands it out again: seconds per 24 GB); at most 160 GB idle, and never more than three quarters of what the
+ * (the driver clears memory before it hands it out again: seconds per 24 GB); at most 224 GB idle (the longest-idle blocks go first), and never more than three quarters of what the
  * device could hand out if the pool gave everything back (the idle blocks are invisible to other allocators of the process).  This returns the idle ones to the
  * driver, e.g. before another allocator in the process needs the memory; gmk_shutdown does it too. */
 int gmk_pool_release(void);
@@ -204,6 +204,11 @@ int gmk_mcts_add_root_noise(gmk_mcts *m, float alpha, float epsilon, void *strea
 enum { GMK_OPT_NOISE_SAMPLER = 1, GMK_OPT_LOCKSTEP = 2 };
 enum { GMK_NOISE_SAMPLER_STD = 0, GMK_NOISE_SAMPLER_COUNTER = 1 };
 int gmk_mcts_set_option(gmk_mcts *m, int option, int value);
+/* The handle's tree arenas, now: one arena per game (what the first gmk_mcts_set_roots allocates) or, two_arenas != 0, the two arenas per game of
+ * the persistent loop with kept subtrees (what gmk_selfplay_run allocates).  Tens of GB, and the driver clears memory it has handed out before
+ * (seconds per 24 GB): for callers that want that outside a region they time, or want the blocks in the library's pool before a batch starts
+ * (create, reserve, destroy: the next handle of that shape finds them there). */
+int gmk_mcts_reserve(gmk_mcts *m, int two_arenas);
 /* Root statistics after a run (synchronises the stream used by the last run):
  *   h_visits uint32[n][225] child visit counts by cell (MCTS::evalState, MCTS.cpp:104-110),
  *   h_root_value float[n], h_root_visits uint32[n], h_nodes uint32[n] (MCTS::m_size), h_status int32[n] (bit1: arena full). */
@@ -260,6 +265,8 @@ int gmk_trad_step(gmk_trad* t, const int16_t* h_moves);
 int gmk_trad_add_root_noise(gmk_trad* t, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id);
 /* GMK_OPT_NOISE_SAMPLER / GMK_OPT_LOCKSTEP for a K6 / K8 handle (see gmk_mcts_set_option) */
 int gmk_trad_set_option(gmk_trad* t, int option, int value);
+/* gmk_mcts_reserve for a K6 / K8 handle (two_arenas = 0: nothing to do, gmk_trad_create allocates the one arena) */
+int gmk_trad_reserve(gmk_trad* t, int two_arenas);
 /* The self-play loop of the pattern-guided searchers, resident on the device (replaces the host loop of network/data_helper.py:56-83
  * around agents/mcts.py:17-21 for config.py:9-12's supervisor): n_total games (global ids first_game_id ..) are played through the
  * handle's n_games SLOTS with continuous batching -- every move = Default::AddNoise (noise_alpha > 0; MCTS.cpp:182) + one search of
