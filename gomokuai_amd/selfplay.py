@@ -477,6 +477,11 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
     kernel per ply (gmk_az_advance) and the host sees four bytes per move (plus the root priors when root_noise is mixed in, which is a
     host step); False = the host-driven loop it replaced (numpy boards, root statistics down and moves up every ply), kept for the
     tests that compare the two.  Returns GameRecords like play_games."""
+    if slots is not None and slots < n_games and (max_moves < N or (device_loop and opening_plies > 8)):
+        # (the slot loops play whole games, the device-resident one from openings of at most 8 plies -- gmk_az_set_slots' limit: say so instead of
+        # ignoring the cap or failing inside the library; ADVICE r3)
+        raise ValueError("play_network_games: with slots, games are played to their end (max_moves >= 225)" +
+                         (" from openings of at most 8 plies on the device loop" if device_loop else "") + "; play all games at once (slots=None) for a move cap")
     G.init(torch.cuda.current_device() if device is None else device.index)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     if slots is not None and slots < n_games and device_loop:

@@ -236,3 +236,14 @@ def test_plan_games_spreads_games_over_handles_and_slots():
         selfplay.plan_games(20000, slots=100, opening_plies=12)
     with pytest.raises(ValueError):
         selfplay.plan_games(0)
+
+
+def test_network_slot_loops_refuse_what_they_would_ignore():
+    """play_network_games: the slot loops play whole games (and the device-resident one takes openings of at most 8 plies): a move cap or a longer
+    opening is refused up front, not silently ignored (no GPU needed: the check comes first)."""
+    import pytest
+    from gomokuai_amd import selfplay
+    with pytest.raises(ValueError):
+        selfplay.play_network_games(8, None, 4, slots=2, max_moves=10)
+    with pytest.raises(ValueError):
+        selfplay.play_network_games(8, None, 4, slots=2, opening_plies=12)
