@@ -306,19 +306,17 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     // layout: [trans (LDS address 0)][records (16-byte aligned)][lane jobs 128][initial line words 96][boards: kBoardsPerBlock * kBoardWords]
     const uint4* s_rec = reinterpret_cast<const uint4*>(lds + trans_words);
     uint32_t* s_jobs = lds + trans_words + record_words;
-    const uint32_t* s_line_init = s_jobs + 128;
 
     for (int i = threadIdx.x; i < trans_words; i += kThreads) lds[i] = g_trans[i];
     for (int i = threadIdx.x; i < record_words; i += kThreads) lds[trans_words + i] = g_records[i];
     if (threadIdx.x < 128) s_jobs[threadIdx.x] = c_lane_jobs[threadIdx.x];
-    if (threadIdx.x < kLineWords) s_jobs[128 + threadIdx.x] = c_line_init[threadIdx.x];
     uint2* s_lut = reinterpret_cast<uint2*>(s_jobs + 128 + kLineWords);      // byte -> its eight bits as bytes (the stone operands of phase D)
     if (threadIdx.x < 256) s_lut[threadIdx.x] = make_uint2(((threadIdx.x & 15u) * 0x204081u) & 0x01010101u, ((threadIdx.x >> 4) * 0x204081u) & 0x01010101u);
     uint32_t* s_wtab_words = s_jobs + 128 + kLineWords + 512;
     for (int i = threadIdx.x; i < kWtabWords; i += kThreads) s_wtab_words[i] = g_wtab[i];
     const v4i* s_wtab = reinterpret_cast<const v4i*>(s_wtab_words);
     uint32_t* s_handout = s_wtab_words + kWtabWords;        // [0] boards handed out, [1] density bursts handed out
-    if (threadIdx.x < 4) s_handout[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_handout[threadIdx.x] = threadIdx.x == 0 ? 2u * kBoardsPerBlock : 0u;      // (every wavefront's first two boards are its own: see below)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
     uint32_t* s_scores = lds + trans_words + record_words + kStaticTableWords + wave * kBoardWords;      // int32 scores, accumulated with ds_add
@@ -327,14 +325,16 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     uint32_t* s_queue = s_lines + kLineWords;
     uint32_t* s_misc = s_queue + kQueueCap;
 
-    __syncthreads();                                         // tables staged; from here on waves never wait for each other
+    // (no barrier here: the tables are on their way while every wavefront runs phase 0 of its first board, which needs none of them; the one
+    // barrier of the kernel stands in front of that board's phase 1)
     GMK_STAMP(0);
 
     // ---- work distribution: see the hand-out counters below ----
     const bool planes_out = out_density != nullptr && (phase_mask & 64) && !(phase_mask & 1024);
     int lane = lane0;
-    const uint32_t job_a = s_jobs[lane * 2], job_b = s_jobs[lane * 2 + 1];
-    const uint32_t line_init_lo = s_line_init[lane], line_init_hi = s_line_init[min(64 + lane, kLineWords - 1)];
+    // (from constant memory, not from their staged copies: those are not there yet)
+    const uint32_t job_a = c_lane_jobs[lane * 2], job_b = c_lane_jobs[lane * 2 + 1];
+    const uint32_t line_init_lo = c_line_init[lane], line_init_hi = c_line_init[min(64 + lane, kLineWords - 1)];
     uint32_t* s_rows = s_misc + 16;                      // row y at [3 + y]
     // the cells this lane owns in the four passes over the board (cell = 64 pass + lane): 4 x row and column, a byte per pass
     uint32_t cell_row4 = 0, cell_col = 0;
@@ -371,7 +371,9 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         if (lane0 == 0) v = atomicAdd(&s_handout[which], 1u);
         return __builtin_amdgcn_readfirstlane(static_cast<int>(v));
     };
-    int idx = hand_out(0), boards_done = 0;
+    // A wavefront's first two boards are fixed (boards w and 16 + w of the workgroup's run; the counter starts behind them): the first dynamic hand-out
+    // then comes after the kernel's one barrier.
+    int idx = wave, boards_done = 0;
     if (idx < wg_boards) fetch_row(wg_first + idx);
     asm volatile("" : "+v"(next_black), "+v"(next_white));        // (once: wait for them here)
 #pragma unroll 1
@@ -380,7 +382,7 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
         const int board = wg_first + idx;
         cur_black = next_black; cur_white = next_white;
         int idx_next = idx;
-        if (live) { idx_next = hand_out(0); fetch_row(wg_first + min(idx_next, wg_boards - 1)); }
+        if (live) { idx_next = boards_done == 0 ? kBoardsPerBlock + wave : hand_out(0); fetch_row(wg_first + min(idx_next, wg_boards - 1)); }
         GMK_STAMP(11);
 
         if (live) {
@@ -452,7 +454,10 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             }
             wave_phase_fence();
             GMK_STAMP(1);
-
+        }
+        if (boards_done == 0) __syncthreads();                  // the tables are staged (the automaton at LDS address 0, the records, jobs, the tables of phase D,
+                                                                // the hand-out counters): from here on the wavefronts never wait for each other
+        if (live) {
             // ---- phase 1: walk the DFA along this lane's lines; transitions that emit go to the queue ----
             // The lane's one or two lines become ONE stream of 2-bit DFA symbols:
             //   '?' cells '?' '?'  ['?' cells '?' '?']  '?' '?' ...
