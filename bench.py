@@ -505,6 +505,14 @@ def selfplay_leg(args, torch, dev, rank, world, distributed, total_games, refere
         return r
     states, values, pi = local_stage("training tuples", tuples, torch, dev, distributed)
     t2 = time.perf_counter()
+    if distributed:
+        # the gather's destination allocates the fixed-stride records of ALL ranks through torch (26 GB of visit rows for 8 x 32 768 games), and the
+        # library's pool holds this leg's arenas (up to 142 GB) where torch's allocator cannot see them: give them back first (untimed: the next leg
+        # allocates its own before its clock starts)
+        from gomokuai_amd import lib as G
+        G.release_pool()
+        torch.cuda.synchronize()
+    t2b = time.perf_counter()
     # the rehearsal mode's gloo has no device transfers: there the same exchange runs on host copies of the records
     gathered = selfplay.gather_records(rec if REDUCE_DEVICE is None else rec.cpu())
     torch.cuda.synchronize()
@@ -515,7 +523,7 @@ def selfplay_leg(args, torch, dev, rank, world, distributed, total_games, refere
     moves = int(rec.lens.sum())
     n_tuples = int(states.shape[0])
     overflow = bool(rec.overflow)
-    times = [t1 - t0, t2 - t1, t3 - t2, t3 - t0, float(rec.lens.max())]
+    times = [t1 - t0, t2 - t1, t3 - t2b, (t2 - t0) + (t3 - t2b), float(rec.lens.max())]
     times, (moves, n_tuples, n_overflow) = reduce_leg(torch, dev, distributed, times, [moves, n_tuples, int(overflow)])
     if rank != 0:
         return None
