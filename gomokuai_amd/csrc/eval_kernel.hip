@@ -57,8 +57,10 @@ constexpr int kScoreWords = 4 * kCells;          // 900, 16-byte aligned block. 
 constexpr int kCntWords = 3 * kCells + 1;        // [LiveThree, DeadThree, LiveTwo][cell]: eight 4-bit counters per word, field = colour * 4 + direction:
                                                  // how many '_' pieces of matches of that type lie on the cell (<= 15: at most 8 transitions x 2 matches reach a cell)
 constexpr int kZeroWords = kScoreWords + kCntWords;                   // cleared for every board (a multiple of 4)
-constexpr int kLineWords = 96;                   // line words, 2 bits per cell = its DFA symbol (0 black, 1 white, 3 blank), cell p of the line at bits 2p:
-                                                 // rows [0,15), columns [20,35), diagonals x-y+14 at [36,65), anti-diagonals x+y at [65,94)
+constexpr int kLineWords = 96;                   // line words, 2 bits per cell = its DFA symbol (0 black, 1 white, 3 blank): rows [0,15) cell x at bits 2x,
+                                                 // columns [20,35) cell y at bits 2y, diagonals x-y+14 at [36,65) at bits 2x, anti-diagonals x+y at [65,94) at bits 2y
+                                                 // (a stone's shift is then 2x for its row and diagonal, 2y for its column and anti-diagonal: two shifted
+                                                 // codes per stone instead of four; a reader shifts a diagonal's word down to its first cell)
 constexpr int kColBase = 20, kDiagBase = 36, kAntiBase = 65;
 constexpr int kMiscWords = 48;                   // [0] stones black | white << 16, [1] winner bits, [2] error, [3] compound queue count, [4..14] totals,
                                                  // [19..33] the rows (black | white << 16) between three zero rows on either side ([16..18], [34..36])
@@ -335,6 +337,12 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     // (from constant memory, not from their staged copies: those are not there yet)
     const uint32_t job_a = c_lane_jobs[lane * 2], job_b = c_lane_jobs[lane * 2 + 1];
     const uint32_t line_init_lo = c_line_init[lane], line_init_hi = c_line_init[min(64 + lane, kLineWords - 1)];
+    // where a line's first cell sits in its word: bit 2 x0 for a diagonal, 2 y0 for an anti-diagonal (first cell = job bits 12..19), 0 for rows and columns
+    auto first_bit = [](uint32_t job) -> uint32_t {
+        const uint32_t dir = (job >> 5) & 3u, first = (job >> 12) & 255u, y0 = (first * 0x8889u) >> 19, x0 = first - 15u * y0;
+        return dir == 2u ? 2u * x0 : dir == 3u ? 2u * y0 : 0u;
+    };
+    const uint32_t norm_a = first_bit(job_a), norm_b = first_bit(job_b);
     uint32_t* s_rows = s_misc + 16;                      // row y at [3 + y]
     // the cells this lane owns in the four passes over the board (cell = 64 pass + lane): 4 x row and column, a byte per pass
     uint32_t cell_row4 = 0, cell_col = 0;
@@ -445,10 +453,11 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                 for (uint32_t m = lane < 60 ? (row | (row >> 16)) & (0xFu << (4 * part)) & 0x7FFFu : 0u; m; m &= m - 1u) {
                     const int x = __ffs(m) - 1;
                     const uint32_t code = ((row >> x) & 1u) ? 3u : 2u;
-                    row_sym |= code << (2 * x);
-                    atomicXor(&s_lines[kColBase + x], code << (2 * y));
-                    atomicXor(&s_lines[kDiagBase + x - y + 14], code << (2 * min(x, y)));
-                    atomicXor(&s_lines[kAntiBase + x + y], code << (2 * min(14 - x, y)));
+                    const uint32_t at_x = code << (2 * x), at_y = code << (2 * y);
+                    row_sym |= at_x;
+                    atomicXor(&s_lines[kColBase + x], at_y);
+                    atomicXor(&s_lines[kDiagBase + x - y + 14], at_x);
+                    atomicXor(&s_lines[kAntiBase + x + y], at_y);
                 }
                 if (row_sym) atomicXor(&s_lines[y], row_sym);
             }
@@ -468,8 +477,8 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             int n_queued = 0;                                       // wave-uniform
             if (phase_mask & 2) {
                 const int len_a = static_cast<int>(job_a & 31u) - 3, len_b = static_cast<int>(job_b & 31u) - 3;
-                uint64_t syms = line_symbols(s_lines[(job_a >> 20) & 127u], len_a);
-                syms |= line_symbols(s_lines[(job_b >> 20) & 127u], len_b) << (2 * len_a + 6);
+                uint64_t syms = line_symbols(s_lines[(job_a >> 20) & 127u] >> norm_a, len_a);      // (a diagonal's word shifted down to its first cell)
+                syms |= line_symbols(s_lines[(job_b >> 20) & 127u] >> norm_b, len_b) << (2 * len_a + 6);
                 syms |= 0xAAAAAAAAAAAAAAAAull << (2 * (len_a + len_b) + 12);
                 // The stream is kept shifted left by 2: symbol s at bits 2 s + 2, so that the four bits from 2 s up are (symbol s - 1, symbol s) and
                 // one v_bfe + one v_bfi make the lookup address: (table word & 0x3FF3) | (those four bits & 12) -- the row offsets are multiples of 16.
@@ -651,9 +660,10 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                         const int diag = x - y + 14, anti = x + y;
                         const int line = dir == 0 ? y : dir == 1 ? kColBase + x : dir == 2 ? kDiagBase + diag : kAntiBase + anti;
                         const int at = dir == 0 ? x : dir == 1 ? y : dir == 2 ? min(x, y) : min(14 - x, y);
+                        const int first_at = dir == 2 ? 2 * (x - at) : dir == 3 ? 2 * (y - at) : 0;       // the line's first cell in its word (diagonals: bits 2 x / 2 y)
                         const int len = dir < 2 ? 15 : dir == 2 ? 15 - abs(diag - 14) : min(anti, 28 - anti) + 1;
                         // six '?' | cells | six '?', then the 13 symbols starting six before q
-                        const uint64_t syms = (0xAAAull | (static_cast<uint64_t>(s_lines[line]) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
+                        const uint64_t syms = (0xAAAull | (static_cast<uint64_t>(s_lines[line] >> first_at) << 12) | (0xAAAull << (2 * len + 12))) >> (2 * at);
                         const int start = k > 7 ? k - 7 : 0;
                         const uint32_t cur = static_cast<uint32_t>(syms >> (2 * start)) << 2;      // kept shifted left by 2 as in phase 1
                         uint32_t tw = 0;
@@ -772,7 +782,8 @@ int upload_lane_jobs() {
     }
     uint32_t init[kLineWords] = {};                              // every cell of every line blank (symbol 3)
     for (int i = 0; i < 15; ++i) init[i] = init[kColBase + i] = 0x3FFFFFFFu;
-    for (int d = 0; d <= 28; ++d) init[kDiagBase + d] = init[kAntiBase + d] = (1u << (2 * (15 - std::abs(d - 14)))) - 1u;
+    // (a diagonal's cells sit at bits 2 x, an anti-diagonal's at bits 2 y: the line starts at x = max(0, x - y) resp. y = max(0, x + y - 14))
+    for (int d = 0; d <= 28; ++d) init[kDiagBase + d] = init[kAntiBase + d] = ((1u << (2 * (15 - std::abs(d - 14)))) - 1u) << (2 * std::max(0, d - 14));
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_line_init), init, sizeof init));
     GMK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_lane_jobs), jobs, sizeof jobs));
     if (steps != kScanSteps) { gmk::set_error("lane jobs: %d scan steps, the kernel is built for %d", steps, kScanSteps); return GMK_ERR_STATE; }
