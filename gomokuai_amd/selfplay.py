@@ -77,16 +77,16 @@ class GameRecords:
         return out
 
 
-# Games in flight per MI355X for whole-game RandomPolicy self-play, and the number of search handles they are split over.  A search
-# launch ends with its slowest wavefront, so (a) fewer slots leave SIMDs idle while more slots lengthen the tail where the last games
-# run alone, and (b) two handles searching side by side on two streams fill each other's ends of launches (three or more lose again).
-# Measured, 32 768 games x 800 playouts per move, M playouts/s: one handle 8 192 slots 57, 16 384 slots 71, 24 576 slots 58, all at once 63;
-# two handles x 8 192 slots 80, x 10 240 78, x 16 384 77; three x 6 144 79; four x 4 096 61.  4 096 games: one handle 29, two 28.
-SLOTS_PER_GPU = 16384
-HANDLES_FROM_GAMES = 8192
+# Games in flight per MI355X for whole-game RandomPolicy self-play, and the number of search handles they are split over.  The loop is ONE
+# persistent launch per handle: 8 192 slots are the 2 048 wavefronts (four games each, two per SIMD) the chip holds, so one handle of 8 192 slots fills
+# it and keeps it filled until the games run out.  Measured in one process, alternating (tools/k3_handles_ab.py, 32 768 games x 800 playouts, M playouts/s):
+# one handle x 8 192 slots 134.9 / 135.5; one x 16 384 (the second half of the wavefronts queues behind the first) 127.3 / 126.9; two handles x 8 192 on
+# two streams and host threads -- round 3's default, the best plan of the LOCK-STEP loop, where two handles filled each other's ends of launches --
+# 127.9 / 112.4 (and the run-to-run spread VERDICT r3 noted); two x 4 096: 91.
 # With kept subtrees a slot owns TWO arenas of three times the nodes (the kept subtree + the new search; 17 MB per slot at 800 playouts per move):
-# 8 192 slots are 142 GB of the 288, and they are ONE handle -- its persistent launch (four games per wavefront, two wavefronts per SIMD) fills the
-# chip by itself and stays resident until its games have run out, so a second handle's launch would only queue behind it.
+# 8 192 slots are 142 GB of the 288.
+SLOTS_PER_GPU = 8192
+HANDLES_FROM_GAMES = 1 << 30        # (no longer a default: handles="auto" is one handle; handles=k is still honoured)
 SLOTS_PER_GPU_KEPT = 8192
 
 
@@ -96,7 +96,7 @@ def plan_games(n_games, slots="auto", handles="auto", opening_plies=0, reuse_sub
     if n_games <= 0:
         raise ValueError("play_games: n_games must be positive")
     if handles == "auto":
-        handles = 2 if n_games >= HANDLES_FROM_GAMES and opening_plies <= 8 and not reuse_subtree else 1
+        handles = 1
     if slots == "auto":
         per_gpu = SLOTS_PER_GPU_KEPT if reuse_subtree else SLOTS_PER_GPU
         slots = per_gpu if n_games > per_gpu and opening_plies <= 8 else None
@@ -120,7 +120,7 @@ def play_games(n_games, playouts, seed=G.DEFAULT_SEED, first_game_id=0, c_puct=5
     the next unstarted game inside the step kernel, so the searches stay full instead of waiting for the longest game of the batch.
     "auto" = SLOTS_PER_GPU when there are more games than that, else all games at once; None = all games at once.
     handles: the games are split into that many contiguous blocks, each with its own search handle, HIP stream and host thread
-    (the slots are shared out between them); "auto" = 2 from HANDLES_FROM_GAMES games on, else 1.
+    (the slots are shared out between them); "auto" = 1 (one persistent launch fills the chip, see SLOTS_PER_GPU).
     reuse_subtree + root_noise=(alpha, epsilon) are the reference agent's per-move semantics (agents/mcts.py:17-21: the chosen child's subtree is
     the next search's tree, MCTS.cpp:129-147, and Default::AddNoise runs before every search, MCTS.cpp:182).  noise_sampler: "counter" = the
     counter-based Dirichlet sampler of include/gomoku_noise.h, drawn inside the searching kernel, so that the whole run is ONE persistent launch

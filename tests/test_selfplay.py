@@ -222,8 +222,9 @@ def test_plan_games_spreads_games_over_handles_and_slots():
     slots shared out between the handles, the lock-step loop when neither is asked for."""
     assert selfplay.plan_games(4096) is None                                    # one handle, all games at once
     assert selfplay.plan_games(23, slots=64) is None                            # more slots than games
-    assert selfplay.plan_games(32768) == [(0, 16384, 8192), (16384, 32768, 8192)]
-    assert selfplay.plan_games(8192) == [(0, 4096, 4096), (4096, 8192, 4096)]   # two handles, every game in flight
+    assert selfplay.plan_games(32768) == [(0, 32768, 8192)]                     # one handle: its persistent launch fills the chip
+    assert selfplay.plan_games(8192) is None                                    # every game in flight from the start
+    assert selfplay.plan_games(8192, handles=2) == [(0, 4096, 4096), (4096, 8192, 4096)]   # two handles on request
     assert selfplay.plan_games(23, slots=5) == [(0, 23, 5)]
     for n, slots, handles in [(23, 6, 3), (23, None, 2), (7, 100, 7), (5, 1, 9), (40000, "auto", "auto"), (16385, "auto", 1)]:
         plan = selfplay.plan_games(n, slots, handles)
