@@ -151,7 +151,8 @@ __device__ __forceinline__ int row_scan(int v) {                        // inclu
 template <bool kTurns>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))      // two wavefronts per SIMD: at most 256 registers
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
-                          uint32_t* __restrict__ parent, const float* __restrict__ root_prior, SearchParams prm) {
+                          uint32_t* __restrict__ parent, float* root_prior /* written by this kernel's own root_noise_one between two turns: neither const nor restrict */,
+                          SearchParams prm) {
     // dynamic LDS, sized by the games G and rollouts R of the block (lds_words() below): the rollout positions as line words
     // [word][rollout lane], the rollouts' random cells [block of eight plies][rollout lane], the games' leaf positions, their paths
     extern __shared__ uint32_t s_lane_lines[];
@@ -518,7 +519,7 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (prm.noise_alpha > 0.0f) {                                   // Default::AddNoise before the next search (MCTS.cpp:182), on the roots that have children
-        GameHeader* h_ = headers; uint32_t* lk_ = link; float* rp_ = const_cast<float*>(root_prior);
+        GameHeader* h_ = headers; uint32_t* lk_ = link; float* rp_ = root_prior;
         int first_ = game0, lane_ = lane;
         asm volatile("" : "+s"(h_), "+s"(lk_), "+s"(rp_), "+s"(first_), "+v"(lane_));
 #pragma unroll 1
