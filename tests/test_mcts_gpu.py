@@ -218,3 +218,34 @@ def test_nearly_full_boards(oracle):
         ov, oq, orv, osize, _ = _oracle_search(oracle, moves[g], int(lens[g]), 300, 70 + g)
         assert (visits[g] == ov).all() and nodes[g] == osize and q[g].tobytes() == oq.tobytes() and rv[g] == orv, "game %d" % g
     t.close()
+
+
+def test_reserved_arenas_serve_the_lock_step_calls_too():
+    """gmk_mcts_reserve: a handle whose two arenas are the halves of one block (what the persistent loop with kept subtrees uses) runs the
+    call-by-call API -- set_roots, run, advance with reuse_subtree, root_stats -- exactly as a handle that allocates as it goes."""
+    import torch
+    n, playouts = 6, 40
+    moves, lens, _ = G.synth_boards(n, 0, first_board=77)
+    lens = np.minimum(lens, 3).astype(np.int32)
+    planes = G.moves_to_planes(moves, lens)
+    last = np.array([moves[i, lens[i] - 1] if lens[i] > 0 else -1 for i in range(n)], dtype=np.int16)
+    dev = torch.device("cuda", 0)
+    out = []
+    for reserve in (None, False, True):
+        t = G.BatchedMCTS(n, node_capacity=3 * playouts * 225 + 1)
+        if reserve is not None:
+            t.reserve(two_arenas=reserve)
+        t.set_roots(planes, last, first_game_id=5)
+        d_moves = torch.zeros((n, 225), dtype=torch.uint8, device=dev); d_lens = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_winner = torch.zeros(n, dtype=torch.int8, device=dev); d_unfinished = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_visits = torch.zeros((n, 225, 225), dtype=torch.int16, device=dev)
+        for _ in range(4):
+            t.run(playouts)
+            t.advance(d_moves.data_ptr(), d_visits.data_ptr(), d_lens.data_ptr(), d_winner.data_ptr(), d_unfinished.data_ptr(), reuse_subtree=True)
+        t.run(playouts)
+        visits, q, rv, nodes, status = t.root_stats()
+        out.append((d_moves.cpu().numpy().copy(), d_visits.cpu().numpy().copy(), visits.copy(), nodes.copy()))
+        t.close()
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert (a == b).all()
