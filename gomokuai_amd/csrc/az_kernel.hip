@@ -23,6 +23,7 @@
 #include "philox.h"
 #include "rollout_device.h"
 #include "root_noise.h"
+#include "noise_device.h"
 
 namespace {
 
@@ -429,6 +430,46 @@ void az_set_root_priors_kernel(AzTree t, const float* priors) {
         t.prior[base + rk.x + i] = priors[static_cast<size_t>(game) * kCells + ((t.kids[base + rk.x + i].y >> 8) & 0xFFu)];
 }
 
+// Default::AddNoise with the counter-based sampler (include/gomoku_noise.h), one wavefront per game, on the device: the root children's priors travel
+// through 225 words of LDS into by-cell order, lane l mixes the cells l + 64 j (noise_device.h), and back.  The stream belongs to the GAME a slot
+// plays (slot_game under continuous batching, game_ids otherwise) and to the stones on its root board.
+__global__ __launch_bounds__(64)
+void az_root_noise_kernel(AzTree t, const int32_t* __restrict__ slot_game, const uint32_t* __restrict__ game_ids, uint32_t first_game_id,
+                          float alpha, float epsilon, uint32_t seed_lo, uint32_t seed_hi) {
+    __shared__ uint32_t s_cells[kCells];
+    const int game = blockIdx.x, lane = threadIdx.x;
+    const AzHeader& hdr = t.hdr[game];
+    if (hdr.status & kStatusOver) return;
+    const size_t base = static_cast<size_t>(game) * t.cap;
+    const uint2 rk = t.kids[base];
+    const uint32_t first = rk.x, n = rk.y & 0xFFu;
+    if (n == 0u) return;                                         // a root without children takes no noise (the loop over node->children is empty)
+    const uint32_t gid = first_game_id + (slot_game ? static_cast<uint32_t>(max(slot_game[game], 0)) : game_ids[game]);
+    for (int i = lane; i < kCells; i += 64) s_cells[i] = 0u;
+    __syncthreads();
+    uint32_t cell[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = lane + 64 * k;
+        cell[k] = i < n ? (t.kids[base + first + i].y >> 8) & 0xFFu : 0u;
+        if (i < n) s_cells[cell[k]] = __float_as_uint(t.prior[base + first + i]);
+    }
+    __syncthreads();
+    float p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = lane + 64 * j < kCells ? __uint_as_float(s_cells[lane + 64 * j]) : 0.0f;
+    gmk::noise::mix_root_priors(p, lane, alpha, epsilon, gid, hdr.stones, seed_lo, seed_hi);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (lane + 64 * j < kCells) s_cells[lane + 64 * j] = __float_as_uint(p[j]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = lane + 64 * k;
+        if (i < n) t.prior[base + first + i] = __uint_as_float(s_cells[cell[k]]);
+    }
+}
+
 __global__ void az_init_roots_kernel(AzTree t) {
     const int game = blockIdx.x * blockDim.x + threadIdx.x;
     if (game >= t.n_games) return;
@@ -473,6 +514,8 @@ struct gmk_az {
     int32_t* d_open_lens = nullptr;
     std::vector<uint32_t> game_ids;                              // the game a slot is playing, relative to the callers' first_game_id (default: the slot number)
     bool second_arena = false;
+    int noise_sampler = GMK_NOISE_SAMPLER_STD;                   // gmk_az_set_option
+    uint32_t* d_game_ids = nullptr;                              // the device copy of game_ids for az_root_noise_kernel
     // device scratch of the host-driven form (gmk_az_select_host / gmk_az_expand_host)
     float *h_states = nullptr, *h_values = nullptr, *h_probs = nullptr;
     int16_t* h_paths = nullptr;
@@ -483,7 +526,7 @@ extern "C" int gmk_az_destroy(gmk_az* a) {
     if (!a) return GMK_OK;
     (void)gmk::device_free(a->t.hdr); (void)gmk::device_free(a->t.stat); (void)gmk::device_free(a->t.kids); (void)gmk::device_free(a->t.prior); (void)gmk::device_free(a->t.parent);
     (void)gmk::device_free(a->other.stat); (void)gmk::device_free(a->other.kids); (void)gmk::device_free(a->other.prior); (void)gmk::device_free(a->other.parent);
-    (void)gmk::device_free(a->d_forced); (void)gmk::device_free(a->d_noise_priors); (void)gmk::device_free(a->d_unfinished); (void)gmk::device_free(a->d_row_of);
+    (void)gmk::device_free(a->d_forced); (void)gmk::device_free(a->d_game_ids); (void)gmk::device_free(a->d_noise_priors); (void)gmk::device_free(a->d_unfinished); (void)gmk::device_free(a->d_row_of);
     (void)gmk::device_free(a->slots.slot_game); (void)gmk::device_free(a->d_open_moves); (void)gmk::device_free(a->d_open_lens);
     (void)gmk::device_free(a->h_states); (void)gmk::device_free(a->h_values); (void)gmk::device_free(a->h_probs); (void)gmk::device_free(a->h_paths); (void)gmk::device_free(a->h_lens);
     delete a;
@@ -693,11 +736,27 @@ extern "C" int gmk_az_advance(gmk_az* a, uint8_t* d_moves, uint16_t* d_visits, i
     return GMK_OK;
 }
 
+extern "C" int gmk_az_set_option(gmk_az* a, int option, int value) {
+    if (a && option == GMK_OPT_NOISE_SAMPLER && (value == GMK_NOISE_SAMPLER_STD || value == GMK_NOISE_SAMPLER_COUNTER)) { a->noise_sampler = value; return GMK_OK; }
+    gmk::set_error("gmk_az_set_option: bad handle, unknown option %d or value %d", option, value);
+    return GMK_ERR_ARG;
+}
+
 // Default::AddNoise on every root with children, seeded like gmk_mcts_add_root_noise / gmk_trad_add_root_noise
 extern "C" int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id) {
     if (!a || !(alpha > 0.0f)) { gmk::set_error("gmk_az_add_root_noise: bad arguments"); return GMK_ERR_ARG; }
     if (!a->rooted) { gmk::set_error("gmk_az_add_root_noise: gmk_az_set_roots has not been called"); return GMK_ERR_STATE; }
     const size_t n = static_cast<size_t>(a->t.n_games);
+    if (a->noise_sampler == GMK_NOISE_SAMPLER_COUNTER) {         // drawn on the device, one wavefront per game: nothing comes back to the host
+        if (!a->slots.slot_game) {
+            if (!a->d_game_ids) GMK_HIP_CHECK(gmk::device_malloc(&a->d_game_ids, n * 4));
+            GMK_HIP_CHECK(hipMemcpy(a->d_game_ids, a->game_ids.data(), n * 4, hipMemcpyHostToDevice));
+        }
+        hipLaunchKernelGGL(az_root_noise_kernel, dim3(a->t.n_games), dim3(64), 0, nullptr, a->t, a->slots.slot_game, a->d_game_ids, first_game_id, alpha, epsilon,
+                           static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+        GMK_HIP_CHECK(hipGetLastError());
+        return GMK_OK;
+    }
     if (a->slots.slot_game) {                                    // continuous batching: the random stream belongs to the GAME a slot plays
         std::vector<int32_t> slot_game(n);
         GMK_HIP_CHECK(hipMemcpy(slot_game.data(), a->slots.slot_game, n * 4, hipMemcpyDeviceToHost));

@@ -41,7 +41,7 @@ EXPORTS = [
     "gmk_mcts_create", "gmk_mcts_destroy", "gmk_mcts_set_roots", "gmk_mcts_set_game_ids", "gmk_mcts_run", "gmk_mcts_root_stats",
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_mcts_set_option", "gmk_mcts_reserve", "gmk_selfplay_run", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
-    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_read_node_host", "gmk_az_read_children_host", "gmk_az_set_leaf_host", "gmk_az_rollout_host", "gmk_az_expand_stages_host", "gmk_az_write_stats_host", "gmk_az_step", "gmk_az_advance", "gmk_az_set_slots", "gmk_az_live_games", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_root_stats",
+    "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_read_node_host", "gmk_az_read_children_host", "gmk_az_set_leaf_host", "gmk_az_rollout_host", "gmk_az_expand_stages_host", "gmk_az_write_stats_host", "gmk_az_step", "gmk_az_advance", "gmk_az_set_slots", "gmk_az_live_games", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_set_option", "gmk_az_root_stats",
     "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_set_option", "gmk_trad_reserve", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_trad_selfplay_run", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
 ]
 
@@ -119,6 +119,7 @@ def load():
     L.gmk_az_set_slots.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.gmk_az_advance.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int32), vp]
     L.gmk_az_add_root_noise.argtypes = [vp, C.c_float, C.c_float, C.c_uint64, C.c_uint32]
+    L.gmk_az_set_option.argtypes = [vp, C.c_int, C.c_int]
     L.gmk_az_expand_host.argtypes = [vp, vp, vp]
     L.gmk_az_root_stats.argtypes = [vp] * 8
     L.gmk_trad_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
@@ -639,6 +640,10 @@ class AlphaZeroMCTS:
 
     def add_root_noise(self, alpha=0.05, epsilon=0.25, seed=DEFAULT_SEED, first_game_id=0):
         _check(load().gmk_az_add_root_noise(self.h, alpha, epsilon, seed, first_game_id))
+
+    def set_option(self, option, value):
+        """gmk_az_set_option: OPT_NOISE_SAMPLER -> NOISE_SAMPLERS["std" | "counter"]."""
+        _check(load().gmk_az_set_option(self.h, int(option), int(value)))
 
     def search(self, network, playouts, graph=False):
         """`playouts` lock-step playouts; network(states) -> (value [n], probs [n, 225]) on the GPU.  graph=True: the first playout

@@ -466,7 +466,7 @@ def _play_supervisor_slots(n_games, slots, playouts, c_puct, seed, first_game_id
 
 
 def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SEED, first_game_id=0, opening_plies=0, max_moves=N,
-                       device=None, node_capacity=None, reuse_subtree=True, root_noise=(0.05, 0.25), slots=None, device_loop=True):
+                       device=None, node_capacity=None, reuse_subtree=True, root_noise=(0.05, 0.25), slots=None, device_loop=True, noise_sampler="counter"):
     """n_games complete games of the network-guided searcher against itself (agents/alphazero.py:5-9 on both sides: the
     reference's AlphaZero self-play), all games in lock step on the current GPU: every move = `playouts` lock-step playouts of
     K7 with `network(states [n,6,15,15]) -> (value [n], probs [n,225])` at the leaves (network.FusedPolicyValueNetwork = K9),
@@ -474,8 +474,8 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
     subtree is kept and root_noise = (alpha, epsilon) is mixed into the root priors before every search (MCTS.cpp:182).
     slots: at most that many games in flight, a finished game hands its slot to the next one (see play_supervisor_games; on the
     host-driven loop with fresh roots only).  device_loop (all games at once): the move, the record, the end-of-game check and the re-rooting are one
-    kernel per ply (gmk_az_advance) and the host sees four bytes per move (plus the root priors when root_noise is mixed in, which is a
-    host step); False = the host-driven loop it replaced (numpy boards, root statistics down and moves up every ply), kept for the
+    kernel per ply (gmk_az_advance) and the host sees four bytes per move; noise_sampler "counter" (default) draws the root noise on the device
+    (az_root_noise_kernel, include/gomoku_noise.h), "std" on the host with std::gamma_distribution (priors down and up every ply); False = the host-driven loop it replaced (numpy boards, root statistics down and moves up every ply), kept for the
     tests that compare the two.  Returns GameRecords like play_games."""
     if slots is not None and slots < n_games and (max_moves < N or (device_loop and opening_plies > 8)):
         # (the slot loops play whole games, the device-resident one from openings of at most 8 plies -- gmk_az_set_slots' limit: say so instead of
@@ -494,6 +494,7 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
         slots = int(slots)
         cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * N + 1, (1 << 24) - 1)
         tree = G.AlphaZeroMCTS(slots, node_capacity=cap, c_puct=c_puct)
+        tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS[noise_sampler])
         tree.set_slots(n_games, games.moves[:, :max(int(games.lens.max()), 1)], games.lens)
         d_moves, d_lens = torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev)
         d_winner = torch.zeros(n_games, dtype=torch.int8, device=dev)
@@ -556,6 +557,7 @@ def play_network_games(n_games, network, playouts, c_puct=5.0, seed=G.DEFAULT_SE
         games.open_with(m, l, opening_plies)
     cap = node_capacity if node_capacity is not None else min((3 if reuse_subtree else 1) * playouts * N + 1, (1 << 24) - 1)
     tree = G.AlphaZeroMCTS(n_games, node_capacity=cap, c_puct=c_puct)
+    tree.set_option(G.OPT_NOISE_SAMPLER, G.NOISE_SAMPLERS[noise_sampler])
     tree.set_roots(G.moves_to_planes(games.moves, games.lens), games.last_two())
     if device_loop:
         d_moves, d_lens = torch.from_numpy(games.moves).to(dev), torch.from_numpy(games.lens).to(dev)

@@ -347,6 +347,8 @@ int gmk_az_advance(gmk_az* a, uint8_t* d_moves, uint16_t* d_visits, int32_t* d_l
  * by first_game_id + ids[g], ids as set by gmk_az_set_game_ids (uint32[n], host; default: the slot number) */
 int gmk_az_set_game_ids(gmk_az* a, const uint32_t* h_ids);
 int gmk_az_add_root_noise(gmk_az* a, float alpha, float epsilon, uint64_t seed, uint32_t first_game_id);
+/* GMK_OPT_NOISE_SAMPLER for a K7 handle (see gmk_mcts_set_option): GMK_NOISE_SAMPLER_COUNTER draws the noise on the device, one wavefront per game */
+int gmk_az_set_option(gmk_az* a, int option, int value);
 /* The same two steps for an evaluator that runs on the host and wants positions, not planes (the Python callable of
  * Policy(eval_state=...)): select, then the moves from the root to every pending leaf (h_paths int16[n][226], h_lens int32[n],
  * -1 = nothing to evaluate); expand from host memory.  Synchronous. */

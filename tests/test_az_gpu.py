@@ -131,15 +131,18 @@ def test_policy_value_network_end_to_end():
     tree.close()
 
 
-def test_step_keeps_the_subtree_and_noise(oracle):
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_step_keeps_the_subtree_and_noise(oracle, sampler):
     """gmk_az_step + gmk_az_add_root_noise: search, step to the most visited child, step to the opponent's reply (a child or
-    not), search again from the kept subtree with fresh root noise: equal to the oracle's persistent MCTS object."""
+    not), search again from the kept subtree with fresh root noise: equal to the oracle's persistent MCTS object -- with the noise drawn on the
+    host (sampler 0: std::gamma_distribution) and on the device (sampler 1: the counter-based sampler of include/gomoku_noise.h, az_root_noise_kernel)."""
     import torch
     O = oracle
     G.init()
     n, playouts = 6, 90
     moves, lens, planes, last = _roots(n, 12)
     tree = G.AlphaZeroMCTS(n, node_capacity=1 << 17, c_puct=5.0)
+    tree.set_option(G.OPT_NOISE_SAMPLER, sampler)
     tree.set_roots(planes, last)
 
     def host_network(states):
@@ -153,7 +156,7 @@ def test_step_keeps_the_subtree_and_noise(oracle):
             O.lib().go_board_apply(C.byref(b), int(moves[g, i]), 1)
         om = O.MCTS(playouts, 5.0, 5, 777, 20 + g)
         om.set_evaluator(surrogate)
-        om.set_noise(0.05, 0.25)
+        om.set_noise(0.05, 0.25, sampler=sampler)
         boards.append(b); orcs.append(om)
     kept = 0
     for rnd in range(3):
