@@ -575,6 +575,9 @@ __device__ bool advance_one(int g, int lane, GameHeader* headers, uint2* stats, 
             hdr.root = 0;
             hdr.n_nodes = 1;
         }
+        // The persistent loop (flip_all = 0, no forced moves) ends when every slot's game has: a game whose root has no child after its search -- an
+        // arena too small for one expansion -- would never end.  Its slot stops here, reported as an arena that filled up.
+        if (!flip_all && !forced && !(hdr.status & 1u) && lane == 0) hdr.status |= 1u | 2u;
         return reuse && flip_all;
     }
     const int n_child = 225 - static_cast<int>(stones);
@@ -1055,8 +1058,9 @@ extern "C" int gmk_mcts_step(gmk_mcts* m, const int16_t* d_forced_moves, uint8_t
 extern "C" int gmk_selfplay_run(gmk_mcts* m, int n_total, uint32_t first_game_id, int playouts, int reuse_subtree, float noise_alpha, float noise_epsilon,
                                 const uint8_t* h_open_moves, int open_stride, const int32_t* h_open_lens,
                                 uint8_t* d_moves, uint16_t* d_visits, int32_t* d_lens, int8_t* d_winner, int32_t* h_steps, void* stream) {
-    if (!m || n_total <= 0 || playouts < 0 || !d_moves || !d_lens || !d_winner || (h_open_moves && (!h_open_lens || open_stride <= 0))) {
-        gmk::set_error("gmk_selfplay_run: bad arguments");
+    // (playouts >= 1: a root that was never searched has no child to play, and the persistent launch ends only when every game has)
+    if (!m || n_total <= 0 || playouts < 1 || !d_moves || !d_lens || !d_winner || (h_open_moves && (!h_open_lens || open_stride <= 0))) {
+        gmk::set_error("gmk_selfplay_run: bad arguments (playouts >= 1)");
         return GMK_ERR_ARG;
     }
     const int n_slots = m->n_games;

@@ -73,3 +73,13 @@ def test_illegal_steps_are_reported_not_played():
     a.step(np.array([113], np.int16))
     assert a.root_stats()["status"][0] & 4
     a.close()
+
+
+def test_persistent_self_play_ends_when_nothing_can_be_played():
+    """The one-launch self-play loop ends when every slot's game has; configurations in which a game can never move must not spin: an arena
+    too small for a single expansion stops its slot and is reported as an overflow, and zero playouts per move are refused up front."""
+    from gomokuai_amd import selfplay
+    rec = selfplay.play_games(6, 10, node_capacity=100, slots=4)         # 100 nodes: the root's 225 children do not fit
+    assert rec.overflow and int(rec.lens.max()) == 0
+    with pytest.raises(G.GmkError):
+        selfplay.play_games(6, 0, slots=4)
