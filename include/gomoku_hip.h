@@ -174,6 +174,8 @@ int gmk_mcts_advance(gmk_mcts *m, uint8_t *d_moves, uint16_t *d_visits, int32_t 
  * ONE persistent launch plays all games (every wavefront searches and steps its slots' games turn by turn at its own pace; with
  * reuse_subtree the chosen child's subtree is compacted into the game's second arena inside the launch) unless the noise has to be drawn
  * on the host (GMK_NOISE_SAMPLER_STD with noise_alpha > 0) or GMK_OPT_LOCKSTEP is set; the records are the same bytes either way.
+ * playouts >= 1 (a root that was never searched has no child to play).  A slot whose game can never move -- a node capacity too small for one
+ * expansion -- stops and is reported through status bit 1 (arena full) instead of keeping the launch alive.
  * Synchronous; *h_steps (optional) = search launches it took (lock step: each one move for every busy slot; persistent: 1). */
 int gmk_selfplay_run(gmk_mcts *m, int n_total, uint32_t first_game_id, int playouts, int reuse_subtree, float noise_alpha, float noise_epsilon,
                      const uint8_t *h_open_moves, int open_stride, const int32_t *h_open_lens,
