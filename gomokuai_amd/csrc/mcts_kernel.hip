@@ -42,6 +42,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kMaxGamesPerBlock = 16;
 constexpr int kPathCap = 32;           // deeper descents fall back to walking parent[] with loads
 constexpr int kCellBlocks = 30;        // Philox blocks of a rollout: 29 cover 225 plies, one more is read ahead
+constexpr int kStageBlocks = 12;       // ... of which the first twelve (96 plies) are generated for every rollout, the others for those still running then
 
 struct GameHeader {                 // 128 B per game, in HBM
     uint32_t rows[16];              // root position: black | white << 16 per row
@@ -148,7 +149,9 @@ __device__ __forceinline__ int row_scan(int v) {                        // inclu
 
 // kTurns = false: one search (gmk_mcts_run); true: the persistent self-play loop, search after search with the step (and the root noise) in between.
 // Two instantiations, so that the bare search does not carry the registers of the turn loop through its playouts.
-template <bool kTurns>
+// kStaged: the rollouts' draws are generated in two stages (the pairs form: wavefronts of three or four games); a separate instantiation, so that
+// the other forms -- BASELINE configs[2] runs on quads -- are the code they were, to the register.
+template <bool kTurns, bool kStaged>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))      // two wavefronts per SIMD: at most 256 registers
 void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ stats, uint32_t* __restrict__ link,
                           uint32_t* __restrict__ parent, float* root_prior /* written by this kernel's own root_noise_one between two turns: neither const nor restrict */,
@@ -172,9 +175,11 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
     __shared__ uint2 s_root_stats[kMaxGamesPerBlock];
     __shared__ uint32_t s_root_link[kMaxGamesPerBlock], s_leaf_link[kMaxGamesPerBlock];
     __shared__ uint32_t s_rng_game[kMaxGamesPerBlock], s_rng_playout[kMaxGamesPerBlock], s_rng_stones[kMaxGamesPerBlock];   // Philox counter words of a game's rollouts
+    __shared__ uint32_t s_running[64], s_inverse[65];             // the rollouts that go into the second stage; 2^32 / n rounded up, n = 1 .. 64
     __shared__ size_t s_arena[kMaxGamesPerBlock];                // first node of the game's LIVE arena (the persistent loop with kept subtrees flips it per game)
 
     const int lane = threadIdx.x, quarter = lane >> 4, l16 = lane & 15;
+    if constexpr (kStaged) s_inverse[lane + 1] = lane == 0 ? 0u : 0xFFFFFFFFu / static_cast<uint32_t>(lane + 1) + 1u;      // (n = 1 takes the dividend as it is; read after the turn's first barrier)
     const int G = prm.games_per_block, R = prm.c_rollouts;
     const int game0 = blockIdx.x * G;
     const int games_here = min(G, prm.n_games - game0);
@@ -366,10 +371,17 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
         __syncthreads();
         if (gmk::kProfileBuild && prm.profile) { const unsigned long long t = __builtin_amdgcn_s_memtime(); prof[1] += t - t_mark; t_mark = t; }
 
-        // ---- simulate (Random.h:22-35).  First the random cells of all rollouts, with all 64 lanes: one Philox block = eight plies
-        //      per task, block-major, so that the rollout loop below only plays (the generator is ~150 instructions a block, and
-        //      a third of the lanes roll out) ----
-        for (int t = lane; t < 29 * n_rollout_lanes; t += 64) {
+        // ---- simulate (Random.h:22-35).  First the random cells of the rollouts, with all 64 lanes: one Philox block = eight plies per task,
+        //      block-major, so that the rollout loop below only plays (the generator is ~150 instructions a block, and a third of the lanes
+        //      roll out) -- in TWO STAGES where the rollouts can stop and go on (quads, pairs): blocks 0 .. kStageBlocks - 1 for every rollout,
+        //      the others only for the rollouts that are still running after those 96 plies (a rollout ends after ~100 of up to 220 plies:
+        //      round 3 generated 27 blocks per rollout and played 13 of them on average) ----
+        // Measured (tools/mcts_time.py): with 20 rollouts per wavefront (four games, pairs) 9 generator passes become 7: 75.2 -> 73.7 ms at 16 384 games;
+        // with 10 (two games, quads: BASELINE configs[2]) 5 become 4 and the second stage's bookkeeping costs more than that pass: 28.0 -> 28.5 ms.
+        // So: staged for the pairs form only; quads and the one-lane form generate everything and play straight through.
+        constexpr bool staged = kStaged;                            // (the host instantiates it for 2 * rollouts <= 64 < 4 * rollouts)
+        const int first_blocks = staged ? kStageBlocks : 29;
+        for (int t = lane; t < first_blocks * n_rollout_lanes; t += 64) {
             const uint32_t b = div_lanes(static_cast<uint32_t>(t)), rl = static_cast<uint32_t>(t) - b * static_cast<uint32_t>(n_rollout_lanes);
             const uint32_t gs = div_r(rl), r = rl - gs * static_cast<uint32_t>(R);
             if (static_cast<int>(gs) < games_here && s_active[gs] && s_need[gs] && 8u * b < 225u - s_ply[gs])
@@ -386,7 +398,10 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
             const int share = 4 * n_rollout_lanes <= 64 ? 2 : 2 * n_rollout_lanes <= 64 ? 1 : 0;       // log2 of the lanes per rollout
             const int rl = lane >> share, part = lane & ((1 << share) - 1), parts = 1 << share;      // the rollout this lane works on, and its share of it
             const int gs = static_cast<int>(div_r(static_cast<uint32_t>(rl)));
-            if (rl < n_rollout_lanes && gs < games_here && s_active[gs] && s_need[gs]) {
+            const bool rolls = rl < n_rollout_lanes && gs < games_here && s_active[gs] && s_need[gs];
+            RolloutState state;
+            state.live = rolls;
+            if (rolls) {
                 // the leaf's line words into the rollout's position, 23 reads in flight at a time (one by one each copy is a
                 // round trip: the compiler cannot tell that the two regions are apart); the lanes of a rollout copy a share each
                 static_assert(kLineWords == 4 * 23, "copy batches");
@@ -406,10 +421,51 @@ void mcts_playouts_kernel(GameHeader* __restrict__ headers, uint2* __restrict__ 
                 auto fetch = [&](uint32_t b) { return my_cells[b * static_cast<uint32_t>(n_rollout_lanes)]; };
                 uint32_t* const position = &s_lane_lines[rl];
                 const uint32_t stride = static_cast<uint32_t>(n_rollout_lanes);
-                const int winner = share == 2 ? random_rollout_quads(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch)
-                                 : share == 1 ? random_rollout_pairs(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch)
-                                              : random_rollout_blocks(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch);
-                if (part == 0) atomicAdd(&s_sum[gs], init_player * winner);              // CalcScore(init_player, winner)
+                if constexpr (kStaged) {
+                    (void)random_rollout_pairs_span(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch, state, 0u, static_cast<uint32_t>(kStageBlocks));
+                } else {
+                    // (quads and the one-lane form: every block is there, the rollout plays straight through -- the code of round 3, untouched:
+                    // BASELINE configs[2] runs here, and the resumable form costs it 3 %)
+                    const int winner = share == 2 ? random_rollout_quads(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch)
+                                     : share == 1 ? random_rollout_pairs(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch)
+                                                  : random_rollout_blocks(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch);
+                    if (part == 0) atomicAdd(&s_sum[gs], init_player * winner);          // CalcScore(init_player, winner)
+                    state.live = false;
+                }
+            }
+            // second stage (pairs): the blocks from kStageBlocks on, for the rollouts that are still running (wave-uniform: most playouts have some)
+            const unsigned long long running = kStaged ? __ballot(state.live && part == 0) : 0ull;
+            if (kStaged && running) {
+                const uint32_t n_running = static_cast<uint32_t>(__popcll(running));
+                if (state.live && part == 0)
+                    s_running[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(running >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(running), 0u))] = static_cast<uint32_t>(rl);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t inv_running = s_inverse[n_running];      // t / n_running = umulhi(t, 2^32 / n_running rounded up) for the small t here
+                for (uint32_t t = static_cast<uint32_t>(lane); t < static_cast<uint32_t>(29 - kStageBlocks) * n_running; t += 64u) {
+                    const uint32_t k = n_running == 1u ? t : __umulhi(t, inv_running), trl = s_running[t - k * n_running], b = static_cast<uint32_t>(kStageBlocks) + k;
+                    const uint32_t tg = div_r(trl), r = trl - tg * static_cast<uint32_t>(R);
+                    if (8u * b < 225u - s_ply[tg])
+                        s_cells[b * static_cast<uint32_t>(n_rollout_lanes) + trl] = rollout_cells(s_rng_game[tg], s_rng_playout[tg] + static_cast<uint32_t>(playout), s_rng_stones[tg] | r,
+                                                                                                b, prm.seed_lo, prm.seed_hi);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (state.live) {
+                    const uint32_t ply = s_ply[gs];
+                    const int init_player = (ply & 1u) ? -1 : 1;
+                    const uint2* my_cells = s_cells + rl;
+                    auto fetch = [&](uint32_t b) { return my_cells[b * static_cast<uint32_t>(n_rollout_lanes)]; };
+                    uint32_t* const position = &s_lane_lines[rl];
+                    const uint32_t stride = static_cast<uint32_t>(n_rollout_lanes);
+                    (void)random_rollout_pairs_span(position, stride, init_player, static_cast<int>(ply), no_tie_before, fetch, state, static_cast<uint32_t>(kStageBlocks), 30u);
+                }
+            }
+            if (kStaged && rolls && part == 0) {
+                const int init_player = (s_ply[gs] & 1u) ? -1 : 1;
+                atomicAdd(&s_sum[gs], init_player * state.winner(init_player));          // CalcScore(init_player, winner)
             }
         }
         __syncthreads();
@@ -1004,12 +1060,12 @@ extern "C" int gmk_mcts_run(gmk_mcts* m, int playouts, void* stream) {
         prm.reuse = m->persistent_rec.reuse; prm.noise_alpha = m->persistent_rec.noise_alpha; prm.noise_epsilon = m->persistent_rec.noise_epsilon;
     }
     m->last_stream = static_cast<hipStream_t>(stream);
-    if (prm.persistent)
-        hipLaunchKernelGGL(mcts_playouts_kernel<true>, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
-                           m->d_root_prior, prm);
-    else
-        hipLaunchKernelGGL(mcts_playouts_kernel<false>, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
-                           m->d_root_prior, prm);
+    const int rollout_lanes = m->games_per_block * m->c_rollouts;
+    const bool staged = 2 * rollout_lanes <= 64 && 4 * rollout_lanes > 64;      // the pairs form (mcts_playouts_kernel: kStaged)
+    auto* kernel = prm.persistent ? (staged ? mcts_playouts_kernel<true, true> : mcts_playouts_kernel<true, false>)
+                                  : (staged ? mcts_playouts_kernel<false, true> : mcts_playouts_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds_words(m->games_per_block, m->c_rollouts) * 4, m->last_stream, m->d_headers, m->d_stats, m->d_link, m->d_parent,
+                       m->d_root_prior, prm);
     GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }

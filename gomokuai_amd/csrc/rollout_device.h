@@ -114,6 +114,15 @@ __device__ inline int random_rollout_blocks(uint32_t* lines /* [word * stride], 
     }
 }
 
+// What a rollout carries from one span of blocks to the next (random_rollout_quads_span / _pairs_span): the callers generate a rollout's draws in
+// STAGES -- the first blocks for every rollout, the rest only for the rollouts that are still running after them (a rollout ends after ~100 of up to
+// 220 plies, and a Philox block is ~150 instructions) -- and the rollout stops at the end of a stage and goes on after the next one.
+struct RolloutState {
+    bool live = true;
+    uint32_t won = 0;                              // 2 | parity of the ply that made five, 0: none (yet)
+    __device__ __forceinline__ int winner(int to_move) const { return won ? ((won & 1u) ? -to_move : to_move) : 0; }
+};
+
 // The same rollout on FOUR lanes (an aligned quad of the wavefront, all four called with the same arguments): lane d of the quad keeps
 // the line of direction d through the move's cell (0 row, 1 column, 2 diagonal, 3 anti-diagonal) -- one address, one read, one write and
 // one run test per lane and ply where the single-lane form does four of each, and the quad ORs its four verdicts with two DPP
@@ -190,7 +199,8 @@ __device__ inline int random_rollout_quads(uint32_t* lines /* [word * stride], i
 // writes and one run test (both words' mover halves side by side) per lane and ply, one DPP instruction for the pair's verdict: ~31
 // instructions a ply.
 template <class Fetch>
-__device__ inline int random_rollout_pairs(uint32_t* lines /* [word * stride], in LDS */, uint32_t stride, int to_move, int stones, int no_tie_before, Fetch fetch) {
+__device__ inline bool random_rollout_pairs_span(uint32_t* lines /* [word * stride], in LDS */, uint32_t stride, int to_move, int stones, int no_tie_before, Fetch fetch,
+                                                 RolloutState& state, uint32_t b_from, uint32_t b_to) {
     uint32_t sb = 4u * stride;
     uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32*)lines));
     asm volatile("" : "+v"(sb), "+v"(base));                       // opaque, as in random_rollout_quads
@@ -204,9 +214,9 @@ __device__ inline int random_rollout_pairs(uint32_t* lines /* [word * stride], i
     uint32_t odd_mask = odd ? 0xFFFFFFFFu : 0u;                   // second word's bit position: x on the odd lane (anti-diagonal), y on the even one (column)
     asm volatile("" : "+v"(odd_mask));
     const int last_ply = 224 - stones;
-    uint32_t won = 0;
-    bool live = true;
-    uint2 cur = fetch(0u);
+    uint32_t won = state.won;
+    bool live = state.live;
+    uint2 cur = fetch(b_from);
     uint32_t rw_ahead = *lds_at(base + __umul24(cur.x & 15u, sb));
     auto play_block = [&](auto tie_tag, uint32_t b, const uint2 ahead) -> bool {
         constexpr bool kTie = decltype(tie_tag)::value;
@@ -246,12 +256,21 @@ __device__ inline int random_rollout_pairs(uint32_t* lines /* [word * stride], i
         }
         return false;
     };
-    for (uint32_t b = 0;; ++b) {
-        const uint2 ahead = fetch(b + 1u);
+    for (uint32_t b = b_from; b < b_to; ++b) {
+        const uint2 ahead = b + 1u < b_to ? fetch(b + 1u) : make_uint2(0u, 0u);      // (see random_rollout_quads_span)
         const bool over = static_cast<int>(8u * b) + 7 < no_tie_before ? play_block(std::false_type{}, b, ahead) : play_block(std::true_type{}, b, ahead);
-        if (over) return won ? ((won & 1u) ? -to_move : to_move) : 0;
+        if (over) { state.live = false; state.won = won; return true; }
         cur = ahead;
     }
+    state.live = live; state.won = won;
+    return false;
+}
+
+template <class Fetch>
+__device__ inline int random_rollout_pairs(uint32_t* lines, uint32_t stride, int to_move, int stones, int no_tie_before, Fetch fetch) {
+    RolloutState state;
+    (void)random_rollout_pairs_span(lines, stride, to_move, stones, no_tie_before, fetch, state, 0u, 30u);
+    return state.winner(to_move);
 }
 
 // five or more through cell (x, y) for the colour in bits [shift, shift+15), from line words at lines[word * Stride]
