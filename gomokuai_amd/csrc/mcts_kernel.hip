@@ -42,7 +42,10 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kMaxGamesPerBlock = 16;
 constexpr int kPathCap = 32;           // deeper descents fall back to walking parent[] with loads
 constexpr int kCellBlocks = 30;        // Philox blocks of a rollout: 29 cover 225 plies, one more is read ahead
-constexpr int kStageBlocks = 12;       // ... of which the first twelve (96 plies) are generated for every rollout, the others for those still running then
+#ifndef GMK_STAGE_BLOCKS
+#define GMK_STAGE_BLOCKS 16
+#endif
+constexpr int kStageBlocks = GMK_STAGE_BLOCKS;       // ... of which the first sixteen (128 plies; 12 .. 18 measure within 1 %, 16 best: profiles/r04_k3_stage_blocks.txt) are generated for every rollout, the others for those still running then
 
 struct GameHeader {                 // 128 B per game, in HBM
     uint32_t rows[16];              // root position: black | white << 16 per row
