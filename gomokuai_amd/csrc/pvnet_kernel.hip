@@ -29,6 +29,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPix = 225;
 constexpr int kPad = 289;                        // 17 x 17: the image with a zero border, per channel
@@ -44,7 +45,8 @@ struct PvParams {
     const float* w1;                             // packed A operands, see pack_layer(): [1 tile][27 k-pairs][64 lanes]
     const float* w2;                             // [2 tiles][144][64]
     const float* w3;                             // [4 tiles][288][64]
-    const float* wh;                             // heads: [4 waves][16 registers][64 lanes]
+    const float* whc;                            // heads for the corner pixel: [4 waves][6 rows][32 channels]
+    const float* wh;                             // heads: [4 waves][16 registers policy, 16 registers value][64 lanes], A operands of the 4x4x1 form
     const float* b1; const float* b2; const float* b3; const float* bh;      // biases [32], [64], [128], [6]
     float* pflat;                                // [n][900]  relu(policy conv), flattened (pixel, channel) like tf.layers.flatten of NHWC
     float* vflat;                                // [n][450]  relu(value conv), flattened (pixel, channel)
@@ -67,65 +69,68 @@ __host__ __device__ inline void step_chunk_tap(int step, int chunks, int& chunk,
 // One convolution layer for NP pixel tiles and one tile of 32 output channels: acc[t] += W^T * Act over all k-pairs.
 // k-pair order (= the order pack_layer() writes): steps as step_chunk_tap() numbers them, inside a step CP channel pairs.  `in` points at the layer's input activations in LDS, base[t] is this lane's byte offset for tile t:
 // ((lane >> 5) * kPad + padded_index(pixel) - 18) * 4, so that tap (ky, kx) of channel c adds (c * kPad + ky * 17 + kx) * 4.
-// CORNER: the last tile is pixel tile 7, whose only real pixel is the corner (14, 14): its taps with ky = 2 or kx = 2 read the zero
-// border, so their MFMAs (5 of 9) add exact zeros and are left out.
+// CORNER: 225 pixels are seven tiles and ONE pixel, the corner (14, 14).  A whole MFMA for it would compute 31 columns nobody reads, so it is
+// computed beside the matrix cores: the A operand a lane holds anyway (W[channel lane & 31][k = 2 kp + (lane >> 5)]) times the corner's activation
+// for that k (one more LDS read per k-pair, base[NP], the same address on all lanes of a half) is one v_fma into `corner`, which ends as this
+// lane's half of the k sum for channel lane & 31; the FMA issues in the shadow of the MFMAs.  The corner's taps with ky = 2 or kx = 2 read the
+// zero border, so those steps (5 of 9) leave it out.
 template <int CIN, int NP, bool CORNER = false>
-__device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP], f32x16 (&acc)[NP]) {
+__device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP + (CORNER ? 1 : 0)], f32x16 (&acc)[NP], float& corner) {
     constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
     constexpr int STEPS = CIN / 2 / CP * 9;                      // one step = one tap of one chunk = CP k-pairs
+    constexpr int NB = NP + (CORNER ? 1 : 0);                    // B operands fetched per k-pair
     static_assert(STEPS % 3 == 0, "the step loop is unrolled by three");
     // Operands are fetched AHEAD of the MFMAs that use them, and the scheduling barriers keep the fetches where they are written
     // (left alone, the compiler sinks every load to just before its use, and each MFMA then waits for LDS or L2 behind it):
     //   * a step's CP weights two steps ahead, one global load per k-pair block, into one of three rotating register sets;
-    //   * the NP activation reads of a k-pair one k-pair ahead, one read behind each MFMA of the current k-pair.
+    //   * the NB activation reads of a k-pair one k-pair ahead, one read behind each MFMA of the current k-pair.
     // Three steps per loop iteration make the rotation of the weight sets free of register moves.
     auto step_src = [in](int step) {
         int chunk, tap;
         step_chunk_tap(step, STEPS / 9, chunk, tap);
         return in + (chunk * 2 * CP * kPad + (tap / 3) * 17 + (tap % 3)) * 4;
     };
-    float wA[CP], wB[CP], wC[CP], b[2][NP];
+    float wA[CP], wB[CP], wC[CP], b[2][NB];
 #pragma unroll
     for (int i = 0; i < CP; ++i) { wA[i] = w[i * 64 + lane]; wB[i] = w[(CP + i) * 64 + lane]; }
 #pragma unroll
-    for (int t = 0; t < NP; ++t) b[0][t] = *reinterpret_cast<const float*>(in + base[t]);
-    auto do_step = [&](int step, const float (&wc)[CP], float (&wl)[CP], auto skip_last) {
-        constexpr int NT = decltype(skip_last)::value ? NP - 1 : NP;         // tiles that take part in this step
+    for (int t = 0; t < NB; ++t) b[0][t] = *reinterpret_cast<const float*>(in + base[t]);
+    auto do_step = [&](int step, const float (&wc)[CP], float (&wl)[CP], auto with_corner) {
         const char* src = step_src(step);
         const char* src_next = step_src(min(step + 1, STEPS - 1));
         const float* w_ahead = w + min(step + 2, STEPS - 1) * CP * 64 + lane;
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
             const int cur = cp & 1;
-            const int nr = cp + 1 < CP ? NT : NP;                           // the next step may need the last tile again: always fetch it at the boundary
 #pragma unroll
-            for (int t = 0; t < nr; ++t)
+            for (int t = 0; t < NB; ++t)
                 b[cur ^ 1][t] = *reinterpret_cast<const float*>((cp + 1 < CP ? src + 2 * (cp + 1) * kPad * 4 : src_next) + base[t]);
             wl[cp] = w_ahead[cp * 64];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < NP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
+            if (CORNER && decltype(with_corner)::value) corner = __builtin_fmaf(wc[cp], b[cur][NB - 1], corner);
             // issue order inside this block: MFMA, one LDS read (for the next k-pair), MFMA, one LDS read, ... then the weight load:
             // every fetch sits in the 64-cycle shadow of the MFMA before it
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NP; ++t) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            if (nr > NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (CORNER) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (CP & 1) {                                            // an odd number of k-pairs leaves the current operands in b[1]
 #pragma unroll
-            for (int t = 0; t < NP; ++t) b[0][t] = b[1][t];
+            for (int t = 0; t < NB; ++t) b[0][t] = b[1][t];
         }
     };
-    constexpr std::integral_constant<bool, false> all_tiles{};
-    constexpr std::integral_constant<bool, CORNER> corner_out{};
+    constexpr std::integral_constant<bool, true> corner_in{};
+    constexpr std::integral_constant<bool, false> corner_out{};
 #pragma unroll 1
     for (int step = 0; step < STEPS / 9 * 6; step += 3) {        // three steps = the taps kx = 0, 1, 2 of one kernel row ky < 2
-        do_step(step, wA, wC, all_tiles);
-        do_step(step + 1, wB, wA, all_tiles);
+        do_step(step, wA, wC, corner_in);
+        do_step(step + 1, wB, wA, corner_in);
         do_step(step + 2, wC, wB, corner_out);                   // kx = 2
     }
 #pragma unroll 1
@@ -176,6 +181,7 @@ void pvnet_trunk_kernel(PvParams prm) {
     store_input();
     __syncthreads();
 
+    float no_corner = 0.0f;                                                   // layers 1 and 2 compute the corner with its tile
     unsigned long long t_mark = 0, t_stage[6] = {};
     auto stamp = [&](int stage) {
         if (prm.prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage[stage] += t - t_mark; t_mark = t; }
@@ -191,7 +197,7 @@ void pvnet_trunk_kernel(PvParams prm) {
             float bias1[16];                                                  // of the channels this lane's accumulator registers hold; fetched before
 #pragma unroll                                                                // the layer so that their latency hides behind it
             for (int r = 0; r < 16; ++r) bias1[r] = prm.b1[cd_row(r, lane)];
-            conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc);
+            conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc, no_corner);
             store_tile(lds + oAct1, acc[0], bias1, 0, 2 * wave, lane);
             store_tile(lds + oAct1, acc[1], bias1, 0, 2 * wave + 1, lane);
         }
@@ -208,7 +214,7 @@ void pvnet_trunk_kernel(PvParams prm) {
             float bias2[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) bias2[r] = prm.b2[32 * (wave & 1) + cd_row(r, lane)];
-            conv_tiles<32, 4>(reinterpret_cast<const char*>(lds + oAct1), prm.w2 + static_cast<size_t>(wave & 1) * 144 * 64, lane, base, acc);
+            conv_tiles<32, 4>(reinterpret_cast<const char*>(lds + oAct1), prm.w2 + static_cast<size_t>(wave & 1) * 144 * 64, lane, base, acc, no_corner);
 #pragma unroll
             for (int t = 0; t < 4; ++t) store_tile(lds + oAct2, acc[t], bias2, 32 * (wave & 1), 4 * (wave >> 1) + t, lane);
         }
@@ -216,28 +222,62 @@ void pvnet_trunk_kernel(PvParams prm) {
         __syncthreads();
         stamp(2);
 
-        // ---- layer 3: 64 -> 128, wave w takes channel tile w and all 8 pixel tiles; its output never leaves the registers ----
-        f32x16 acc[kTiles] = {};
-        float bias3[16], wh[16];
+        // ---- layer 3: 64 -> 128, wave w takes channel tile w, the seven full pixel tiles on the matrix cores and the corner pixel beside them;
+        //      its output never leaves the registers ----
+        f32x16 acc[kTiles - 1] = {};
+        float corner = 0.0f;
+        float bias3[16], whp[16], whv[16], whc[kHeadRows];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             bias3[r] = prm.b3[32 * wave + cd_row(r, lane)];
-            wh[r] = prm.wh[(wave * 16 + r) * 64 + lane];
+            whp[r] = prm.wh[(wave * 32 + r) * 64 + lane];
+            whv[r] = prm.wh[(wave * 32 + 16 + r) * 64 + lane];
         }
-        conv_tiles<64, kTiles, true>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc);
+        const float bias3c = prm.b3[32 * wave + (lane & 31)];                 // the corner's channel on this lane is lane & 31
+#pragma unroll
+        for (int j = 0; j < kHeadRows; ++j) whc[j] = prm.whc[(wave * kHeadRows + j) * 32 + (lane & 31)];
+        conv_tiles<64, kTiles - 1, true>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc, corner);
         stamp(3);
 
-        // ---- heads: Out6^T[j][pixel] = sum_c W6^T[j][c] * relu(Out3^T[c][pixel] + b3[c]); register r of the accumulators holds
-        //      channels cd_row(r, .) of this wave's 32 for the two lane halves = the two k of one MFMA ----
+        // ---- heads: Out6^T[j][pixel] = sum_c W6^T[j][c] * relu(Out3^T[c][pixel] + b3[c]).  Six output rows would leave a 32 x 32 tile four fifths
+        //      empty, so the heads run on v_mfma_f32_4x4x1_16B_f32 (16 independent 4 x 4 outer products per instruction, 8 cycles; layout checked
+        //      by tools/mfma4x4_probe.hip): block l / 4 is the four pixels of lanes 4 (l / 4) .. + 3, B = this lane's activation (accumulator
+        //      register r: channel cd_row(r, .) of this wave's 32), A = the head weights of that channel (policy rows 0..3 in one instruction,
+        //      value rows 0..1 in a second), D register i = head row i for this lane's pixel, summed over the 16 registers = the 16 channels of
+        //      this lane half. ----
+        f32x4 hp[kTiles - 1] = {}, hv[kTiles - 1] = {};
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int t = 0; t < kTiles - 1; ++t) {
+                const float x = fmaxf(acc[t][r] + bias3[r], 0.0f);
+                hp[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(whp[r], x, hp[t], 0, 0, 0);
+                hv[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(whv[r], x, hv[t], 0, 0, 0);
+            }
+        // the two lane halves hold the two halves of the wave's channels for the same pixel: one half exchange adds two rows at once (lanes 0..31
+        // end with row a, lanes 32..63 with row b of the pair)
         float* part = lds + oPart;                                            // [wave][8 rows][256 pixels]
+        auto add_halves = [](float a, float b) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+            return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        };
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            f32x16 h = {};
+        for (int t = 0; t < kTiles - 1; ++t) {
+            float* dst = part + (wave * 8 + (lane >> 5)) * 256 + t * 32 + (lane & 31);
+            dst[0 * 256] = add_halves(hp[t][0], hp[t][1]);
+            dst[2 * 256] = add_halves(hp[t][2], hp[t][3]);
+            dst[4 * 256] = add_halves(hv[t][0], hv[t][1]);
+        }
+        // the corner pixel: both halves' k sums make channel lane & 31 (on both halves alike), then six dot products over the wave's 32 channels
+        {
+            const float x = fmaxf(add_halves(corner, corner) + bias3c, 0.0f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wh[r], fmaxf(acc[t][r] + bias3[r], 0.0f), h, 0, 0, 0);
-            // rows 0..3 sit in registers 0..3 of lanes 0..31, rows 4..7 in registers 0..3 of lanes 32..63
+            for (int j = 0; j < kHeadRows; ++j) {
+                float v = x * whc[j];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[(wave * 8 + cd_row(r, lane)) * 256 + t * 32 + (lane & 31)] = h[r];
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                if (lane == 0) part[(wave * 8 + j) * 256 + kPix - 1] = v;
+            }
         }
         __syncthreads();
         stamp(4);
@@ -297,16 +337,20 @@ extern "C" int gmk_pvnet_create(const float* w1, const float* b1, const float* w
     gmk::DeviceState& st = gmk::device_state();
     if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
     if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !wp || !bp || !wv || !bv || !out) { gmk::set_error("gmk_pvnet_create: bad arguments"); return GMK_ERR_ARG; }
-    std::vector<float> p1, p2, p3, ph(4 * 16 * 64, 0.0f), bias(32 + 64 + 128 + 8, 0.0f);
+    std::vector<float> p1, p2, p3, ph(4 * 32 * 64 + 4 * kHeadRows * 32, 0.0f), bias(32 + 64 + 128 + 8, 0.0f);
     pack_layer(w1, 6, 32, p1);
     pack_layer(w2, 32, 64, p2);
     pack_layer(w3, 64, 128, p3);
-    for (int wave = 0; wave < 4; ++wave)                         // A[i = head row j][k = lane >> 5] for accumulator register r of wave `wave`
-        for (int r = 0; r < 16; ++r)
+    for (int wave = 0; wave < 4; ++wave)                         // 4x4x1 A operands: lane l carries row l % 4 of its block, for the channel that accumulator
+        for (int r = 0; r < 16; ++r)                             // register r of wave `wave` holds on that lane half
             for (int lane = 0; lane < 64; ++lane) {
-                const int c = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
-                ph[(wave * 16 + r) * 64 + lane] = j < 4 ? wp[j * 128 + c] : j < 6 ? wv[(j - 4) * 128 + c] : 0.0f;
+                const int c = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 3;
+                ph[(wave * 32 + r) * 64 + lane] = wp[j * 128 + c];
+                ph[(wave * 32 + 16 + r) * 64 + lane] = j < 2 ? wv[j * 128 + c] : 0.0f;
             }
+    for (int wave = 0; wave < 4; ++wave)                         // ... and per channel for the corner pixel
+        for (int j = 0; j < kHeadRows; ++j)
+            for (int c = 0; c < 32; ++c) ph[4 * 32 * 64 + (wave * kHeadRows + j) * 32 + c] = j < 4 ? wp[j * 128 + 32 * wave + c] : wv[(j - 4) * 128 + 32 * wave + c];
     std::memcpy(&bias[0], b1, 32 * 4); std::memcpy(&bias[32], b2, 64 * 4); std::memcpy(&bias[96], b3, 128 * 4);
     std::memcpy(&bias[224], bp, 4 * 4); std::memcpy(&bias[228], bv, 2 * 4);
     gmk_pvnet* net = new gmk_pvnet;
@@ -335,7 +379,7 @@ extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, f
     }
     PvParams prm;
     prm.states = d_states; prm.n = n;
-    prm.w1 = net->d_w1; prm.w2 = net->d_w2; prm.w3 = net->d_w3; prm.wh = net->d_wh;
+    prm.w1 = net->d_w1; prm.w2 = net->d_w2; prm.w3 = net->d_w3; prm.wh = net->d_wh; prm.whc = net->d_wh + 4 * 32 * 64;
     prm.b1 = net->d_b; prm.b2 = net->d_b + 32; prm.b3 = net->d_b + 96; prm.bh = net->d_b + 224;
     prm.pflat = d_pflat; prm.vflat = d_vflat;
     static const bool profile = gmk::profile_env("GMK_PVNET_PROFILE") != nullptr;
