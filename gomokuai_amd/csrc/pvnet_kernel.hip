@@ -57,88 +57,96 @@ __device__ __forceinline__ int padded_index(int p) { return (p / 15 + 1) * 17 + 
 // row of the 32 x 32 C/D tile that register r of this lane holds (cdna_hip_programming.md, fragment layout)
 __device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// The order in which a layer's k-pairs are walked (and packed): steps of CP k-pairs = one tap of one chunk of 2 * CP channels.
-// First the kernel rows ky = 0, 1 of every chunk, then the row ky = 2 of every chunk: the taps that the corner tile may skip
-// (see CORNER below) form one loop of their own.
-__host__ __device__ inline void step_chunk_tap(int step, int chunks, int& chunk, int& tap) {
-    const int first = 6 * chunks;
-    if (step < first) { chunk = step / 6; tap = step - 6 * chunk; }
-    else { chunk = (step - first) / 3; tap = 6 + (step - first) - 3 * chunk; }
-}
+// The order in which a layer's k-pairs are walked (and packed): chunks of 2 * CP input channels; inside a chunk the nine taps; inside a tap
+// ("step") the chunk's CP channel pairs.
+__host__ __device__ inline void step_chunk_tap(int step, int& chunk, int& tap) { chunk = step / 9; tap = step - 9 * chunk; }
 
-// One convolution layer for NP pixel tiles and one tile of 32 output channels: acc[t] += W^T * Act over all k-pairs.
-// k-pair order (= the order pack_layer() writes): steps as step_chunk_tap() numbers them, inside a step CP channel pairs.  `in` points at the layer's input activations in LDS, base[t] is this lane's byte offset for tile t:
+// One convolution layer for NP pixel tiles and one tile of 32 output channels: acc[t] += W^T * Act over all k-pairs (in pack_layer()'s order).
+// `in` points at the layer's input activations in LDS, base[t] is this lane's byte offset for tile t:
 // ((lane >> 5) * kPad + padded_index(pixel) - 18) * 4, so that tap (ky, kx) of channel c adds (c * kPad + ky * 17 + kx) * 4.
-// CORNER: 225 pixels are seven tiles and ONE pixel, the corner (14, 14).  A whole MFMA for it would compute 31 columns nobody reads, so it is
-// computed beside the matrix cores: the A operand a lane holds anyway (W[channel lane & 31][k = 2 kp + (lane >> 5)]) times the corner's activation
-// for that k (one more LDS read per k-pair, base[NP], the same address on all lanes of a half) is one v_fma into `corner`, which ends as this
-// lane's half of the k sum for channel lane & 31; the FMA issues in the shadow of the MFMAs.  The corner's taps with ky = 2 or kx = 2 read the
-// zero border, so those steps (5 of 9) leave it out.
-template <int CIN, int NP, bool CORNER = false>
-__device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP + (CORNER ? 1 : 0)], f32x16 (&acc)[NP], float& corner) {
+//
+// What shapes this loop (tools/mfma_issue_probe.hip, one wavefront per SIMD): back-to-back v_mfma_f32_32x32x2_f32 issue every 64.1 clocks, an LDS
+// read or a global load issued between them costs nothing, but EVERY VECTOR-ALU INSTRUCTION between them costs 20-30 clocks (the f32 matrix
+// instruction runs at the vector FMA rate: it has no shadow for vector work).  So the loop is written to contain none: the nine taps and the CP
+// channel pairs of a chunk are unrolled, which makes every LDS address `a register that changes once per chunk + an immediate` and every weight
+// address `a scalar base + the lane + an immediate`; the only vector instructions left per chunk are the NB address increments and, with CORNER, the
+// corner's v_fma.
+//   * Operands are fetched AHEAD of the MFMAs that use them, and the scheduling barriers keep the fetches where they are written (left alone, the
+//     compiler sinks every load to just before its use, and each MFMA then waits for LDS or L2 behind it): a step's CP weights two steps ahead, one
+//     global load per k-pair block, into one of three rotating register sets (three steps per rotation: no register moves); the NB activation
+//     reads of a k-pair one k-pair ahead, in one burst behind the third MFMA of the current k-pair.  The fetches past the layer's last k-pair read
+//     two steps of padding behind the weights and the LDS behind the activations (both there, both unused).
+//   * CORNER: 225 pixels are seven tiles and ONE pixel, the corner (14, 14).  A whole MFMA for it would compute 31 columns nobody reads, so it is
+//     computed beside the matrix cores: the A operand a lane holds anyway (W[channel lane & 31][k = 2 kp + (lane >> 5)]) times the corner's
+//     activation for that k (one more LDS read per k-pair, base[NB - 1], the same address on all lanes of a half) is one v_fma into `corner`, which
+//     ends as this lane's half of the k sum for channel lane & 31.  The corner's taps with ky = 2 or kx = 2 read the zero border: those five of nine
+//     taps leave it out.
+//   * SHARED: one more pixel tile, acc[NP] / base[NP], takes part in chunk `shared_chunk` only: two waves share that tile's k range and one of them
+//     adds the other's partial sums afterwards -- how layer 2's fourteen tile jobs become 3.5 per wave.
+template <int CIN, int NP, bool CORNER = false, bool SHARED = false>
+__device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0)],
+                                           f32x16 (&acc)[NP + (SHARED ? 1 : 0)], float& corner, int shared_chunk = -1) {
     constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
-    constexpr int STEPS = CIN / 2 / CP * 9;                      // one step = one tap of one chunk = CP k-pairs
-    constexpr int NB = NP + (CORNER ? 1 : 0);                    // B operands fetched per k-pair
-    static_assert(STEPS % 3 == 0, "the step loop is unrolled by three");
-    // Operands are fetched AHEAD of the MFMAs that use them, and the scheduling barriers keep the fetches where they are written
-    // (left alone, the compiler sinks every load to just before its use, and each MFMA then waits for LDS or L2 behind it):
-    //   * a step's CP weights two steps ahead, one global load per k-pair block, into one of three rotating register sets;
-    //   * the NB activation reads of a k-pair one k-pair ahead, one read behind each MFMA of the current k-pair.
-    // Three steps per loop iteration make the rotation of the weight sets free of register moves.
-    auto step_src = [in](int step) {
-        int chunk, tap;
-        step_chunk_tap(step, STEPS / 9, chunk, tap);
-        return in + (chunk * 2 * CP * kPad + (tap / 3) * 17 + (tap % 3)) * 4;
-    };
+    constexpr int CHUNKS = CIN / 2 / CP;
+    constexpr int NB = NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0); // B operands fetched per k-pair
+    constexpr int kChunkBytes = 2 * CP * kPad * 4;               // LDS distance of two chunks
+    uint32_t addr[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) addr[t] = base[t];
+    const float* wl_ptr = w + lane;
     float wA[CP], wB[CP], wC[CP], b[2][NB];
 #pragma unroll
-    for (int i = 0; i < CP; ++i) { wA[i] = w[i * 64 + lane]; wB[i] = w[(CP + i) * 64 + lane]; }
+    for (int i = 0; i < CP; ++i) { wA[i] = wl_ptr[i * 64]; wB[i] = wl_ptr[(CP + i) * 64]; }
 #pragma unroll
-    for (int t = 0; t < NB; ++t) b[0][t] = *reinterpret_cast<const float*>(in + base[t]);
-    auto do_step = [&](int step, const float (&wc)[CP], float (&wl)[CP], auto with_corner) {
-        const char* src = step_src(step);
-        const char* src_next = step_src(min(step + 1, STEPS - 1));
-        const float* w_ahead = w + min(step + 2, STEPS - 1) * CP * 64 + lane;
+    for (int t = 0; t < NB; ++t) b[0][t] = *reinterpret_cast<const float*>(in + addr[t]);
+    auto do_step = [&](auto tap_c, const float (&wc)[CP], float (&wl)[CP], auto with_shared) {
+        constexpr int tap = decltype(tap_c)::value;
+        constexpr bool with_corner = CORNER && tap / 3 < 2 && tap % 3 < 2;
+        constexpr int NT = NP + (decltype(with_shared)::value ? 1 : 0);    // MFMAs per k-pair
+        constexpr int lead = NT >= 4 ? 3 : 1;
+        constexpr int src = ((tap / 3) * 17 + (tap % 3)) * 4;
+        constexpr int src_next = tap < 8 ? (((tap + 1) / 3) * 17 + ((tap + 1) % 3)) * 4 : kChunkBytes;
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
-            const int cur = cp & 1;
+            const int cur = (tap * CP + cp) & 1;
 #pragma unroll
             for (int t = 0; t < NB; ++t)
-                b[cur ^ 1][t] = *reinterpret_cast<const float*>((cp + 1 < CP ? src + 2 * (cp + 1) * kPad * 4 : src_next) + base[t]);
-            wl[cp] = w_ahead[cp * 64];
+                b[cur ^ 1][t] = *reinterpret_cast<const float*>(in + addr[t] + (cp + 1 < CP ? src + 2 * (cp + 1) * kPad * 4 : src_next));
+            wl[cp] = wl_ptr[((tap + 2) * CP + cp) * 64];
 #pragma unroll
-            for (int t = 0; t < NP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
-            if (CORNER && decltype(with_corner)::value) corner = __builtin_fmaf(wc[cp], b[cur][NB - 1], corner);
-            // issue order inside this block: MFMA, one LDS read (for the next k-pair), MFMA, one LDS read, ... then the weight load:
-            // every fetch sits in the 64-cycle shadow of the MFMA before it
-#pragma unroll
-            for (int t = 0; t < NP; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            if (CORNER) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
+            if (with_corner) corner = __builtin_fmaf(wc[cp], b[cur][NB - 1], corner);
+            // issue order inside this block: `lead` MFMAs, the LDS reads and the weight load in their shadow, the other MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, lead, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT - lead, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (CP & 1) {                                            // an odd number of k-pairs leaves the current operands in b[1]
+    };
+    auto chunk_steps = [&](auto with_shared) {
+        do_step(std::integral_constant<int, 0>{}, wA, wC, with_shared); do_step(std::integral_constant<int, 1>{}, wB, wA, with_shared); do_step(std::integral_constant<int, 2>{}, wC, wB, with_shared);
+        do_step(std::integral_constant<int, 3>{}, wA, wC, with_shared); do_step(std::integral_constant<int, 4>{}, wB, wA, with_shared); do_step(std::integral_constant<int, 5>{}, wC, wB, with_shared);
+        do_step(std::integral_constant<int, 6>{}, wA, wC, with_shared); do_step(std::integral_constant<int, 7>{}, wB, wA, with_shared); do_step(std::integral_constant<int, 8>{}, wC, wB, with_shared);
+        if ((9 * CP) & 1) {                                      // an odd number of k-pairs in a chunk leaves the current operands in b[1]
 #pragma unroll
             for (int t = 0; t < NB; ++t) b[0][t] = b[1][t];
         }
     };
-    constexpr std::integral_constant<bool, true> corner_in{};
-    constexpr std::integral_constant<bool, false> corner_out{};
 #pragma unroll 1
-    for (int step = 0; step < STEPS / 9 * 6; step += 3) {        // three steps = the taps kx = 0, 1, 2 of one kernel row ky < 2
-        do_step(step, wA, wC, corner_in);
-        do_step(step + 1, wB, wA, corner_in);
-        do_step(step + 2, wC, wB, corner_out);                   // kx = 2
+    for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+        if (SHARED && chunk == shared_chunk) chunk_steps(std::integral_constant<bool, SHARED>{});
+        else chunk_steps(std::integral_constant<bool, false>{});
+#pragma unroll
+        for (int t = 0; t < NB; ++t) addr[t] += kChunkBytes;
+        wl_ptr += 9 * CP * 64;
     }
-#pragma unroll 1
-    for (int step = STEPS / 9 * 6; step < STEPS; step += 3) {    // ky = 2
-        do_step(step, wA, wC, corner_out);
-        do_step(step + 1, wB, wA, corner_out);
-        do_step(step + 2, wC, wB, corner_out);
-    }
+}
+
+// lanes 0..31 get a[l] + a[l + 32], lanes 32..63 get b[l - 32] + b[l]: one half exchange adds the lane halves of two registers
+__device__ __forceinline__ float add_halves(float a, float b) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
 // bias + ReLU on a C/D tile of 32 channels x 32 pixels and its store into the next layer's activations (valid pixels only)
@@ -182,7 +190,7 @@ void pvnet_trunk_kernel(PvParams prm) {
     __syncthreads();
 
     float no_corner = 0.0f;                                                   // layers 1 and 2 compute the corner with its tile
-    unsigned long long t_mark = 0, t_stage[6] = {};
+    unsigned long long t_mark = 0, t_stage[12] = {};
     auto stamp = [&](int stage) {
         if (prm.prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage[stage] += t - t_mark; t_mark = t; }
     };
@@ -205,18 +213,37 @@ void pvnet_trunk_kernel(PvParams prm) {
         store_input();                                                        // layer 1 is done with the current planes
         stamp(0);
 
-        // ---- layer 2: 32 -> 64, wave w takes channel tile w & 1 and pixel tiles 4 (w >> 1) .. + 3 ----
+        // ---- layer 2: 32 -> 64.  Two channel tiles x (seven pixel tiles + the corner) over four waves: wave w takes channel tile w & 1, three
+        //      pixel tiles of its own (0..2 or 4..6), HALF the k range of pixel tile 3 (its partner w ^ 2 takes the other half; the upper wave
+        //      hands its partial sums over through LDS) and the corner pixel beside the matrix cores (the upper wave's is the one that is kept) ----
         {
+            const int ct = wave & 1, upper = wave >> 1;
             f32x16 acc[4] = {};
-            uint32_t base[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) base[t] = tile_base(4 * (wave >> 1) + t);
+            float corner2 = 0.0f;
+            const uint32_t base[5] = {tile_base(4 * upper), tile_base(4 * upper + 1), tile_base(4 * upper + 2), tile_base(3), tile_base(7)};
             float bias2[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bias2[r] = prm.b2[32 * (wave & 1) + cd_row(r, lane)];
-            conv_tiles<32, 4>(reinterpret_cast<const char*>(lds + oAct1), prm.w2 + static_cast<size_t>(wave & 1) * 144 * 64, lane, base, acc, no_corner);
+            for (int r = 0; r < 16; ++r) bias2[r] = prm.b2[32 * ct + cd_row(r, lane)];
+            const float bias2c = prm.b2[32 * ct + (lane & 31)];
+            conv_tiles<32, 3, true, true>(reinterpret_cast<const char*>(lds + oAct1), prm.w2 + static_cast<size_t>(ct) * 144 * 64, lane, base, acc, corner2, upper);
+            stamp(6);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) store_tile(lds + oAct2, acc[t], bias2, 32 * (wave & 1), 4 * (wave >> 1) + t, lane);
+            for (int t = 0; t < 3; ++t) store_tile(lds + oAct2, acc[t], bias2, 32 * ct, 4 * upper + t, lane);
+            float* handover = lds + oPart + ct * 16 * 64;                     // the head partials' place is free until this position's heads
+            if (upper) {
+                const float v = fmaxf(add_halves(corner2, corner2) + bias2c, 0.0f);
+                if (lane < 32) lds[oAct2 + (32 * ct + lane) * kPad + padded_index(kPix - 1)] = v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) handover[r * 64 + lane] = acc[3][r];
+            }
+            stamp(7);
+            __syncthreads();
+            stamp(8);
+            if (!upper) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[3][r] += handover[r * 64 + lane];
+                store_tile(lds + oAct2, acc[3], bias2, 32 * ct, 3, lane);
+            }
         }
         stamp(1);
         __syncthreads();
@@ -236,6 +263,7 @@ void pvnet_trunk_kernel(PvParams prm) {
         const float bias3c = prm.b3[32 * wave + (lane & 31)];                 // the corner's channel on this lane is lane & 31
 #pragma unroll
         for (int j = 0; j < kHeadRows; ++j) whc[j] = prm.whc[(wave * kHeadRows + j) * 32 + (lane & 31)];
+        stamp(9);
         conv_tiles<64, kTiles - 1, true>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc, corner);
         stamp(3);
 
@@ -257,10 +285,6 @@ void pvnet_trunk_kernel(PvParams prm) {
         // the two lane halves hold the two halves of the wave's channels for the same pixel: one half exchange adds two rows at once (lanes 0..31
         // end with row a, lanes 32..63 with row b of the pair)
         float* part = lds + oPart;                                            // [wave][8 rows][256 pixels]
-        auto add_halves = [](float a, float b) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-            return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        };
 #pragma unroll
         for (int t = 0; t < kTiles - 1; ++t) {
             float* dst = part + (wave * 8 + (lane >> 5)) * 256 + t * 32 + (lane & 31);
@@ -268,6 +292,7 @@ void pvnet_trunk_kernel(PvParams prm) {
             dst[2 * 256] = add_halves(hp[t][2], hp[t][3]);
             dst[4 * 256] = add_halves(hv[t][0], hv[t][1]);
         }
+        stamp(10);
         // the corner pixel: both halves' k sums make channel lane & 31 (on both halves alike), then six dot products over the wave's 32 channels
         {
             const float x = fmaxf(add_halves(corner, corner) + bias3c, 0.0f);
@@ -279,6 +304,7 @@ void pvnet_trunk_kernel(PvParams prm) {
                 if (lane == 0) part[(wave * 8 + j) * 256 + kPix - 1] = v;
             }
         }
+        stamp(11);
         __syncthreads();
         stamp(4);
         // ---- sum the four waves' partial head outputs, bias, ReLU, flatten (pixel, channel) ----
@@ -297,17 +323,17 @@ void pvnet_trunk_kernel(PvParams prm) {
         stamp(5);
     }
     if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0)
-        for (int k = 0; k < 6; ++k) prm.prof[k] = t_stage[k];
+        for (int k = 0; k < 12; ++k) prm.prof[k] = t_stage[k];
 }
 
 // A operands of one layer in lane order: [cout tile][k-pair][64 lanes]; k-pair order as conv_tiles() walks it
 void pack_layer(const float* w /* [cout][cin][3][3] */, int cin, int cout, std::vector<float>& out) {
     const int CP = cin >= 16 ? 8 : cin / 2, chunks = cin / 2 / CP, steps = chunks * 9, kps = steps * CP;
-    out.assign(static_cast<size_t>(cout / 32) * kps * 64, 0.0f);
+    out.assign(static_cast<size_t>(cout / 32) * kps * 64 + 2 * CP * 64, 0.0f);      // + the two steps conv_tiles() fetches past the last tile's end
     for (int tile = 0; tile < cout / 32; ++tile)
         for (int step = 0; step < steps; ++step) {
             int chunk, tap;
-            step_chunk_tap(step, chunks, chunk, tap);
+            step_chunk_tap(step, chunk, tap);
             for (int cp = 0; cp < CP; ++cp) {
                 const int kp = step * CP + cp;
                 for (int lane = 0; lane < 64; ++lane) {
@@ -384,18 +410,20 @@ extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, f
     prm.pflat = d_pflat; prm.vflat = d_vflat;
     static const bool profile = gmk::profile_env("GMK_PVNET_PROFILE") != nullptr;
     prm.prof = nullptr;
-    if (profile) GMK_HIP_CHECK(hipMalloc(&prm.prof, 6 * sizeof(unsigned long long)));
+    if (profile) GMK_HIP_CHECK(hipMalloc(&prm.prof, 12 * sizeof(unsigned long long)));
     const int grid = std::min(n, st.cu_count > 0 ? st.cu_count : 256);        // one workgroup per CU, each takes every grid-th position
     hipLaunchKernelGGL(pvnet_trunk_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), prm);
     GMK_HIP_CHECK(hipGetLastError());
     if (profile) {
-        unsigned long long t[6];
+        unsigned long long t[12];
         GMK_HIP_CHECK(hipDeviceSynchronize());
         GMK_HIP_CHECK(hipMemcpy(t, prm.prof, sizeof t, hipMemcpyDeviceToHost));
         (void)hipFree(prm.prof);
         const double per = 1.0 / ((n + grid - 1) / grid);
-        std::fprintf(stderr, "[GMK_PVNET_PROFILE] shader clocks per position (workgroup 0): layer 1 %.0f, layer 2 %.0f, wait %.0f, layer 3 %.0f, heads %.0f, output %.0f\n",
-                     t[0] * per, t[1] * per, t[2] * per, t[3] * per, t[4] * per, t[5] * per);
+        std::fprintf(stderr, "[GMK_PVNET_PROFILE] shader clocks per position (workgroup 0): layer 1 %.0f, layer 2 %.0f (MFMA loop %.0f, stores %.0f, barrier %.0f, shared tile %.0f), "
+                             "wait %.0f, layer 3 %.0f (operands %.0f, MFMA loop %.0f), heads %.0f (MFMAs + stores %.0f, corner %.0f, barrier %.0f), output %.0f\n",
+                     t[0] * per, (t[6] + t[7] + t[8] + t[1]) * per, t[6] * per, t[7] * per, t[8] * per, t[1] * per, t[2] * per, (t[9] + t[3]) * per, t[9] * per, t[3] * per,
+                     (t[10] + t[11] + t[4]) * per, t[10] * per, t[11] * per, t[4] * per, t[5] * per);
     }
     return GMK_OK;
 }
