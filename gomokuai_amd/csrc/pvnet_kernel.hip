@@ -69,23 +69,23 @@ __host__ __device__ inline void step_chunk_tap(int step, int& chunk, int& tap) {
 // read or a global load issued between them costs nothing, but EVERY VECTOR-ALU INSTRUCTION between them costs 20-30 clocks (the f32 matrix
 // instruction runs at the vector FMA rate: it has no shadow for vector work).  So the loop is written to contain none: the nine taps and the CP
 // channel pairs of a chunk are unrolled, which makes every LDS address `a register that changes once per chunk + an immediate` and every weight
-// address `a scalar base + the lane + an immediate`; the only vector instructions left per chunk are the NB address increments and, with CORNER, the
-// corner's v_fma.
+// address `a scalar base + the lane + an immediate`; the only vector instructions left per chunk are the NB address increments.
 //   * Operands are fetched AHEAD of the MFMAs that use them, and the scheduling barriers keep the fetches where they are written (left alone, the
 //     compiler sinks every load to just before its use, and each MFMA then waits for LDS or L2 behind it): a step's CP weights two steps ahead, one
 //     global load per k-pair block, into one of three rotating register sets (three steps per rotation: no register moves); the NB activation
 //     reads of a k-pair one k-pair ahead, in one burst behind the third MFMA of the current k-pair.  The fetches past the layer's last k-pair read
 //     two steps of padding behind the weights and the LDS behind the activations (both there, both unused).
-//   * CORNER: 225 pixels are seven tiles and ONE pixel, the corner (14, 14).  A whole MFMA for it would compute 31 columns nobody reads, so it is
-//     computed beside the matrix cores: the A operand a lane holds anyway (W[channel lane & 31][k = 2 kp + (lane >> 5)]) times the corner's
-//     activation for that k (one more LDS read per k-pair, base[NB - 1], the same address on all lanes of a half) is one v_fma into `corner`, which
-//     ends as this lane's half of the k sum for channel lane & 31.  The corner's taps with ky = 2 or kx = 2 read the zero border: those five of nine
-//     taps leave it out.
+//   * CORNER: 225 pixels are seven tiles and ONE pixel, the corner (14, 14).  A 32 x 32 MFMA for it would compute 31 columns nobody reads (64
+//     clocks) and a v_fma costs 20-30 here, so it rides on v_mfma_f32_4x4x1_16B_f32 (8 clocks): A = the A operand the lane holds anyway
+//     (W[channel l & 31][k = 2 kp + (l >> 5)]), B = the corner's activation for that k (one more LDS read per k-pair, base[NB - 1]: the same address
+//     on all lanes of a half, so all four columns of a block are the corner).  Block l >> 2 multiplies the A values of its four lanes with that
+//     activation: register i of lane l accumulates channel 4 ((l >> 2) & 7) + i over the k of the lane's half.  The corner's taps with ky = 2 or
+//     kx = 2 read the zero border: those five of nine taps leave it out.
 //   * SHARED: one more pixel tile, acc[NP] / base[NP], takes part in chunk `shared_chunk` only: two waves share that tile's k range and one of them
 //     adds the other's partial sums afterwards -- how layer 2's fourteen tile jobs become 3.5 per wave.
 template <int CIN, int NP, bool CORNER = false, bool SHARED = false>
 __device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0)],
-                                           f32x16 (&acc)[NP + (SHARED ? 1 : 0)], float& corner, int shared_chunk = -1) {
+                                           f32x16 (&acc)[NP + (SHARED ? 1 : 0)], f32x4& corner, int shared_chunk = -1) {
     constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
     constexpr int CHUNKS = CIN / 2 / CP;
     constexpr int NB = NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0); // B operands fetched per k-pair
@@ -115,12 +115,12 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
             wl[cp] = wl_ptr[((tap + 2) * CP + cp) * 64];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
-            if (with_corner) corner = __builtin_fmaf(wc[cp], b[cur][NB - 1], corner);
+            if (with_corner) corner = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[cp], b[cur][NB - 1], corner, 0, 0, 0);
             // issue order inside this block: `lead` MFMAs, the LDS reads and the weight load in their shadow, the other MFMAs
             __builtin_amdgcn_sched_group_barrier(0x008, lead, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NT - lead, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT - lead + (with_corner ? 1 : 0), 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -149,14 +149,15 @@ __device__ __forceinline__ float add_halves(float a, float b) {
     return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-// bias + ReLU on a C/D tile of 32 channels x 32 pixels and its store into the next layer's activations (valid pixels only)
-__device__ __forceinline__ void store_tile(float* out /* [channel][kPad] */, const f32x16& acc, const float (&bias)[16] /* of cd_row(r, lane) */, int cout0, int tile, int lane) {
+// ReLU on a C/D tile of 32 channels x 32 pixels (the bias is what the accumulators started from) and its store into the next layer's activations
+// (valid pixels only)
+__device__ __forceinline__ void store_tile(float* out /* [channel][kPad] */, const f32x16& acc, int cout0, int tile, int lane) {
     const int p = tile * 32 + (lane & 31);
     const int q = padded_index(min(p, kPix - 1));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int c = cout0 + cd_row(r, lane);
-        const float v = fmaxf(acc[r] + bias[r], 0.0f);
+        const float v = fmaxf(acc[r], 0.0f);
         if (p < kPix) out[c * kPad + q] = v;
     }
 }
@@ -189,7 +190,7 @@ void pvnet_trunk_kernel(PvParams prm) {
     store_input();
     __syncthreads();
 
-    float no_corner = 0.0f;                                                   // layers 1 and 2 compute the corner with its tile
+    f32x4 no_corner = {};                                                     // layers 1 and 2 compute the corner with its tile
     unsigned long long t_mark = 0, t_stage[12] = {};
     auto stamp = [&](int stage) {
         if (prm.prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage[stage] += t - t_mark; t_mark = t; }
@@ -200,14 +201,13 @@ void pvnet_trunk_kernel(PvParams prm) {
 
         // ---- layer 1: 6 -> 32, wave w takes pixel tiles 2w, 2w+1 ----
         {
-            f32x16 acc[2] = {};
             const uint32_t base[2] = {tile_base(2 * wave), tile_base(2 * wave + 1)};
-            float bias1[16];                                                  // of the channels this lane's accumulator registers hold; fetched before
-#pragma unroll                                                                // the layer so that their latency hides behind it
-            for (int r = 0; r < 16; ++r) bias1[r] = prm.b1[cd_row(r, lane)];
+            f32x16 acc[2];                                                    // the accumulators start from the bias of the channel they hold
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = prm.b1[cd_row(r, lane)];
             conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc, no_corner);
-            store_tile(lds + oAct1, acc[0], bias1, 0, 2 * wave, lane);
-            store_tile(lds + oAct1, acc[1], bias1, 0, 2 * wave + 1, lane);
+            store_tile(lds + oAct1, acc[0], 0, 2 * wave, lane);
+            store_tile(lds + oAct1, acc[1], 0, 2 * wave + 1, lane);
         }
         __syncthreads();
         store_input();                                                        // layer 1 is done with the current planes
@@ -218,21 +218,29 @@ void pvnet_trunk_kernel(PvParams prm) {
         //      hands its partial sums over through LDS) and the corner pixel beside the matrix cores (the upper wave's is the one that is kept) ----
         {
             const int ct = wave & 1, upper = wave >> 1;
-            f32x16 acc[4] = {};
-            float corner2 = 0.0f;
+            f32x16 acc[4];
+            f32x4 corner2 = {};
             const uint32_t base[5] = {tile_base(4 * upper), tile_base(4 * upper + 1), tile_base(4 * upper + 2), tile_base(3), tile_base(7)};
-            float bias2[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bias2[r] = prm.b2[32 * ct + cd_row(r, lane)];
-            const float bias2c = prm.b2[32 * ct + (lane & 31)];
+            for (int r = 0; r < 16; ++r) {                                    // start from the bias; of the shared tile's two partial sums only one does
+                const float bias = prm.b2[32 * ct + cd_row(r, lane)];
+                acc[0][r] = acc[1][r] = acc[2][r] = bias;
+                acc[3][r] = upper ? 0.0f : bias;
+            }
+            const int corner_channel = 32 * ct + 4 * ((lane >> 2) & 7);       // + i for register i of the corner's accumulator
+            const float4 bias2c = *reinterpret_cast<const float4*>(prm.b2 + corner_channel);
             conv_tiles<32, 3, true, true>(reinterpret_cast<const char*>(lds + oAct1), prm.w2 + static_cast<size_t>(ct) * 144 * 64, lane, base, acc, corner2, upper);
             stamp(6);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) store_tile(lds + oAct2, acc[t], bias2, 32 * ct, 4 * upper + t, lane);
+            for (int t = 0; t < 3; ++t) store_tile(lds + oAct2, acc[t], 32 * ct, 4 * upper + t, lane);
             float* handover = lds + oPart + ct * 16 * 64;                     // the head partials' place is free until this position's heads
             if (upper) {
-                const float v = fmaxf(add_halves(corner2, corner2) + bias2c, 0.0f);
-                if (lane < 32) lds[oAct2 + (32 * ct + lane) * kPad + padded_index(kPix - 1)] = v;
+                const float bias[4] = {bias2c.x, bias2c.y, bias2c.z, bias2c.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = fmaxf(add_halves(corner2[i], corner2[i]) + bias[i], 0.0f);
+                    if ((lane & 35) == 0) lds[oAct2 + (corner_channel + i) * kPad + padded_index(kPix - 1)] = v;     // lanes 0, 4, .. 28
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) handover[r * 64 + lane] = acc[3][r];
             }
@@ -242,7 +250,7 @@ void pvnet_trunk_kernel(PvParams prm) {
             if (!upper) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[3][r] += handover[r * 64 + lane];
-                store_tile(lds + oAct2, acc[3], bias2, 32 * ct, 3, lane);
+                store_tile(lds + oAct2, acc[3], 32 * ct, 3, lane);
             }
         }
         stamp(1);
@@ -251,37 +259,46 @@ void pvnet_trunk_kernel(PvParams prm) {
 
         // ---- layer 3: 64 -> 128, wave w takes channel tile w, the seven full pixel tiles on the matrix cores and the corner pixel beside them;
         //      its output never leaves the registers ----
-        f32x16 acc[kTiles - 1] = {};
-        float corner = 0.0f;
-        float bias3[16], whp[16], whv[16], whc[kHeadRows];
+        f32x16 acc[kTiles - 1];
+        f32x4 corner = {};
+        float whp[16], whv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            bias3[r] = prm.b3[32 * wave + cd_row(r, lane)];
+            const float bias = prm.b3[32 * wave + cd_row(r, lane)];
+#pragma unroll
+            for (int t = 0; t < kTiles - 1; ++t) acc[t][r] = bias;
             whp[r] = prm.wh[(wave * 32 + r) * 64 + lane];
             whv[r] = prm.wh[(wave * 32 + 16 + r) * 64 + lane];
         }
-        const float bias3c = prm.b3[32 * wave + (lane & 31)];                 // the corner's channel on this lane is lane & 31
+        const int corner_channel = 4 * ((lane >> 2) & 7);                     // of this wave's 32, + i for register i of the corner's accumulator
+        const float4 bias3c = *reinterpret_cast<const float4*>(prm.b3 + 32 * wave + corner_channel);
+        float4 whc[kHeadRows];
 #pragma unroll
-        for (int j = 0; j < kHeadRows; ++j) whc[j] = prm.whc[(wave * kHeadRows + j) * 32 + (lane & 31)];
+        for (int j = 0; j < kHeadRows; ++j) whc[j] = *reinterpret_cast<const float4*>(prm.whc + (wave * kHeadRows + j) * 32 + corner_channel);
         stamp(9);
         conv_tiles<64, kTiles - 1, true>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc, corner);
         stamp(3);
 
-        // ---- heads: Out6^T[j][pixel] = sum_c W6^T[j][c] * relu(Out3^T[c][pixel] + b3[c]).  Six output rows would leave a 32 x 32 tile four fifths
+        // ---- heads: Out6^T[j][pixel] = sum_c W6^T[j][c] * relu(Out3^T[c][pixel]).  Six output rows would leave a 32 x 32 tile four fifths
         //      empty, so the heads run on v_mfma_f32_4x4x1_16B_f32 (16 independent 4 x 4 outer products per instruction, 8 cycles; layout checked
         //      by tools/mfma4x4_probe.hip): block l / 4 is the four pixels of lanes 4 (l / 4) .. + 3, B = this lane's activation (accumulator
         //      register r: channel cd_row(r, .) of this wave's 32), A = the head weights of that channel (policy rows 0..3 in one instruction,
         //      value rows 0..1 in a second), D register i = head row i for this lane's pixel, summed over the 16 registers = the 16 channels of
-        //      this lane half. ----
+        //      this lane half.  All ReLUs first, then the MFMAs back to back (vector work between matrix instructions is what costs). ----
+#pragma unroll
+        for (int t = 0; t < kTiles - 1; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.0f);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 hp[kTiles - 1] = {}, hv[kTiles - 1] = {};
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
             for (int t = 0; t < kTiles - 1; ++t) {
-                const float x = fmaxf(acc[t][r] + bias3[r], 0.0f);
-                hp[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(whp[r], x, hp[t], 0, 0, 0);
-                hv[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(whv[r], x, hv[t], 0, 0, 0);
+                hp[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(whp[r], acc[t][r], hp[t], 0, 0, 0);
+                hv[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(whv[r], acc[t][r], hv[t], 0, 0, 0);
             }
+        __builtin_amdgcn_sched_barrier(0);
         // the two lane halves hold the two halves of the wave's channels for the same pixel: one half exchange adds two rows at once (lanes 0..31
         // end with row a, lanes 32..63 with row b of the pair)
         float* part = lds + oPart;                                            // [wave][8 rows][256 pixels]
@@ -293,14 +310,18 @@ void pvnet_trunk_kernel(PvParams prm) {
             dst[4 * 256] = add_halves(hv[t][0], hv[t][1]);
         }
         stamp(10);
-        // the corner pixel: both halves' k sums make channel lane & 31 (on both halves alike), then six dot products over the wave's 32 channels
+        // the corner pixel: the halves' k sums added, bias, ReLU -- four channels per lane, the same four on the four lanes of a block and on both
+        // halves -- then six dot products over the wave's 32 channels = over the eight blocks of a half
         {
-            const float x = fmaxf(add_halves(corner, corner) + bias3c, 0.0f);
+            const float bias[4] = {bias3c.x, bias3c.y, bias3c.z, bias3c.w};
+            float x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = fmaxf(add_halves(corner[i], corner[i]) + bias[i], 0.0f);
 #pragma unroll
             for (int j = 0; j < kHeadRows; ++j) {
-                float v = x * whc[j];
+                float v = ((x[0] * whc[j].x + x[1] * whc[j].y) + x[2] * whc[j].z) + x[3] * whc[j].w;
 #pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                for (int m = 16; m >= 4; m >>= 1) v += __shfl_xor(v, m, 64);
                 if (lane == 0) part[(wave * 8 + j) * 256 + kPix - 1] = v;
             }
         }
