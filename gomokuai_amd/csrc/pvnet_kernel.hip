@@ -35,8 +35,8 @@ constexpr int kPix = 225;
 constexpr int kPad = 289;                        // 17 x 17: the image with a zero border, per channel
 constexpr int kTiles = 8;                        // pixel tiles of 32 (225 -> 256)
 constexpr int kHeadRows = 6;                     // 4 policy + 2 value channels
-// LDS (floats): input planes | layer-1 activations | layer-2 activations | the four waves' partial head outputs [4][8][256]
-constexpr int oIn = 0, oAct1 = oIn + 6 * kPad, oAct2 = oAct1 + 32 * kPad, oPart = oAct2 + 64 * kPad, kLdsFloats = oPart + 4 * 8 * 256;
+// LDS (floats): input planes | layer-1 activations | layer-2 activations | the four waves' partial head outputs [4][8][256] | the three layers' biases
+constexpr int oIn = 0, oAct1 = oIn + 6 * kPad, oAct2 = oAct1 + 32 * kPad, oPart = oAct2 + 64 * kPad, oBias = oPart + 4 * 8 * 256, kLdsFloats = oBias + 32 + 64 + 128;
 constexpr int kInPerThread = (6 * kPix + 255) / 256;
 
 struct PvParams {
@@ -85,7 +85,7 @@ __host__ __device__ inline void step_chunk_tap(int step, int& chunk, int& tap) {
 //     adds the other's partial sums afterwards -- how layer 2's fourteen tile jobs become 3.5 per wave.
 template <int CIN, int NP, bool CORNER = false, bool SHARED = false>
 __device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0)],
-                                           f32x16 (&acc)[NP + (SHARED ? 1 : 0)], f32x4& corner, int shared_chunk = -1) {
+                                           f32x16 (&acc)[NP + (SHARED ? 1 : 0)], f32x4& corner, const float (&first)[CIN >= 16 ? 8 : CIN / 2], int shared_chunk = -1) {
     constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
     constexpr int CHUNKS = CIN / 2 / CP;
     constexpr int NB = NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0); // B operands fetched per k-pair
@@ -96,7 +96,7 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
     const float* wl_ptr = w + lane;
     float wA[CP], wB[CP], wC[CP], b[2][NB];
 #pragma unroll
-    for (int i = 0; i < CP; ++i) { wA[i] = wl_ptr[i * 64]; wB[i] = wl_ptr[(CP + i) * 64]; }
+    for (int i = 0; i < CP; ++i) { wA[i] = first[i]; wB[i] = wl_ptr[(CP + i) * 64]; }      // step 0's are the same for every position: the kernel keeps them, nothing to wait for
 #pragma unroll
     for (int t = 0; t < NB; ++t) b[0][t] = *reinterpret_cast<const float*>(in + addr[t]);
     auto do_step = [&](auto tap_c, const float (&wc)[CP], float (&wl)[CP], auto with_shared) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256)
 void pvnet_trunk_kernel(PvParams prm) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = 0.0f;       // the zero borders are written once
+    for (int i = threadIdx.x; i < kLdsFloats; i += 256) lds[i] = i >= oBias ? prm.b1[i - oBias] : 0.0f;       // the zero borders are written once
     // this lane's read offset for pixel tile t (a pixel past the image reads pixel 224's neighbourhood; its column is never stored)
     auto tile_base = [lane](int t) { return static_cast<uint32_t>(((lane >> 5) * kPad + padded_index(min(t * 32 + (lane & 31), kPix - 1)) - 18) * 4); };
     uint32_t base_all[kTiles];
@@ -177,6 +177,9 @@ void pvnet_trunk_kernel(PvParams prm) {
     // the input planes of a position travel through registers: fetched while the previous position computes, written into LDS
     // (float32 [6][225] -> [6][17 x 17]) once layer 1 has read the previous ones
     float in_next[kInPerThread];
+    int in_at[kInPerThread];                                                  // where this thread's j-th input value goes in LDS (-1: none)
+#pragma unroll
+    for (int j = 0; j < kInPerThread; ++j) { const int i = threadIdx.x + 256 * j; in_at[j] = i < 6 * kPix ? oIn + (i / kPix) * kPad + padded_index(i % kPix) : -1; }
     auto fetch_input = [&](int img) {
         const float* src = prm.states + static_cast<size_t>(min(img, prm.n - 1)) * 6 * kPix;
 #pragma unroll
@@ -184,8 +187,21 @@ void pvnet_trunk_kernel(PvParams prm) {
     };
     auto store_input = [&]() {
 #pragma unroll
-        for (int j = 0; j < kInPerThread; ++j) { const int i = threadIdx.x + 256 * j; if (i < 6 * kPix) lds[oIn + (i / kPix) * kPad + padded_index(i % kPix)] = in_next[j]; }
+        for (int j = 0; j < kInPerThread; ++j) if (in_at[j] >= 0) lds[in_at[j]] = in_next[j];
     };
+    // the output stage's indices are the same for every position too: output i of this thread = head row j of pixel p, bias bh[j]
+    constexpr int kOutPerThread = (kHeadRows * kPix + 255) / 256;
+    int out_from[kOutPerThread];                                              // j * 256 + p in a wave's partials, -1: none
+    float out_bias[kOutPerThread];
+#pragma unroll
+    for (int it = 0; it < kOutPerThread; ++it) {
+        const int i = threadIdx.x + 256 * it;
+        const bool policy = i < 4 * kPix;
+        const int k = policy ? i : i - 4 * kPix;
+        const int p = policy ? k >> 2 : k >> 1, j = policy ? (k & 3) : 4 + (k & 1);
+        out_from[it] = i < kHeadRows * kPix ? j * 256 + p : -1;
+        out_bias[it] = prm.bh[min(j, kHeadRows - 1)];
+    }
     fetch_input(blockIdx.x);
     store_input();
     __syncthreads();
@@ -195,6 +211,16 @@ void pvnet_trunk_kernel(PvParams prm) {
     auto stamp = [&](int stage) {
         if (prm.prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage[stage] += t - t_mark; t_mark = t; }
     };
+    // What is the same for every position and would otherwise be waited for at the start of a layer (an L2 round trip each): the biases the
+    // accumulators start from (in LDS: prm.b1 | b2 | b3 are one array) and the A operands of each layer's first step (in registers).
+    const int ct2 = wave & 1;                                                 // layer 2: this wave's channel tile
+    const float* w2_mine = prm.w2 + static_cast<size_t>(ct2) * 144 * 64;
+    const float* w3_mine = prm.w3 + static_cast<size_t>(wave) * 288 * 64;
+    float w1_first[3], w2_first[8], w3_first[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w2_first[i] = w2_mine[i * 64 + lane]; w3_first[i] = w3_mine[i * 64 + lane]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w1_first[i] = prm.w1[i * 64 + lane];
     if (prm.prof) t_mark = __builtin_amdgcn_s_memtime();
     for (int img = blockIdx.x; img < prm.n; img += gridDim.x) {
         fetch_input(img + gridDim.x);
@@ -204,8 +230,8 @@ void pvnet_trunk_kernel(PvParams prm) {
             const uint32_t base[2] = {tile_base(2 * wave), tile_base(2 * wave + 1)};
             f32x16 acc[2];                                                    // the accumulators start from the bias of the channel they hold
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = prm.b1[cd_row(r, lane)];
-            conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc, no_corner);
+            for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = lds[oBias + cd_row(r, lane)];
+            conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc, no_corner, w1_first);
             store_tile(lds + oAct1, acc[0], 0, 2 * wave, lane);
             store_tile(lds + oAct1, acc[1], 0, 2 * wave + 1, lane);
         }
@@ -217,19 +243,19 @@ void pvnet_trunk_kernel(PvParams prm) {
         //      pixel tiles of its own (0..2 or 4..6), HALF the k range of pixel tile 3 (its partner w ^ 2 takes the other half; the upper wave
         //      hands its partial sums over through LDS) and the corner pixel beside the matrix cores (the upper wave's is the one that is kept) ----
         {
-            const int ct = wave & 1, upper = wave >> 1;
+            const int ct = ct2, upper = wave >> 1;
             f32x16 acc[4];
             f32x4 corner2 = {};
             const uint32_t base[5] = {tile_base(4 * upper), tile_base(4 * upper + 1), tile_base(4 * upper + 2), tile_base(3), tile_base(7)};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                                    // start from the bias; of the shared tile's two partial sums only one does
-                const float bias = prm.b2[32 * ct + cd_row(r, lane)];
+                const float bias = lds[oBias + 32 + 32 * ct + cd_row(r, lane)];
                 acc[0][r] = acc[1][r] = acc[2][r] = bias;
                 acc[3][r] = upper ? 0.0f : bias;
             }
             const int corner_channel = 32 * ct + 4 * ((lane >> 2) & 7);       // + i for register i of the corner's accumulator
             const float4 bias2c = *reinterpret_cast<const float4*>(prm.b2 + corner_channel);
-            conv_tiles<32, 3, true, true>(reinterpret_cast<const char*>(lds + oAct1), prm.w2 + static_cast<size_t>(ct) * 144 * 64, lane, base, acc, corner2, upper);
+            conv_tiles<32, 3, true, true>(reinterpret_cast<const char*>(lds + oAct1), w2_mine, lane, base, acc, corner2, w2_first, upper);
             stamp(6);
 #pragma unroll
             for (int t = 0; t < 3; ++t) store_tile(lds + oAct2, acc[t], 32 * ct, 4 * upper + t, lane);
@@ -264,9 +290,8 @@ void pvnet_trunk_kernel(PvParams prm) {
         float whp[16], whv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float bias = prm.b3[32 * wave + cd_row(r, lane)];
 #pragma unroll
-            for (int t = 0; t < kTiles - 1; ++t) acc[t][r] = bias;
+            for (int t = 0; t < kTiles - 1; ++t) acc[t][r] = lds[oBias + 96 + 32 * wave + cd_row(r, lane)];
             whp[r] = prm.wh[(wave * 32 + r) * 64 + lane];
             whv[r] = prm.wh[(wave * 32 + 16 + r) * 64 + lane];
         }
@@ -276,7 +301,7 @@ void pvnet_trunk_kernel(PvParams prm) {
 #pragma unroll
         for (int j = 0; j < kHeadRows; ++j) whc[j] = *reinterpret_cast<const float4*>(prm.whc + (wave * kHeadRows + j) * 32 + corner_channel);
         stamp(9);
-        conv_tiles<64, kTiles - 1, true>(reinterpret_cast<const char*>(lds + oAct2), prm.w3 + static_cast<size_t>(wave) * 288 * 64, lane, base_all, acc, corner);
+        conv_tiles<64, kTiles - 1, true>(reinterpret_cast<const char*>(lds + oAct2), w3_mine, lane, base_all, acc, corner, w3_first);
         stamp(3);
 
         // ---- heads: Out6^T[j][pixel] = sum_c W6^T[j][c] * relu(Out3^T[c][pixel]).  Six output rows would leave a 32 x 32 tile four fifths
@@ -331,14 +356,14 @@ void pvnet_trunk_kernel(PvParams prm) {
         // ---- sum the four waves' partial head outputs, bias, ReLU, flatten (pixel, channel) ----
         float* pf = prm.pflat + static_cast<size_t>(img) * 4 * kPix;
         float* vf = prm.vflat + static_cast<size_t>(img) * 2 * kPix;
-        for (int i = threadIdx.x; i < kHeadRows * kPix; i += 256) {
-            // policy outputs first (index = pixel * 4 + channel), then value outputs (pixel * 2 + channel): coalesced stores
-            const bool policy = i < 4 * kPix;
-            const int k = policy ? i : i - 4 * kPix;
-            const int p = policy ? k >> 2 : k >> 1, j = policy ? (k & 3) : 4 + (k & 1);
-            const float s = ((part[(0 * 8 + j) * 256 + p] + part[(1 * 8 + j) * 256 + p]) + part[(2 * 8 + j) * 256 + p]) + part[(3 * 8 + j) * 256 + p];
-            const float v = fmaxf(s + prm.bh[j], 0.0f);
-            if (policy) pf[k] = v; else vf[k] = v;
+        // policy outputs first (index = pixel * 4 + channel), then value outputs (pixel * 2 + channel): coalesced stores
+#pragma unroll
+        for (int it = 0; it < kOutPerThread; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            if (out_from[it] < 0) continue;
+            const float* src = part + out_from[it];
+            const float v = fmaxf((((src[0 * 8 * 256] + src[1 * 8 * 256]) + src[2 * 8 * 256]) + src[3 * 8 * 256]) + out_bias[it], 0.0f);
+            if (i < 4 * kPix) pf[i] = v; else vf[i - 4 * kPix] = v;
         }
         // no barrier here: the partials are next written behind the two barriers of the next position's layers 1 and 2
         stamp(5);
