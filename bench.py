@@ -406,7 +406,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
     moves, lens, planes, _ = mcts_openings(G, np, n, rank * n)
     last = np.stack([moves[np.arange(n), lens - 1], moves[np.arange(n), lens - 2]], 1).astype(np.int16)
     net = PolicyValueNetwork(seed=1).to(dev).eval()
-    fused = FusedPolicyValueNetwork(net)                   # K9: the convolutions as one fused f32-MFMA kernel, the dense layers in PyTorch
+    fused = FusedPolicyValueNetwork(net)                   # K9: the convolutions as one fused f32-MFMA kernel, the dense layers + softmax / tanh as a second
     tree = G.AlphaZeroMCTS(n, node_capacity=(P + 4) * 225 + 1)
     tree.set_roots(planes, last)
     with torch.no_grad():
@@ -466,8 +466,8 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
                          "frac": conv_flop / (trunk_ms * 1e-3) / 1e12 / 157.3, "traffic": measured_traffic("pvnet_trunk_kernel", "positions_per_launch", n), "traffic_source": "profiles/traffic.json (committed rocprofv3 PMC passes; not re-measured in this run)", "kernel": "pvnet_trunk_kernel", "kernel_ms": trunk_ms,
                          "alg_flop_per_launch": conv_flop, "note": "dense f32-input MFMA peak (MI355X_MICROARCH.md); the convolution FLOPs of the 225 real pixels"},
             "pytorch_module_ms_per_step": torch_ms, "max_abs_diff_vs_pytorch_module": err, "selfplay_pipeline": pipeline,
-            "note": "the step is the network's forward pass: K9 (one fused kernel for the convolutions, float32 MFMA) + three small dense layers through PyTorch-ROCm; "
-                    "the select and expand kernels take the remainder"}
+            "note": "the step is the network's forward pass, two HIP kernels (gmk_pvnet_evaluate): K9's fused convolution trunk and the dense layers with softmax / tanh, "
+                    "both float32 MFMA; the select and expand kernels take the remainder"}
 
 
 REFERENCE_NOISE = (0.05, 0.25)      # Default::AddNoise's defaults (MonteCarlo.hpp:97), what MCTS::runPlayouts calls it with (MCTS.cpp:182)

@@ -1,24 +1,25 @@
-// pvnet_kernel.hip -- K9: the convolutional trunk of the policy-value network as ONE fused kernel on the f32 matrix cores.
+// pvnet_kernel.hip -- K9: the policy-value network on the f32 matrix cores: its convolutional trunk as ONE fused kernel, its dense layers as a second.
 //
 // The network the network-guided search (K7) calls at every leaf is the reference's PolicyValueNetwork
 // (network/model_tf.py:28-66): conv3x3 6->32->64->128 (+ReLU), a 1x1 policy head (128->4, ReLU) and a 1x1 value head
 // (128->2, ReLU) on 15x15 boards, then small dense layers.  The convolutions are 99 % of its arithmetic (43 MFLOP per
-// position).  This kernel runs them for a batch of positions in float32 on v_mfma_f32_32x32x2_f32 (exact f32, same rate as
+// position).  pvnet_trunk_kernel runs them for a batch of positions in float32 on v_mfma_f32_32x32x2_f32 (exact f32, same rate as
 // the vector FMA peak, MI355X_MICROARCH.md): one workgroup (4 wavefronts, one per SIMD) takes one position at a time and
 // keeps every activation in LDS; nothing but the 6 input planes is read from and nothing but the 1 350 head activations is
-// written to HBM per position.  The dense layers stay with the caller (a batched GEMM over all positions, PyTorch-ROCm).
+// written to HBM per position.  pvnet_dense_kernel (further down) turns those into the value and the 225 probabilities.
 //
 // Formulation: every layer is Out^T[cout][pixel] = sum_k W^T[cout][k] * Act[k][pixel], k = (channel pair, tap):
 //   A operand (lane l: A[i = l & 31][k = l >> 5]) = weights, packed on the host in exactly that lane order, read from L2;
 //   B operand (lane l: B[k = l >> 5][j = l & 31]) = activations of 32 pixels for two adjacent input channels at one tap,
 //     one ds_read_b32 per MFMA: activations live in LDS as act[channel][17 x 17] with a zero border, so a tap is a
 //     constant address offset and "same" padding costs nothing;
-//   C/D (column = pixel on the lane, rows = 16 output channels in registers per lane half) -> bias, ReLU, one LDS write per
-//     register, conflict-free (lanes = consecutive pixels).
-// The 1x1 heads reuse the layer-3 accumulators as B operands directly (rows = channels = the summation index, the idiom
-// of cdna_hip_programming.md "An accumulator tile as the next MFMA's operand"): no transpose, no LDS round trip.
-// Wave w owns output channels [32 w, 32 w + 32) of layer 3 for all 8 pixel tiles (128 accumulator registers); layer 2
-// splits 2 channel tiles x 2 pixel halves over the waves, layer 1 the 8 pixel tiles.
+//   C/D (column = pixel on the lane, rows = 16 output channels in registers per lane half) start from the bias -> ReLU, one LDS
+//     write per register, conflict-free (lanes = consecutive pixels).
+// 225 pixels are seven tiles of 32 and the corner (14, 14), which rides on v_mfma_f32_4x4x1_16B_f32 beside them (conv_tiles()).
+// The 1x1 heads use the layer-3 accumulators as B operands directly (the idiom of cdna_hip_programming.md "An accumulator tile as
+// the next MFMA's operand": no transpose, no LDS round trip), on the 4x4x1 form as well: six output rows fill it, a 32 x 32 tile not.
+// Wave w owns output channels [32 w, 32 w + 32) of layer 3 for the 7 pixel tiles + the corner (112 + 4 accumulator registers);
+// layer 2 gives each wave one of 2 channel tiles, 3 pixel tiles and half the k range of a fourth; layer 1 the 8 pixel tiles, two each.
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -372,6 +373,164 @@ void pvnet_trunk_kernel(PvParams prm) {
         for (int k = 0; k < 12; ++k) prm.prof[k] = t_stage[k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The three dense layers behind the trunk (network/model_tf.py:53-66): policy = softmax(dense 900 -> 225), value = tanh(dense 64 -> 1 of
+// relu(dense 450 -> 64)), 0.46 MFLOP per position -- 1 % of the network, one small kernel.  One workgroup takes 16 positions: their 1 350 head
+// activations are staged in LDS, every layer is Out[position][output] = sum_k Act[position][k] W^T[k][output] on v_mfma_f32_16x16x4_f32 (A =
+// activations, one conflict-free ds_read_b32 per step: row stride 900 and 452 floats = 4 banks; B = weights, packed on the host in lane order
+// per (output tile, step of 4 k) and streamed from L2).  Wave w owns the policy's output tiles w, w + 4, w + 8, w + 12 (225 outputs = 15 tiles of
+// 16; the 16th is zero weights) and tile w of the 64 hidden units; the hidden layer's 450 k ride along the first 117 steps of the policy's 225.
+// Steps come in bodies of nine with all addresses `register + immediate` (vector instructions between f32 MFMAs cost 20-30 clocks each, see
+// conv_tiles()), and a body fetches the NEXT body's weights before its own MFMAs start (two register sets).  Then bias, the logits and hidden
+// units through LDS, and per position one wavefront's softmax / dot product + tanh.
+constexpr int kDensePos = 16;                      // positions per workgroup
+constexpr int kDenseBody = 9;                      // steps (of 4 k) per body: 225 = 25 bodies, the hidden layer's 113 -> 117 = 13 bodies
+constexpr int kPolicySteps = 225, kHiddenSteps = 13 * kDenseBody;
+constexpr int kVfStride = 452;
+constexpr int oDensePf = 0, oDenseVf = kDensePos * 900, kDenseLdsFloats = oDenseVf + kDensePos * kVfStride + 16;
+// after the MFMAs the logits [16][256] take the place of the policy activations, the hidden units [16][64] that of the value activations
+
+struct DenseParams {
+    const float* pflat; const float* vflat; int n;
+    const float* wp;                               // [16 tiles][225 steps][64 lanes] + one body of padding
+    const float* wv;                               // [4 tiles][117 + 9 steps][64 lanes]
+    const float* bp;                               // [256]: the policy's biases, 0 behind the 225th
+    const float* bhid; const float* wo; float bo;  // [64], [64]
+    float* value; float* probs;                    // [n], [n][225]
+};
+
+__global__ __launch_bounds__(256)
+void pvnet_dense_kernel(DenseParams prm) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pos0 = blockIdx.x * kDensePos, npos = min(kDensePos, prm.n - pos0);
+    // ---- stage the 16 positions' activations (rows of positions past the batch are zeros): all loads first (16 and 8 bytes per lane), then the
+    //      LDS writes; the policy rows are contiguous in both places, the value rows go from 450 to 452 floats apart ----
+    {
+        constexpr int kPfVec = kDensePos * 900 / 4;                                       // 3 600 float4, and as many float2 of the value rows
+        static_assert(kPfVec == kDensePos * 450 / 2, "one index walks both");
+        constexpr int kPerThread = (kPfVec + 255) / 256;                                  // 15 of each per thread
+        const float4* src = reinterpret_cast<const float4*>(prm.pflat + static_cast<size_t>(pos0) * 900);
+        const float2* srcv = reinterpret_cast<const float2*>(prm.vflat + static_cast<size_t>(pos0) * 450);
+        float4 p4[kPerThread];
+        float2 v2[kPerThread];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            p4[j] = i < npos * 225 ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // 225 float4 per row
+            v2[j] = i < npos * 225 ? srcv[i] : make_float2(0.0f, 0.0f);                  // 225 float2 per row
+        }
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < kPfVec) {
+                reinterpret_cast<float4*>(lds + oDensePf)[i] = p4[j];
+                const int r = i / 225, c = i - r * 225;
+                *reinterpret_cast<float2*>(lds + oDenseVf + r * kVfStride + 2 * c) = v2[j];
+            }
+        }
+        if (threadIdx.x < kDensePos + 8) {                                              // the two pad columns of every row and the 16 floats behind the last
+            if (threadIdx.x < kDensePos) *reinterpret_cast<float2*>(lds + oDenseVf + threadIdx.x * kVfStride + 450) = make_float2(0.0f, 0.0f);
+            else *reinterpret_cast<float2*>(lds + oDenseVf + kDensePos * kVfStride + 2 * (threadIdx.x - kDensePos)) = make_float2(0.0f, 0.0f);
+        }
+    }
+    __syncthreads();
+    f32x4 acc[4] = {}, acch = {};
+    const char* a_pf = reinterpret_cast<const char*>(lds + oDensePf + (lane & 15) * 900 + (lane >> 4));        // + 16 bytes per step
+    const char* a_vf = reinterpret_cast<const char*>(lds + oDenseVf + (lane & 15) * kVfStride + (lane >> 4));
+    const float* wp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wp[q] = prm.wp + static_cast<size_t>(wave + 4 * q) * kPolicySteps * 64 + lane;
+    const float* wv = prm.wv + static_cast<size_t>(wave) * (kHiddenSteps + kDenseBody) * 64 + lane;
+    float bw[2][kDenseBody][4], bh[2][kDenseBody];
+    auto fetch = [&](float (&w4)[kDenseBody][4], float (&w1)[kDenseBody], int body, auto with_hidden) {
+#pragma unroll
+        for (int s = 0; s < kDenseBody; ++s) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4[s][q] = wp[q][(body * kDenseBody + s) * 64];
+            if (decltype(with_hidden)::value) w1[s] = wv[(body * kDenseBody + s) * 64];
+        }
+    };
+    auto body_mfmas = [&](const float (&w4)[kDenseBody][4], const float (&w1)[kDenseBody], int body, auto with_hidden) {
+        const char* ap = a_pf + body * kDenseBody * 16;
+        const char* av = a_vf + body * kDenseBody * 16;
+#pragma unroll
+        for (int s = 0; s < kDenseBody; ++s) {
+            const float a = *reinterpret_cast<const float*>(ap + s * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w4[s][q], acc[q], 0, 0, 0);
+            if (decltype(with_hidden)::value) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(*reinterpret_cast<const float*>(av + s * 16), w1[s], acch, 0, 0, 0);
+        }
+    };
+    constexpr std::integral_constant<bool, true> yes{};
+    constexpr std::integral_constant<bool, false> no{};
+    fetch(bw[0], bh[0], 0, yes);
+#pragma unroll 1
+    for (int body = 0; body < 12; body += 2) {                                // bodies 0 .. 11
+        fetch(bw[1], bh[1], body + 1, yes); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[0], bh[0], body, yes); __builtin_amdgcn_sched_barrier(0);
+        fetch(bw[0], bh[0], body + 2, yes); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[1], bh[1], body + 1, yes); __builtin_amdgcn_sched_barrier(0);
+    }
+    fetch(bw[1], bh[1], 13, no); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[0], bh[0], 12, yes); __builtin_amdgcn_sched_barrier(0);      // body 12: the hidden layer's last
+#pragma unroll 1
+    for (int body = 13; body < 25; body += 2) {                               // bodies 13 .. 24, policy only (the last fetch reads the padding)
+        fetch(bw[0], bh[0], body + 1, no); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[1], bh[1], body, no); __builtin_amdgcn_sched_barrier(0);
+        fetch(bw[1], bh[1], body + 2, no); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[0], bh[0], body + 1, no); __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                                          // everybody is done with the activations: their place is reused
+    // ---- C/D: column (output) = lane & 15, row (position) = 4 (lane >> 4) + register ----
+    float* logits = lds + oDensePf;                                           // [16][256]
+    float* hidden = lds + oDenseVf;                                           // [16][64]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = (wave + 4 * q) * 16 + (lane & 15);
+        const float bias = prm.bp[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) logits[(4 * (lane >> 4) + r) * 256 + col] = acc[q][r] + bias;
+    }
+    {
+        const int col = wave * 16 + (lane & 15);
+        const float bias = prm.bhid[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hidden[(4 * (lane >> 4) + r) * 64 + col] = fmaxf(acch[r] + bias, 0.0f);
+    }
+    __syncthreads();
+    // ---- per position (four per wave, side by side so that their reductions overlap): softmax over the 225 logits, tanh of the hidden units' dot
+    //      product ----
+    const float wo = prm.wo[lane];
+    float x[4][4], m[4], sum[4], v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * wave + i;
+        m[i] = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int c = lane + 64 * e; x[i][e] = c < kPix ? logits[row * 256 + c] : -INFINITY; m[i] = fmaxf(m[i], x[i][e]); }
+        v[i] = hidden[row * 64 + lane] * wo;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[i] = fmaxf(m[i], __shfl_xor(m[i], s, 64)); v[i] += __shfl_xor(v[i], s, 64); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sum[i] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[i][e] = expf(x[i][e] - m[i]); sum[i] += x[i][e]; }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] += __shfl_xor(sum[i], s, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * wave + i;
+        if (row >= npos) break;
+        float* out = prm.probs + static_cast<size_t>(pos0 + row) * kPix;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int c = lane + 64 * e; if (c < kPix) out[c] = x[i][e] / sum[i]; }
+        if (lane == 0) prm.value[pos0 + row] = tanhf(v[i] + prm.bo);
+    }
+}
+
 // A operands of one layer in lane order: [cout tile][k-pair][64 lanes]; k-pair order as conv_tiles() walks it
 void pack_layer(const float* w /* [cout][cin][3][3] */, int cin, int cout, std::vector<float>& out) {
     const int CP = cin >= 16 ? 8 : cin / 2, chunks = cin / 2 / CP, steps = chunks * 9, kps = steps * CP;
@@ -395,11 +554,18 @@ void pack_layer(const float* w /* [cout][cin][3][3] */, int cin, int cout, std::
 struct gmk_pvnet {
     float *d_w1 = nullptr, *d_w2 = nullptr, *d_w3 = nullptr, *d_wh = nullptr, *d_b = nullptr;
     bool attr_set = false;
+    // the dense layers (gmk_pvnet_set_dense): packed weights, biases (policy [256] | hidden [64] | output weights [64]), the output bias, and the
+    // head activations between the two kernels of gmk_pvnet_evaluate ([capacity][900 + 450], grown on demand)
+    float *d_wp = nullptr, *d_wv = nullptr, *d_dense = nullptr, *d_flat = nullptr;
+    float b_out = 0.0f;
+    bool has_dense = false, dense_attr_set = false;
+    int flat_capacity = 0;
 };
 
 extern "C" int gmk_pvnet_destroy(gmk_pvnet* net) {
     if (!net) return GMK_OK;
     (void)hipFree(net->d_w1); (void)hipFree(net->d_w2); (void)hipFree(net->d_w3); (void)hipFree(net->d_wh); (void)hipFree(net->d_b);
+    (void)hipFree(net->d_wp); (void)hipFree(net->d_wv); (void)hipFree(net->d_dense); (void)gmk::device_free(net->d_flat);
     delete net;
     return GMK_OK;
 }
@@ -439,11 +605,10 @@ extern "C" int gmk_pvnet_create(const float* w1, const float* b1, const float* w
     return GMK_OK;
 }
 
-extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, float* d_pflat, float* d_vflat, void* stream) {
+namespace {
+
+int launch_trunk(gmk_pvnet* net, const float* d_states, int n, float* d_pflat, float* d_vflat, hipStream_t stream) {
     gmk::DeviceState& st = gmk::device_state();
-    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
-    if (!net || n < 0 || (n > 0 && (!d_states || !d_pflat || !d_vflat))) { gmk::set_error("gmk_pvnet_forward: bad arguments"); return GMK_ERR_ARG; }
-    if (n == 0) return GMK_OK;
     const size_t lds = static_cast<size_t>(kLdsFloats) * 4;
     if (!net->attr_set) {
         GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pvnet_trunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -458,7 +623,7 @@ extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, f
     prm.prof = nullptr;
     if (profile) GMK_HIP_CHECK(hipMalloc(&prm.prof, 12 * sizeof(unsigned long long)));
     const int grid = std::min(n, st.cu_count > 0 ? st.cu_count : 256);        // one workgroup per CU, each takes every grid-th position
-    hipLaunchKernelGGL(pvnet_trunk_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), prm);
+    hipLaunchKernelGGL(pvnet_trunk_kernel, dim3(grid), dim3(256), lds, stream, prm);
     GMK_HIP_CHECK(hipGetLastError());
     if (profile) {
         unsigned long long t[12];
@@ -471,5 +636,78 @@ extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, f
                      t[0] * per, (t[6] + t[7] + t[8] + t[1]) * per, t[6] * per, t[7] * per, t[8] * per, t[1] * per, t[2] * per, (t[9] + t[3]) * per, t[9] * per, t[3] * per,
                      (t[10] + t[11] + t[4]) * per, t[10] * per, t[11] * per, t[4] * per, t[5] * per);
     }
+    return GMK_OK;
+}
+
+}  // namespace
+
+extern "C" int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, float* d_pflat, float* d_vflat, void* stream) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!net || n < 0 || (n > 0 && (!d_states || !d_pflat || !d_vflat))) { gmk::set_error("gmk_pvnet_forward: bad arguments"); return GMK_ERR_ARG; }
+    if (n == 0) return GMK_OK;
+    return launch_trunk(net, d_states, n, d_pflat, d_vflat, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gmk_pvnet_set_dense(gmk_pvnet* net, const float* w_policy, const float* b_policy, const float* w_hidden, const float* b_hidden,
+                                   const float* w_out, float b_out) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!net || !w_policy || !b_policy || !w_hidden || !b_hidden || !w_out) { gmk::set_error("gmk_pvnet_set_dense: bad arguments"); return GMK_ERR_ARG; }
+    // B operands of v_mfma_f32_16x16x4_f32 in lane order: lane l carries W[output = 16 tile + (l & 15)][k = 4 step + (l >> 4)]
+    std::vector<float> wp((static_cast<size_t>(16) * kPolicySteps + kDenseBody) * 64, 0.0f), wv(static_cast<size_t>(4) * (kHiddenSteps + kDenseBody) * 64, 0.0f),
+        dense(256 + 64 + 64, 0.0f);
+    for (int tile = 0; tile < 16; ++tile)
+        for (int step = 0; step < kPolicySteps; ++step)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = 16 * tile + (lane & 15), k = 4 * step + (lane >> 4);
+                if (o < kPix) wp[(static_cast<size_t>(tile) * kPolicySteps + step) * 64 + lane] = w_policy[static_cast<size_t>(o) * 900 + k];
+            }
+    for (int tile = 0; tile < 4; ++tile)
+        for (int step = 0; step < kHiddenSteps; ++step)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = 16 * tile + (lane & 15), k = 4 * step + (lane >> 4);
+                if (k < 450) wv[(static_cast<size_t>(tile) * (kHiddenSteps + kDenseBody) + step) * 64 + lane] = w_hidden[static_cast<size_t>(o) * 450 + k];
+            }
+    std::memcpy(&dense[0], b_policy, kPix * 4); std::memcpy(&dense[256], b_hidden, 64 * 4); std::memcpy(&dense[320], w_out, 64 * 4);
+    if (!net->d_wp) {
+        const bool ok = hipMalloc(&net->d_wp, wp.size() * 4) == hipSuccess && hipMalloc(&net->d_wv, wv.size() * 4) == hipSuccess &&
+                        hipMalloc(&net->d_dense, dense.size() * 4) == hipSuccess;
+        if (!ok) { gmk::set_error("gmk_pvnet_set_dense: device allocation failed"); return GMK_ERR_HIP; }
+    }
+    GMK_HIP_CHECK(hipMemcpy(net->d_wp, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(net->d_wv, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
+    GMK_HIP_CHECK(hipMemcpy(net->d_dense, dense.data(), dense.size() * 4, hipMemcpyHostToDevice));
+    net->b_out = b_out;
+    net->has_dense = true;
+    return GMK_OK;
+}
+
+extern "C" int gmk_pvnet_evaluate(gmk_pvnet* net, const float* d_states, int n, float* d_value, float* d_probs, void* stream) {
+    gmk::DeviceState& st = gmk::device_state();
+    if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
+    if (!net || n < 0 || (n > 0 && (!d_states || !d_value || !d_probs))) { gmk::set_error("gmk_pvnet_evaluate: bad arguments"); return GMK_ERR_ARG; }
+    if (!net->has_dense) { gmk::set_error("gmk_pvnet_evaluate: the dense layers have not been set (gmk_pvnet_set_dense)"); return GMK_ERR_STATE; }
+    if (n == 0) return GMK_OK;
+    if (n > net->flat_capacity) {                                // the head activations between the two kernels; grows, never shrinks
+        if (net->d_flat) { GMK_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream))); (void)gmk::device_free(net->d_flat); net->d_flat = nullptr; net->flat_capacity = 0; }
+        const int capacity = std::max(n, 1024);
+        GMK_HIP_CHECK(gmk::device_malloc(&net->d_flat, static_cast<size_t>(capacity) * 1350 * sizeof(float)));
+        net->flat_capacity = capacity;
+    }
+    float* d_pflat = net->d_flat;
+    float* d_vflat = net->d_flat + static_cast<size_t>(net->flat_capacity) * 900;
+    const int rc = launch_trunk(net, d_states, n, d_pflat, d_vflat, static_cast<hipStream_t>(stream));
+    if (rc != GMK_OK) return rc;
+    if (!net->dense_attr_set) {
+        GMK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pvnet_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        net->dense_attr_set = true;
+    }
+    DenseParams prm;
+    prm.pflat = d_pflat; prm.vflat = d_vflat; prm.n = n;
+    prm.wp = net->d_wp; prm.wv = net->d_wv; prm.bp = net->d_dense; prm.bhid = net->d_dense + 256; prm.wo = net->d_dense + 320; prm.bo = net->b_out;
+    prm.value = d_value; prm.probs = d_probs;
+    hipLaunchKernelGGL(pvnet_dense_kernel, dim3((n + kDensePos - 1) / kDensePos), dim3(256), static_cast<size_t>(kDenseLdsFloats) * 4, static_cast<hipStream_t>(stream), prm);
+    GMK_HIP_CHECK(hipGetLastError());
     return GMK_OK;
 }

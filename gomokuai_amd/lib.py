@@ -42,7 +42,7 @@ EXPORTS = [
     "gmk_mcts_alg_bytes", "gmk_mcts_launch_info", "gmk_visits_to_pi", "gmk_mcts_advance", "gmk_mcts_step", "gmk_mcts_step_host", "gmk_mcts_add_root_noise", "gmk_mcts_set_option", "gmk_mcts_reserve", "gmk_selfplay_run", "gmk_samples_from_records",
     "gmk_evalstate_create", "gmk_evalstate_destroy", "gmk_evalstate_reset", "gmk_evalstate_update", "gmk_evalstate_update_host", "gmk_evalstate_read",
     "gmk_az_create", "gmk_az_destroy", "gmk_az_set_roots", "gmk_az_select", "gmk_az_expand", "gmk_az_select_host", "gmk_az_expand_host", "gmk_az_read_node_host", "gmk_az_read_children_host", "gmk_az_set_leaf_host", "gmk_az_rollout_host", "gmk_az_expand_stages_host", "gmk_az_write_stats_host", "gmk_az_step", "gmk_az_advance", "gmk_az_set_slots", "gmk_az_live_games", "gmk_az_set_game_ids", "gmk_az_add_root_noise", "gmk_az_set_option", "gmk_az_root_stats",
-    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_set_option", "gmk_trad_reserve", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_trad_selfplay_run", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward",
+    "gmk_trad_create", "gmk_trad_destroy", "gmk_trad_reset_evaluators", "gmk_trad_set_game_ids", "gmk_trad_set_positions", "gmk_trad_run", "gmk_trad_step", "gmk_trad_add_root_noise", "gmk_trad_set_option", "gmk_trad_reserve", "gmk_trad_root_stats", "gmk_trad_read_evaluators", "gmk_trad_run_poolrave", "gmk_trad_root_amaf", "gmk_trad_selfplay_run", "gmk_pvnet_create", "gmk_pvnet_destroy", "gmk_pvnet_forward", "gmk_pvnet_set_dense", "gmk_pvnet_evaluate",
 ]
 
 
@@ -139,6 +139,8 @@ def load():
     L.gmk_pvnet_create.argtypes = [vp] * 10 + [C.POINTER(vp)]
     L.gmk_pvnet_destroy.argtypes = [vp]
     L.gmk_pvnet_forward.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.gmk_pvnet_set_dense.argtypes = [vp] * 6 + [C.c_float]
+    L.gmk_pvnet_evaluate.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.gmk_samples_from_records.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     _lib = L
     return L

@@ -56,10 +56,10 @@ class PolicyValueNetwork(nn.Module):
 
 
 class FusedPolicyValueNetwork:
-    """The same function as PolicyValueNetwork.forward with the convolutions (99 % of the arithmetic) in ONE fused HIP kernel on
-    the f32 matrix cores (K9, gmk_pvnet_forward: activations never leave LDS) and the three small dense layers as batched
-    GEMMs in PyTorch-ROCm.  float32 throughout; sums run in a different order than MIOpen's, so outputs agree with the module's
-    to rounding (tests/test_pvnet_gpu.py: 2e-5), not bit for bit.  Takes the weights of `net` at construction."""
+    """The same function as PolicyValueNetwork.forward in two HIP kernels on the f32 matrix cores (gmk_pvnet_evaluate): the convolutions (99 % of
+    the arithmetic) as ONE fused kernel whose activations never leave LDS (K9), and the three dense layers with softmax / tanh as a second one.
+    float32 throughout; sums run in a different order than MIOpen's / rocBLAS's, so outputs agree with the module's to rounding
+    (tests/test_pvnet_gpu.py: 2e-5), not bit for bit.  Takes the weights of `net` at construction."""
 
     def __init__(self, net):
         import ctypes as C
@@ -72,6 +72,10 @@ class FusedPolicyValueNetwork:
                   host(net.value_conv.weight).reshape(2, 128), host(net.value_conv.bias)]
         arrays = [np.ascontiguousarray(a) for a in arrays]
         G._check(G.load().gmk_pvnet_create(*[a.ctypes.data for a in arrays], C.byref(self.h)))
+        dense = [host(net.policy_dense.weight), host(net.policy_dense.bias), host(net.value_hidden.weight), host(net.value_hidden.bias),
+                 host(net.value_out.weight).reshape(64)]
+        assert dense[0].shape == (225, 900) and dense[2].shape == (64, 450)
+        G._check(G.load().gmk_pvnet_set_dense(self.h, *[a.ctypes.data for a in dense], float(net.value_out.bias.detach().cpu().reshape(-1)[0])))
 
     def close(self):
         if getattr(self, "h", None) and getattr(self, "G", None) is not None and self.G.load is not None:
@@ -93,7 +97,18 @@ class FusedPolicyValueNetwork:
 
     @torch.no_grad()
     def __call__(self, states):
-        """states float32 [B, 6, 15, 15] -> (value [B], probs [B, 225])."""
+        """states float32 [B, 6, 15, 15] on the GPU -> (value [B], probs [B, 225]); both kernels go to torch's current stream."""
+        assert states.is_cuda and states.dtype == torch.float32 and states.is_contiguous() and tuple(states.shape[1:]) == (6, 15, 15)
+        n = states.shape[0]
+        value = torch.empty((n,), dtype=torch.float32, device=states.device)
+        probs = torch.empty((n, 225), dtype=torch.float32, device=states.device)
+        self.G._check(self.G.load().gmk_pvnet_evaluate(self.h, states.data_ptr(), n, value.data_ptr(), probs.data_ptr(),
+                                                       torch.cuda.current_stream(states.device).cuda_stream))
+        return value, probs
+
+    @torch.no_grad()
+    def dense_reference(self, states):
+        """The dense layers through PyTorch on the kernel's trunk outputs (what __call__ did before the second kernel existed): a check, not a path."""
         pflat, vflat = self.trunk(states)
         probs = F.softmax(self.net.policy_dense(pflat), dim=1)
         value = torch.tanh(self.net.value_out(F.relu(self.net.value_hidden(vflat)))).reshape(-1)

@@ -383,12 +383,21 @@ int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_p
  * Weights are host arrays in PyTorch's conv layout [cout][cin][3][3] ([cout][cin] for the 1x1 heads), packed once at creation.
  * gmk_pvnet_forward: d_states float32 [n][6][225] (Board.encoded_states(), game_ext.hpp:87-104) ->
  *   d_pflat float32 [n][900] = relu(policy conv) flattened (pixel, channel), d_vflat float32 [n][450] likewise for the value head:
- * the inputs of the network's dense layers (tf.layers.flatten of the NHWC tensors), which stay with the caller. */
+ * the inputs of the network's dense layers (tf.layers.flatten of the NHWC tensors).
+ * gmk_pvnet_set_dense: the three dense layers behind them (network/model_tf.py:53-54 policy_logits / policy_output, :64-66 value_hidden /
+ *   value_logits / value_output), host arrays in [out][in] order over the (pixel, channel) flattening: w_policy [225][900], b_policy [225],
+ *   w_hidden [64][450], b_hidden [64], w_out [64], b_out; packed once, may be called again with new weights.
+ * gmk_pvnet_evaluate: the whole PolicyValueNetwork.eval_state forward (network/model_tf.py:136-145) for a batch, two kernels on `stream`:
+ *   d_states float32 [n][6][225] -> d_value float32 [n] = tanh(...), d_probs float32 [n][225] = softmax(...).  The head activations between
+ *   the kernels live in the handle (grown on demand).  GMK_ERR_STATE before gmk_pvnet_set_dense. */
 typedef struct gmk_pvnet gmk_pvnet;
 int gmk_pvnet_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                      const float* w_policy, const float* b_policy, const float* w_value, const float* b_value, gmk_pvnet** out);
 int gmk_pvnet_destroy(gmk_pvnet* net);
 int gmk_pvnet_forward(gmk_pvnet* net, const float* d_states, int n, float* d_pflat, float* d_vflat, void* stream);
+int gmk_pvnet_set_dense(gmk_pvnet* net, const float* w_policy, const float* b_policy, const float* w_hidden, const float* b_hidden,
+                        const float* w_out, float b_out);
+int gmk_pvnet_evaluate(gmk_pvnet* net, const float* d_states, int n, float* d_value, float* d_probs, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
-"""K9: the fused convolution trunk of the policy-value network (gmk_pvnet_forward, f32 MFMA) against the plain PyTorch float32
-module of the same architecture (gomokuai_amd/network.py, network/model_tf.py:28-66).  Both compute in float32; the sums run in
+"""K9: the policy-value network in HIP -- the fused convolution trunk (gmk_pvnet_forward) and, behind it, the dense layers with softmax / tanh
+(gmk_pvnet_evaluate), both on the f32 matrix cores -- against the plain PyTorch float32 module of the same architecture (gomokuai_amd/network.py, network/model_tf.py:28-66).  Both compute in float32; the sums run in
 different orders, so the bar is a tolerance: 2e-5 absolute on activations of order 1 and on the final value / probabilities."""
 import numpy as np
 import pytest
@@ -117,6 +117,56 @@ def test_eval_state_for_agents():
     move = agent.move(b)
     assert b.check_move(move)
     fused.close()
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 100, 1029, 4096])
+def test_dense_layers_in_hip(n):
+    """gmk_pvnet_evaluate = trunk kernel + dense kernel: value / probabilities against the module and against PyTorch's dense layers on the
+    kernel's own trunk outputs (the tighter check: only the second kernel differs), at batch sizes around the kernel's 16-position workgroups;
+    every row of probabilities sums to one, the value lies in [-1, 1]."""
+    G.init()
+    net = PolicyValueNetwork(seed=11).cuda().eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "bias") and m.bias is not None:
+                m.bias.uniform_(-0.3, 0.3)
+        net.policy_dense.weight.mul_(60.0)                        # logits of a few units: a softmax that is far from uniform
+    fused = FusedPolicyValueNetwork(net)
+    torch.manual_seed(100 + n)
+    states = (torch.rand((n, 6, 15, 15), device="cuda") > 0.6).float()
+    with torch.no_grad():
+        rvalue, rprobs = net(states)
+    dvalue, dprobs = fused.dense_reference(states)
+    value, probs = fused(states)
+    assert value.shape == (n,) and probs.shape == (n, 225)
+    assert float((value - dvalue).abs().max()) < 2e-6 and float((probs - dprobs).abs().max()) < 5e-6
+    assert float((value - rvalue).abs().max()) < TOL and float((probs - rprobs).abs().max()) < TOL
+    assert float((probs.sum(1) - 1).abs().max()) < 1e-5 and float(value.abs().max()) <= 1.0
+    assert float(probs.max()) > 2.0 / 225, float(probs.max())       # not vacuous: the distribution has structure
+    # a second, smaller batch through the same handle (the scratch between the kernels is reused), then a larger one (it grows)
+    for m in (max(1, n // 3), 2 * n + 5):
+        s2 = (torch.rand((m, 6, 15, 15), device="cuda") > 0.5).float()
+        v2, p2 = fused(s2)
+        dv2, dp2 = fused.dense_reference(s2)
+        assert float((v2 - dv2).abs().max()) < 2e-6 and float((p2 - dp2).abs().max()) < 5e-6
+    fused.close()
+
+
+def test_evaluate_needs_the_dense_layers():
+    """gmk_pvnet_evaluate before gmk_pvnet_set_dense is an error, not a guess."""
+    import ctypes as C
+    G.init()
+    net = PolicyValueNetwork(seed=1).cuda().eval()
+    host = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy())
+    arrays = [host(net.conv[0].weight), host(net.conv[0].bias), host(net.conv[1].weight), host(net.conv[1].bias), host(net.conv[2].weight), host(net.conv[2].bias),
+              host(net.policy_conv.weight).reshape(4, 128), host(net.policy_conv.bias), host(net.value_conv.weight).reshape(2, 128), host(net.value_conv.bias)]
+    h = C.c_void_p()
+    G._check(G.load().gmk_pvnet_create(*[a.ctypes.data for a in arrays], C.byref(h)))
+    states = torch.zeros((2, 6, 15, 15), device="cuda")
+    value, probs = torch.empty(2, device="cuda"), torch.empty((2, 225), device="cuda")
+    rc = G.load().gmk_pvnet_evaluate(h, states.data_ptr(), 2, value.data_ptr(), probs.data_ptr(), None)
+    assert rc != 0 and b"gmk_pvnet_set_dense" in G.load().gmk_last_error()
+    G.load().gmk_pvnet_destroy(h)
 
 
 def test_errors():
