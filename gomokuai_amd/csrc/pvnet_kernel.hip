@@ -104,7 +104,7 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
         constexpr int tap = decltype(tap_c)::value;
         constexpr bool with_corner = CORNER && tap / 3 < 2 && tap % 3 < 2;
         constexpr int NT = NP + (decltype(with_shared)::value ? 1 : 0);    // MFMAs per k-pair
-        constexpr int lead = NT >= 4 ? 3 : 1;
+        constexpr int lead = NT >= 4 ? 3 : 1;                              // (2 .. 5 measure the same)
         constexpr int src = ((tap / 3) * 17 + (tap % 3)) * 4;
         constexpr int src_next = tap < 8 ? (((tap + 1) / 3) * 17 + ((tap + 1) % 3)) * 4 : kChunkBytes;
 #pragma unroll
@@ -378,22 +378,22 @@ void pvnet_trunk_kernel(PvParams prm) {
 // relu(dense 450 -> 64)), 0.46 MFLOP per position -- 1 % of the network, one small kernel.  One workgroup takes 16 positions: their 1 350 head
 // activations are staged in LDS, every layer is Out[position][output] = sum_k Act[position][k] W^T[k][output] on v_mfma_f32_16x16x4_f32 (A =
 // activations, one conflict-free ds_read_b32 per step: row stride 900 and 452 floats = 4 banks; B = weights, packed on the host in lane order
-// per (output tile, step of 4 k) and streamed from L2).  Wave w owns the policy's output tiles w, w + 4, w + 8, w + 12 (225 outputs = 15 tiles of
+// per (wave, step of 4 k, output tile) and streamed from L2).  Wave w owns the policy's output tiles w, w + 4, w + 8, w + 12 (225 outputs = 15 tiles of
 // 16; the 16th is zero weights) and tile w of the 64 hidden units; the hidden layer's 450 k ride along the first 117 steps of the policy's 225.
 // Steps come in bodies of nine with all addresses `register + immediate` (vector instructions between f32 MFMAs cost 20-30 clocks each, see
 // conv_tiles()), and a body fetches the NEXT body's weights before its own MFMAs start (two register sets).  Then bias, the logits and hidden
 // units through LDS, and per position one wavefront's softmax / dot product + tanh.
 constexpr int kDensePos = 16;                      // positions per workgroup
 constexpr int kDenseBody = 9;                      // steps (of 4 k) per body: 225 = 25 bodies, the hidden layer's 113 -> 117 = 13 bodies
-constexpr int kPolicySteps = 225, kHiddenSteps = 13 * kDenseBody;
+constexpr int kPolicySteps = 225;            // the hidden layer's 113 steps ride along bodies 0 .. 12
 constexpr int kVfStride = 452;
 constexpr int oDensePf = 0, oDenseVf = kDensePos * 900, kDenseLdsFloats = oDenseVf + kDensePos * kVfStride + 16;
 // after the MFMAs the logits [16][256] take the place of the policy activations, the hidden units [16][64] that of the value activations
 
 struct DenseParams {
     const float* pflat; const float* vflat; int n;
-    const float* wp;                               // [16 tiles][225 steps][64 lanes] + one body of padding
-    const float* wv;                               // [4 tiles][117 + 9 steps][64 lanes]
+    const float* w;                                // [4 waves][25 + 1 bodies][9 steps][4 policy tiles (wave + 4 q) | 1 hidden tile (wave)][64 lanes]:
+                                                   // what a wave fetches for a body is one contiguous 11.5 KB run
     const float* bp;                               // [256]: the policy's biases, 0 behind the 225th
     const float* bhid; const float* wo; float bo;  // [64], [64]
     float* value; float* probs;                    // [n], [n][225]
@@ -438,17 +438,18 @@ void pvnet_dense_kernel(DenseParams prm) {
     f32x4 acc[4] = {}, acch = {};
     const char* a_pf = reinterpret_cast<const char*>(lds + oDensePf + (lane & 15) * 900 + (lane >> 4));        // + 16 bytes per step
     const char* a_vf = reinterpret_cast<const char*>(lds + oDenseVf + (lane & 15) * kVfStride + (lane >> 4));
-    const float* wp[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wp[q] = prm.wp + static_cast<size_t>(wave + 4 * q) * kPolicySteps * 64 + lane;
-    const float* wv = prm.wv + static_cast<size_t>(wave) * (kHiddenSteps + kDenseBody) * 64 + lane;
+    // Weight fetches are buffer loads: descriptor of this wave's run + (the lane's byte offset, one register) + a scalar offset that moves once per
+    // body + an immediate -- no vector arithmetic inside the MFMA stream (flat loads made the compiler carry 64-bit pointers in vector registers).
+    constexpr int kBodyBytes = kDenseBody * 5 * 64 * 4, kWaveBytes = (25 + 1) * kBodyBytes;
+    const auto w_mine = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prm.w) + static_cast<size_t>(__builtin_amdgcn_readfirstlane(wave)) * (kWaveBytes / 4), 0, kWaveBytes, 0x00020000);
+    const int lane_bytes = lane * 4;
     float bw[2][kDenseBody][4], bh[2][kDenseBody];
     auto fetch = [&](float (&w4)[kDenseBody][4], float (&w1)[kDenseBody], int body, auto with_hidden) {
 #pragma unroll
         for (int s = 0; s < kDenseBody; ++s) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w4[s][q] = wp[q][(body * kDenseBody + s) * 64];
-            if (decltype(with_hidden)::value) w1[s] = wv[(body * kDenseBody + s) * 64];
+            for (int q = 0; q < 4; ++q) w4[s][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_mine, lane_bytes + (s * 5 + q) * 256, body * kBodyBytes, 0));
+            if (decltype(with_hidden)::value) w1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_mine, lane_bytes + (s * 5 + 4) * 256, body * kBodyBytes, 0));
         }
     };
     auto body_mfmas = [&](const float (&w4)[kDenseBody][4], const float (&w1)[kDenseBody], int body, auto with_hidden) {
@@ -464,17 +465,16 @@ void pvnet_dense_kernel(DenseParams prm) {
     };
     constexpr std::integral_constant<bool, true> yes{};
     constexpr std::integral_constant<bool, false> no{};
+    // The 25 bodies are unrolled (straight-line code, ~20 KB): as a loop the two register sets are loop-carried values that the compiler
+    // copies at the loop header behind an s_waitcnt vmcnt(0) -- which exposes the fetch it was meant to hide.  The hidden layer's weights are
+    // fetched for bodies 0 .. 12 only; body 24 fetches the padding.
     fetch(bw[0], bh[0], 0, yes);
-#pragma unroll 1
-    for (int body = 0; body < 12; body += 2) {                                // bodies 0 .. 11
-        fetch(bw[1], bh[1], body + 1, yes); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[0], bh[0], body, yes); __builtin_amdgcn_sched_barrier(0);
-        fetch(bw[0], bh[0], body + 2, yes); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[1], bh[1], body + 1, yes); __builtin_amdgcn_sched_barrier(0);
-    }
-    fetch(bw[1], bh[1], 13, no); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[0], bh[0], 12, yes); __builtin_amdgcn_sched_barrier(0);      // body 12: the hidden layer's last
-#pragma unroll 1
-    for (int body = 13; body < 25; body += 2) {                               // bodies 13 .. 24, policy only (the last fetch reads the padding)
-        fetch(bw[0], bh[0], body + 1, no); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[1], bh[1], body, no); __builtin_amdgcn_sched_barrier(0);
-        fetch(bw[1], bh[1], body + 2, no); __builtin_amdgcn_sched_barrier(0); body_mfmas(bw[0], bh[0], body + 1, no); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int body = 0; body < 25; ++body) {
+        if (body < 12) fetch(bw[(body + 1) & 1], bh[(body + 1) & 1], body + 1, yes); else fetch(bw[(body + 1) & 1], bh[(body + 1) & 1], body + 1, no);
+        __builtin_amdgcn_sched_barrier(0);
+        if (body < 13) body_mfmas(bw[body & 1], bh[body & 1], body, yes); else body_mfmas(bw[body & 1], bh[body & 1], body, no);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                                          // everybody is done with the activations: their place is reused
     // ---- C/D: column (output) = lane & 15, row (position) = 4 (lane >> 4) + register ----
@@ -556,7 +556,7 @@ struct gmk_pvnet {
     bool attr_set = false;
     // the dense layers (gmk_pvnet_set_dense): packed weights, biases (policy [256] | hidden [64] | output weights [64]), the output bias, and the
     // head activations between the two kernels of gmk_pvnet_evaluate ([capacity][900 + 450], grown on demand)
-    float *d_wp = nullptr, *d_wv = nullptr, *d_dense = nullptr, *d_flat = nullptr;
+    float *d_wp = nullptr, *d_dense = nullptr, *d_flat = nullptr;
     float b_out = 0.0f;
     bool has_dense = false, dense_attr_set = false;
     int flat_capacity = 0;
@@ -565,7 +565,7 @@ struct gmk_pvnet {
 extern "C" int gmk_pvnet_destroy(gmk_pvnet* net) {
     if (!net) return GMK_OK;
     (void)hipFree(net->d_w1); (void)hipFree(net->d_w2); (void)hipFree(net->d_w3); (void)hipFree(net->d_wh); (void)hipFree(net->d_b);
-    (void)hipFree(net->d_wp); (void)hipFree(net->d_wv); (void)hipFree(net->d_dense); (void)gmk::device_free(net->d_flat);
+    (void)hipFree(net->d_wp); (void)hipFree(net->d_dense); (void)gmk::device_free(net->d_flat);
     delete net;
     return GMK_OK;
 }
@@ -654,29 +654,25 @@ extern "C" int gmk_pvnet_set_dense(gmk_pvnet* net, const float* w_policy, const 
     gmk::DeviceState& st = gmk::device_state();
     if (!st.ready) { gmk::set_error("gmk_init has not succeeded (no CPU fallback)"); return GMK_ERR_STATE; }
     if (!net || !w_policy || !b_policy || !w_hidden || !b_hidden || !w_out) { gmk::set_error("gmk_pvnet_set_dense: bad arguments"); return GMK_ERR_ARG; }
-    // B operands of v_mfma_f32_16x16x4_f32 in lane order: lane l carries W[output = 16 tile + (l & 15)][k = 4 step + (l >> 4)]
-    std::vector<float> wp((static_cast<size_t>(16) * kPolicySteps + kDenseBody) * 64, 0.0f), wv(static_cast<size_t>(4) * (kHiddenSteps + kDenseBody) * 64, 0.0f),
-        dense(256 + 64 + 64, 0.0f);
-    for (int tile = 0; tile < 16; ++tile)
+    // B operands of v_mfma_f32_16x16x4_f32 in lane order: lane l carries W[output = 16 tile + (l & 15)][k = 4 step + (l >> 4)]; per wave and body
+    // the nine steps' four policy tiles and hidden tile side by side (zeros: the 16th policy tile, k >= 450 of the hidden layer, the pad body)
+    std::vector<float> wp(static_cast<size_t>(4) * 26 * kDenseBody * 5 * 64, 0.0f), dense(256 + 64 + 64, 0.0f);
+    for (int wave = 0; wave < 4; ++wave)
         for (int step = 0; step < kPolicySteps; ++step)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int o = 16 * tile + (lane & 15), k = 4 * step + (lane >> 4);
-                if (o < kPix) wp[(static_cast<size_t>(tile) * kPolicySteps + step) * 64 + lane] = w_policy[static_cast<size_t>(o) * 900 + k];
-            }
-    for (int tile = 0; tile < 4; ++tile)
-        for (int step = 0; step < kHiddenSteps; ++step)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int o = 16 * tile + (lane & 15), k = 4 * step + (lane >> 4);
-                if (k < 450) wv[(static_cast<size_t>(tile) * (kHiddenSteps + kDenseBody) + step) * 64 + lane] = w_hidden[static_cast<size_t>(o) * 450 + k];
-            }
+            for (int q = 0; q < 5; ++q)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int k = 4 * step + (lane >> 4);
+                    float v = 0.0f;
+                    if (q < 4) { const int o = 16 * (wave + 4 * q) + (lane & 15); if (o < kPix) v = w_policy[static_cast<size_t>(o) * 900 + k]; }
+                    else if (k < 450) v = w_hidden[static_cast<size_t>(16 * wave + (lane & 15)) * 450 + k];
+                    wp[((static_cast<size_t>(wave) * 26 * kDenseBody + step) * 5 + q) * 64 + lane] = v;
+                }
     std::memcpy(&dense[0], b_policy, kPix * 4); std::memcpy(&dense[256], b_hidden, 64 * 4); std::memcpy(&dense[320], w_out, 64 * 4);
     if (!net->d_wp) {
-        const bool ok = hipMalloc(&net->d_wp, wp.size() * 4) == hipSuccess && hipMalloc(&net->d_wv, wv.size() * 4) == hipSuccess &&
-                        hipMalloc(&net->d_dense, dense.size() * 4) == hipSuccess;
+        const bool ok = hipMalloc(&net->d_wp, wp.size() * 4) == hipSuccess && hipMalloc(&net->d_dense, dense.size() * 4) == hipSuccess;
         if (!ok) { gmk::set_error("gmk_pvnet_set_dense: device allocation failed"); return GMK_ERR_HIP; }
     }
     GMK_HIP_CHECK(hipMemcpy(net->d_wp, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
-    GMK_HIP_CHECK(hipMemcpy(net->d_wv, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
     GMK_HIP_CHECK(hipMemcpy(net->d_dense, dense.data(), dense.size() * 4, hipMemcpyHostToDevice));
     net->b_out = b_out;
     net->has_dense = true;
@@ -705,7 +701,7 @@ extern "C" int gmk_pvnet_evaluate(gmk_pvnet* net, const float* d_states, int n, 
     }
     DenseParams prm;
     prm.pflat = d_pflat; prm.vflat = d_vflat; prm.n = n;
-    prm.wp = net->d_wp; prm.wv = net->d_wv; prm.bp = net->d_dense; prm.bhid = net->d_dense + 256; prm.wo = net->d_dense + 320; prm.bo = net->b_out;
+    prm.w = net->d_wp; prm.bp = net->d_dense; prm.bhid = net->d_dense + 256; prm.wo = net->d_dense + 320; prm.bo = net->b_out;
     prm.value = d_value; prm.probs = d_probs;
     hipLaunchKernelGGL(pvnet_dense_kernel, dim3((n + kDensePos - 1) / kDensePos), dim3(256), static_cast<size_t>(kDenseLdsFloats) * 4, static_cast<hipStream_t>(stream), prm);
     GMK_HIP_CHECK(hipGetLastError());

@@ -143,6 +143,41 @@ __global__ __launch_bounds__(256) void probe3(const float* w, float* out, unsign
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
+// 12: two rounds' worth per scheduling block: 14 reads in one burst behind the third MFMA, 14 MFMAs (7 accumulators, two k each): is variant 7's
+// cost per round or per burst?
+__global__ __launch_bounds__(256) void probe4(const float* w, float* out, unsigned long long* clk) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    __syncthreads();
+    f32x16 acc[7] = {};
+    float b[2][14];
+    uint32_t base[7];
+    for (int t = 0; t < 7; ++t) base[t] = ((lane >> 5) * 289 + 18 + t * 32 + (lane & 31)) * 4;
+    const char* in = reinterpret_cast<const char*>(lds);
+    for (int t = 0; t < 14; ++t) b[0][t] = *reinterpret_cast<const float*>(in + (t / 7) * 2312 + base[t % 7]);
+    const float a = w[lane];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int r = 0; r < REPS; r += 4) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int t = 0; t < 14; ++t) b[h ^ 1][t] = *reinterpret_cast<const float*>(in + ((r + 2 * h + t / 7) & 15) * 2 * 289 * 4 + base[t % 7]);
+#pragma unroll
+            for (int t = 0; t < 14; ++t) acc[t % 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][t], acc[t % 7], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.0f;
+    for (int t = 0; t < 7; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
+}
 template <class K>
 void run(K kernel, int variant, double per_rep, const float* w, float* out, unsigned long long* clk) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -164,6 +199,7 @@ int main() {
     run(probe<8>, 8, 7, w, out, clk); run(probe<9>, 9, 7, w, out, clk); run(probe<10>, 10, 7, w, out, clk);
     run(probe<6>, 6, 7, w, out, clk); run(probe<7>, 7, 7, w, out, clk);
     run(probe3, 11, 7.0 * (REPS / 3 * 3) / REPS, w, out, clk);
+    run(probe4, 12, 7, w, out, clk);
     run(probe2<4>, 4, 8, w, out, clk); run(probe2<5>, 5, 8, w, out, clk);
     return 0;
 }
