@@ -74,7 +74,8 @@ __host__ __device__ inline void step_chunk_tap(int step, int& chunk, int& tap) {
 //   * Operands are fetched AHEAD of the MFMAs that use them, and the scheduling barriers keep the fetches where they are written (left alone, the
 //     compiler sinks every load to just before its use, and each MFMA then waits for LDS or L2 behind it): a step's CP weights two steps ahead, one
 //     global load per k-pair block, into one of three rotating register sets (three steps per rotation: no register moves); the NB activation
-//     reads of a k-pair one k-pair ahead, in one burst behind the third MFMA of the current k-pair.  The fetches past the layer's last k-pair read
+//     reads of a k-pair AHEAD k-pairs ahead (one everywhere: two or three for the layers whose k-pairs are two to four MFMAs measured the
+//     same), in one burst behind the third MFMA of the current k-pair.  The fetches past the layer's last k-pair read
 //     two steps of padding behind the weights and the LDS behind the activations (both there, both unused).
 //   * CORNER: 225 pixels are seven tiles and ONE pixel, the corner (14, 14).  A 32 x 32 MFMA for it would compute 31 columns nobody reads (64
 //     clocks) and a v_fma costs 20-30 here, so it rides on v_mfma_f32_4x4x1_16B_f32 (8 clocks): A = the A operand the lane holds anyway
@@ -84,7 +85,7 @@ __host__ __device__ inline void step_chunk_tap(int step, int& chunk, int& tap) {
 //     kx = 2 read the zero border: those five of nine taps leave it out.
 //   * SHARED: one more pixel tile, acc[NP] / base[NP], takes part in chunk `shared_chunk` only: two waves share that tile's k range and one of them
 //     adds the other's partial sums afterwards -- how layer 2's fourteen tile jobs become 3.5 per wave.
-template <int CIN, int NP, bool CORNER = false, bool SHARED = false>
+template <int CIN, int NP, bool CORNER = false, bool SHARED = false, int AHEAD = 1>
 __device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0)],
                                            f32x16 (&acc)[NP + (SHARED ? 1 : 0)], f32x4& corner, const float (&first)[CIN >= 16 ? 8 : CIN / 2], int shared_chunk = -1) {
     constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
@@ -95,24 +96,27 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
 #pragma unroll
     for (int t = 0; t < NB; ++t) addr[t] = base[t];
     const float* wl_ptr = w + lane;
-    float wA[CP], wB[CP], wC[CP], b[2][NB];
+    static_assert(CHUNKS == 1 || (9 * CP) % (AHEAD + 1) == 0, "the operand sets rotate through a whole chunk");
+    static_assert(AHEAD * NB <= 15, "LDS reads in flight (lgkmcnt counts to 15)");
+    float wA[CP], wB[CP], wC[CP], b[AHEAD + 1][NB];
 #pragma unroll
     for (int i = 0; i < CP; ++i) { wA[i] = first[i]; wB[i] = wl_ptr[(CP + i) * 64]; }      // step 0's are the same for every position: the kernel keeps them, nothing to wait for
+    // byte offset of k-pair kp of a chunk from the chunk's base (past the chunk's end: into the next one)
+    auto kp_offset = [](int kp) { const int c = kp / (9 * CP), k = kp - c * 9 * CP, tap = k / CP; return c * kChunkBytes + ((tap / 3) * 17 + (tap % 3)) * 4 + 2 * (k - tap * CP) * kPad * 4; };
 #pragma unroll
-    for (int t = 0; t < NB; ++t) b[0][t] = *reinterpret_cast<const float*>(in + addr[t]);
+    for (int d = 0; d < AHEAD; ++d)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) b[d][t] = *reinterpret_cast<const float*>(in + addr[t] + kp_offset(d));
     auto do_step = [&](auto tap_c, const float (&wc)[CP], float (&wl)[CP], auto with_shared) {
         constexpr int tap = decltype(tap_c)::value;
         constexpr bool with_corner = CORNER && tap / 3 < 2 && tap % 3 < 2;
         constexpr int NT = NP + (decltype(with_shared)::value ? 1 : 0);    // MFMAs per k-pair
         constexpr int lead = NT >= 4 ? 3 : 1;                              // (2 .. 5 measure the same)
-        constexpr int src = ((tap / 3) * 17 + (tap % 3)) * 4;
-        constexpr int src_next = tap < 8 ? (((tap + 1) / 3) * 17 + ((tap + 1) % 3)) * 4 : kChunkBytes;
 #pragma unroll
         for (int cp = 0; cp < CP; ++cp) {
-            const int cur = (tap * CP + cp) & 1;
+            const int kp = tap * CP + cp, cur = kp % (AHEAD + 1), ahead = (kp + AHEAD) % (AHEAD + 1);
 #pragma unroll
-            for (int t = 0; t < NB; ++t)
-                b[cur ^ 1][t] = *reinterpret_cast<const float*>(in + addr[t] + (cp + 1 < CP ? src + 2 * (cp + 1) * kPad * 4 : src_next));
+            for (int t = 0; t < NB; ++t) b[ahead][t] = *reinterpret_cast<const float*>(in + addr[t] + kp_offset(kp + AHEAD));
             wl[cp] = wl_ptr[((tap + 2) * CP + cp) * 64];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
@@ -129,10 +133,6 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
         do_step(std::integral_constant<int, 0>{}, wA, wC, with_shared); do_step(std::integral_constant<int, 1>{}, wB, wA, with_shared); do_step(std::integral_constant<int, 2>{}, wC, wB, with_shared);
         do_step(std::integral_constant<int, 3>{}, wA, wC, with_shared); do_step(std::integral_constant<int, 4>{}, wB, wA, with_shared); do_step(std::integral_constant<int, 5>{}, wC, wB, with_shared);
         do_step(std::integral_constant<int, 6>{}, wA, wC, with_shared); do_step(std::integral_constant<int, 7>{}, wB, wA, with_shared); do_step(std::integral_constant<int, 8>{}, wC, wB, with_shared);
-        if ((9 * CP) & 1) {                                      // an odd number of k-pairs in a chunk leaves the current operands in b[1]
-#pragma unroll
-            for (int t = 0; t < NB; ++t) b[0][t] = b[1][t];
-        }
     };
 #pragma unroll 1
     for (int chunk = 0; chunk < CHUNKS; ++chunk) {
