@@ -87,7 +87,7 @@ __host__ __device__ inline void step_chunk_tap(int step, int& chunk, int& tap) {
 //     adds the other's partial sums afterwards -- how layer 2's fourteen tile jobs become 3.5 per wave.
 template <int CIN, int NP, bool CORNER = false, bool SHARED = false, int AHEAD = 1>
 __device__ __forceinline__ void conv_tiles(const char* in, const float* __restrict__ w, int lane, const uint32_t (&base)[NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0)],
-                                           f32x16 (&acc)[NP + (SHARED ? 1 : 0)], f32x4& corner, const float (&first)[CIN >= 16 ? 8 : CIN / 2], int shared_chunk = -1) {
+                                           f32x16 (&acc)[NP + (SHARED ? 1 : 0)], f32x4& corner, const float (&first)[CIN >= 16 ? 8 : 9 * (CIN / 2)], int shared_chunk = -1) {
     constexpr int CP = CIN >= 16 ? 8 : CIN / 2;
     constexpr int CHUNKS = CIN / 2 / CP;
     constexpr int NB = NP + (SHARED ? 1 : 0) + (CORNER ? 1 : 0); // B operands fetched per k-pair
@@ -95,12 +95,19 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
     uint32_t addr[NB];
 #pragma unroll
     for (int t = 0; t < NB; ++t) addr[t] = base[t];
-    const float* wl_ptr = w + lane;
+    // weights: [step][CP / 4 groups][64 lanes][4 k-pairs]: a lane fetches the A operands of four consecutive k-pairs with one 16-byte load (a
+    // global load costs the MFMA stream ~20 clocks whatever its width, tools/mfma_issue_probe.hip)
+    const float4* wl_ptr = reinterpret_cast<const float4*>(w) + lane;
+    constexpr bool kAllHeld = CIN < 16;                         // layer 1: the caller holds all 27 A operands in registers, nothing is fetched
     static_assert(CHUNKS == 1 || (9 * CP) % (AHEAD + 1) == 0, "the operand sets rotate through a whole chunk");
     static_assert(AHEAD * NB <= 15, "LDS reads in flight (lgkmcnt counts to 15)");
     float wA[CP], wB[CP], wC[CP], b[AHEAD + 1][NB];
 #pragma unroll
-    for (int i = 0; i < CP; ++i) { wA[i] = first[i]; wB[i] = wl_ptr[(CP + i) * 64]; }      // step 0's are the same for every position: the kernel keeps them, nothing to wait for
+    for (int i = 0; i < CP; ++i) wA[i] = first[i];              // step 0's are the same for every position: the kernel keeps them, nothing to wait for
+    if constexpr (!kAllHeld) {
+#pragma unroll
+        for (int g = 0; g < CP / 4; ++g) { const float4 v = wl_ptr[(CP / 4 + g) * 64]; wB[4 * g] = v.x; wB[4 * g + 1] = v.y; wB[4 * g + 2] = v.z; wB[4 * g + 3] = v.w; }
+    }
     // byte offset of k-pair kp of a chunk from the chunk's base (past the chunk's end: into the next one)
     auto kp_offset = [](int kp) { const int c = kp / (9 * CP), k = kp - c * 9 * CP, tap = k / CP; return c * kChunkBytes + ((tap / 3) * 17 + (tap % 3)) * 4 + 2 * (k - tap * CP) * kPad * 4; };
 #pragma unroll
@@ -117,14 +124,18 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
             const int kp = tap * CP + cp, cur = kp % (AHEAD + 1), ahead = (kp + AHEAD) % (AHEAD + 1);
 #pragma unroll
             for (int t = 0; t < NB; ++t) b[ahead][t] = *reinterpret_cast<const float*>(in + addr[t] + kp_offset(kp + AHEAD));
-            wl[cp] = wl_ptr[((tap + 2) * CP + cp) * 64];
+            constexpr bool fetch = !kAllHeld;
+            if constexpr (fetch) {
+                if (cp % 4 == 0) { const float4 v = wl_ptr[((tap + 2) * (CP / 4) + cp / 4) * 64]; wl[cp] = v.x; wl[cp + 1] = v.y; wl[cp + 2] = v.z; wl[cp + 3] = v.w; }
+            }
+            const float a = kAllHeld ? first[kp] : wc[cp];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[cp], b[cur][t], acc[t], 0, 0, 0);
-            if (with_corner) corner = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[cp], b[cur][NB - 1], corner, 0, 0, 0);
-            // issue order inside this block: `lead` MFMAs, the LDS reads and the weight load in their shadow, the other MFMAs
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[cur][t], acc[t], 0, 0, 0);
+            if (with_corner) corner = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b[cur][NB - 1], corner, 0, 0, 0);
+            // issue order inside this block: `lead` MFMAs, the LDS reads and (every fourth k-pair) the weight load in their shadow, the other MFMAs
             __builtin_amdgcn_sched_group_barrier(0x008, lead, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (fetch && cp % 4 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, NT - lead + (with_corner ? 1 : 0), 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -140,7 +151,7 @@ __device__ __forceinline__ void conv_tiles(const char* in, const float* __restri
         else chunk_steps(std::integral_constant<bool, false>{});
 #pragma unroll
         for (int t = 0; t < NB; ++t) addr[t] += kChunkBytes;
-        wl_ptr += 9 * CP * 64;
+        wl_ptr += 9 * (CP / 4) * 64;
     }
 }
 
@@ -217,11 +228,20 @@ void pvnet_trunk_kernel(PvParams prm) {
     const int ct2 = wave & 1;                                                 // layer 2: this wave's channel tile
     const float* w2_mine = prm.w2 + static_cast<size_t>(ct2) * 144 * 64;
     const float* w3_mine = prm.w3 + static_cast<size_t>(wave) * 288 * 64;
-    float w1_first[3], w2_first[8], w3_first[8];
+    float w1_all[27], w2_first[8], w3_first[8];                               // layer 1: all 27 k-pairs (packed as seven groups of four)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { w2_first[i] = w2_mine[i * 64 + lane]; w3_first[i] = w3_mine[i * 64 + lane]; }
+    for (int g = 0; g < 2; ++g) {
+        const float4 v2 = reinterpret_cast<const float4*>(w2_mine)[g * 64 + lane], v3 = reinterpret_cast<const float4*>(w3_mine)[g * 64 + lane];
+        w2_first[4 * g] = v2.x; w2_first[4 * g + 1] = v2.y; w2_first[4 * g + 2] = v2.z; w2_first[4 * g + 3] = v2.w;
+        w3_first[4 * g] = v3.x; w3_first[4 * g + 1] = v3.y; w3_first[4 * g + 2] = v3.z; w3_first[4 * g + 3] = v3.w;
+    }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) w1_first[i] = prm.w1[i * 64 + lane];
+    for (int g = 0; g < 7; ++g) {
+        const float4 v = reinterpret_cast<const float4*>(prm.w1)[g * 64 + lane];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (4 * g + i < 27) w1_all[4 * g + i] = e[i];
+    }
     if (prm.prof) t_mark = __builtin_amdgcn_s_memtime();
     for (int img = blockIdx.x; img < prm.n; img += gridDim.x) {
         fetch_input(img + gridDim.x);
@@ -232,7 +252,7 @@ void pvnet_trunk_kernel(PvParams prm) {
             f32x16 acc[2];                                                    // the accumulators start from the bias of the channel they hold
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = lds[oBias + cd_row(r, lane)];
-            conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc, no_corner, w1_first);
+            conv_tiles<6, 2>(reinterpret_cast<const char*>(lds + oIn), prm.w1, lane, base, acc, no_corner, w1_all);
             store_tile(lds + oAct1, acc[0], 0, 2 * wave, lane);
             store_tile(lds + oAct1, acc[1], 0, 2 * wave + 1, lane);
         }
@@ -531,10 +551,11 @@ void pvnet_dense_kernel(DenseParams prm) {
     }
 }
 
-// A operands of one layer in lane order: [cout tile][k-pair][64 lanes]; k-pair order as conv_tiles() walks it
+// A operands of one layer in lane order, four consecutive k-pairs of a lane side by side: [cout tile][k-pair / 4][64 lanes][4]; k-pair order as
+// conv_tiles() walks it (layer 1's 27 k-pairs: seven groups, the last one padded)
 void pack_layer(const float* w /* [cout][cin][3][3] */, int cin, int cout, std::vector<float>& out) {
-    const int CP = cin >= 16 ? 8 : cin / 2, chunks = cin / 2 / CP, steps = chunks * 9, kps = steps * CP;
-    out.assign(static_cast<size_t>(cout / 32) * kps * 64 + 2 * CP * 64, 0.0f);      // + the two steps conv_tiles() fetches past the last tile's end
+    const int CP = cin >= 16 ? 8 : cin / 2, chunks = cin / 2 / CP, steps = chunks * 9, kps = steps * CP, groups = (kps + 3) / 4;
+    out.assign((static_cast<size_t>(cout / 32) * groups + 2 * CP / 4 + 1) * 256, 0.0f);      // + the two steps conv_tiles() fetches past the last tile's end
     for (int tile = 0; tile < cout / 32; ++tile)
         for (int step = 0; step < steps; ++step) {
             int chunk, tap;
@@ -543,7 +564,7 @@ void pack_layer(const float* w /* [cout][cin][3][3] */, int cin, int cout, std::
                 const int kp = step * CP + cp;
                 for (int lane = 0; lane < 64; ++lane) {
                     const int co = tile * 32 + (lane & 31), ci = chunk * 2 * CP + 2 * cp + (lane >> 5);
-                    out[(static_cast<size_t>(tile) * kps + kp) * 64 + lane] = w[(static_cast<size_t>(co) * cin + ci) * 9 + tap];
+                    out[((static_cast<size_t>(tile) * groups + kp / 4) * 64 + lane) * 4 + (kp & 3)] = w[(static_cast<size_t>(co) * cin + ci) * 9 + tap];
                 }
             }
         }

@@ -178,6 +178,49 @@ __global__ __launch_bounds__(256) void probe4(const float* w, float* out, unsign
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
+// 17: as 13 with a global_load_dwordx4
+// 13 / 14: as 7 (NT MFMAs + NT reads per round, NT = 7 / 3 / 3) + one global_load_dword per round with NO address arithmetic (scalar base + lane
+// offset + immediate), nobody waits for it: what the weight fetch itself costs; 16: NT = 3 without the load
+template <int NT, int LOAD>
+__global__ __launch_bounds__(256) void probe5(const float* w, float* out, unsigned long long* clk) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    __syncthreads();
+    f32x16 acc[NT] = {};
+    float b[2][NT];
+    uint32_t base[NT];
+    for (int t = 0; t < NT; ++t) base[t] = ((lane >> 5) * 289 + 18 + t * 32 + (lane & 31)) * 4;
+    const char* in = reinterpret_cast<const char*>(lds);
+    for (int t = 0; t < NT; ++t) b[0][t] = *reinterpret_cast<const float*>(in + base[t]);
+    const float a = w[lane];
+    const uint32_t lane_off = lane * 4, lane_off4 = lane * 16;
+    float sink = 0.0f;
+    float4 sink4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int r = 0; r < REPS; r += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b[h ^ 1][t] = *reinterpret_cast<const float*>(in + ((r + h) & 31) * 2 * 289 * 4 + base[t]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT >= 4 ? 3 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT - (NT >= 4 ? 3 : 1), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (LOAD == 1) asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(sink) : "v"(lane_off), "s"(w), "n"(256 * 3));
+            if (LOAD == 4) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(sink4) : "v"(lane_off4), "s"(w), "n"(1024));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = sink + sink4.x + sink4.w;
+    for (int t = 0; t < NT; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
+}
 template <class K>
 void run(K kernel, int variant, double per_rep, const float* w, float* out, unsigned long long* clk) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -200,6 +243,7 @@ int main() {
     run(probe<6>, 6, 7, w, out, clk); run(probe<7>, 7, 7, w, out, clk);
     run(probe3, 11, 7.0 * (REPS / 3 * 3) / REPS, w, out, clk);
     run(probe4, 12, 7, w, out, clk);
+    run(probe5<7, 1>, 13, 7, w, out, clk); run(probe5<3, 1>, 14, 3, w, out, clk); run(probe5<3, 0>, 16, 3, w, out, clk); run(probe5<7, 4>, 17, 7, w, out, clk);
     run(probe2<4>, 4, 8, w, out, clk); run(probe2<5>, 5, 8, w, out, clk);
     return 0;
 }
