@@ -221,6 +221,46 @@ __global__ __launch_bounds__(256) void probe5(const float* w, float* out, unsign
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
+// 18: eight MFMAs per round fed by FOUR ds_read2st64_b32 (two dwords 2 560 bytes apart per instruction) in one burst behind the third MFMA:
+// does an LDS read cost per instruction or per dword?
+__global__ __launch_bounds__(256) void probe6(const float* w, float* out, unsigned long long* clk) {
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    __syncthreads();
+    f32x16 acc[8] = {};
+    float2 b[2][4];
+    uint32_t base[4];
+    for (int t = 0; t < 4; ++t) base[t] = ((lane >> 5) * 320 + 18 + t * 32 + (lane & 31)) * 4;
+    auto read2 = [](uint32_t addr) { float2 v; asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:10" : "=v"(v) : "v"(addr)); return v; };
+    for (int t = 0; t < 4; ++t) b[0][t] = read2(base[t]);
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    const float a = w[lane];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int r = 0; r < REPS; r += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][0].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][0].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][1].x, acc[2], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[h ^ 1][t] = read2(base[t] + ((r + h) & 7) * 5120);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][1].y, acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][2].x, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][2].y, acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][3].x, acc[6], 0, 0, 0);
+            acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[h][3].y, acc[7], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.0f;
+    for (int t = 0; t < 8; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
+}
 template <class K>
 void run(K kernel, int variant, double per_rep, const float* w, float* out, unsigned long long* clk) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -244,6 +284,7 @@ int main() {
     run(probe3, 11, 7.0 * (REPS / 3 * 3) / REPS, w, out, clk);
     run(probe4, 12, 7, w, out, clk);
     run(probe5<7, 1>, 13, 7, w, out, clk); run(probe5<3, 1>, 14, 3, w, out, clk); run(probe5<3, 0>, 16, 3, w, out, clk); run(probe5<7, 4>, 17, 7, w, out, clk);
+    run(probe6, 18, 8, w, out, clk);
     run(probe2<4>, 4, 8, w, out, clk); run(probe2<5>, 5, 8, w, out, clk);
     return 0;
 }
