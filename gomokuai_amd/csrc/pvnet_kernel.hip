@@ -399,21 +399,23 @@ void pvnet_trunk_kernel(PvParams prm) {
 // activations are staged in LDS, every layer is Out[position][output] = sum_k Act[position][k] W^T[k][output] on v_mfma_f32_16x16x4_f32 (A =
 // activations, one conflict-free ds_read_b32 per step: row stride 900 and 452 floats = 4 banks; B = weights, packed on the host in lane order
 // per (wave, step of 4 k, output tile) and streamed from L2).  Wave w owns the policy's output tiles w, w + 4, w + 8, w + 12 (225 outputs = 15 tiles of
-// 16; the 16th is zero weights) and tile w of the 64 hidden units; the hidden layer's 450 k ride along the first 117 steps of the policy's 225.
-// Steps come in bodies of nine with all addresses `register + immediate` (vector instructions between f32 MFMAs cost 20-30 clocks each, see
-// conv_tiles()), and a body fetches the NEXT body's weights before its own MFMAs start (two register sets).  Then bias, the logits and hidden
+// 16; the 16th is zero weights) and tile w of the 64 hidden units; the hidden layer's 450 k ride along the first 120 steps of the policy's 228.
+// Steps come in bodies of twelve with all addresses `register + immediate` (vector instructions between f32 MFMAs cost 20-30 clocks each, a
+// load ~20 whatever its width: see conv_tiles()), a lane's B operands of four steps are one 16-byte buffer load, and a body fetches the NEXT
+// body's weights before its own MFMAs start (two register sets).  Then bias, the logits and hidden
 // units through LDS, and per position one wavefront's softmax / dot product + tanh.
 constexpr int kDensePos = 16;                      // positions per workgroup
-constexpr int kDenseBody = 9;                      // steps (of 4 k) per body: 225 = 25 bodies, the hidden layer's 113 -> 117 = 13 bodies
-constexpr int kPolicySteps = 225;            // the hidden layer's 113 steps ride along bodies 0 .. 12
+constexpr int kDenseBody = 12;                     // steps (of 4 k) per body = three groups of four (one 16-byte weight load per lane and group)
+constexpr int kPolicySteps = 225;                  // -> 228 = 19 bodies; the hidden layer's 113 steps -> 120 ride along bodies 0 .. 9
+constexpr int kDenseBodies = 19, kHiddenBodies = 10;
 constexpr int kVfStride = 452;
-constexpr int oDensePf = 0, oDenseVf = kDensePos * 900, kDenseLdsFloats = oDenseVf + kDensePos * kVfStride + 16;
+constexpr int oDensePf = 0, oDenseVf = kDensePos * 900, kDenseLdsFloats = oDenseVf + kDensePos * kVfStride + 32;
 // after the MFMAs the logits [16][256] take the place of the policy activations, the hidden units [16][64] that of the value activations
 
 struct DenseParams {
     const float* pflat; const float* vflat; int n;
-    const float* w;                                // [4 waves][25 + 1 bodies][9 steps][4 policy tiles (wave + 4 q) | 1 hidden tile (wave)][64 lanes]:
-                                                   // what a wave fetches for a body is one contiguous 11.5 KB run
+    const float* w;                                // [4 waves][19 + 1 bodies][4 policy tiles (wave + 4 q) | 1 hidden tile (wave)][3 groups][64 lanes][4 steps]:
+                                                   // what a wave fetches for a body is one contiguous 15 KB run of 16-byte loads
     const float* bp;                               // [256]: the policy's biases, 0 behind the 225th
     const float* bhid; const float* wo; float bo;  // [64], [64]
     float* value; float* probs;                    // [n], [n][225]
@@ -449,7 +451,7 @@ void pvnet_dense_kernel(DenseParams prm) {
                 *reinterpret_cast<float2*>(lds + oDenseVf + r * kVfStride + 2 * c) = v2[j];
             }
         }
-        if (threadIdx.x < kDensePos + 8) {                                              // the two pad columns of every row and the 16 floats behind the last
+        if (threadIdx.x < kDensePos + 16) {                                             // the two pad columns of every row and the 32 floats behind the last
             if (threadIdx.x < kDensePos) *reinterpret_cast<float2*>(lds + oDenseVf + threadIdx.x * kVfStride + 450) = make_float2(0.0f, 0.0f);
             else *reinterpret_cast<float2*>(lds + oDenseVf + kDensePos * kVfStride + 2 * (threadIdx.x - kDensePos)) = make_float2(0.0f, 0.0f);
         }
@@ -460,40 +462,41 @@ void pvnet_dense_kernel(DenseParams prm) {
     const char* a_vf = reinterpret_cast<const char*>(lds + oDenseVf + (lane & 15) * kVfStride + (lane >> 4));
     // Weight fetches are buffer loads: descriptor of this wave's run + (the lane's byte offset, one register) + a scalar offset that moves once per
     // body + an immediate -- no vector arithmetic inside the MFMA stream (flat loads made the compiler carry 64-bit pointers in vector registers).
-    constexpr int kBodyBytes = kDenseBody * 5 * 64 * 4, kWaveBytes = (25 + 1) * kBodyBytes;
+    constexpr int kBodyBytes = kDenseBody * 5 * 64 * 4, kWaveBytes = (kDenseBodies + 1) * kBodyBytes;
     const auto w_mine = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prm.w) + static_cast<size_t>(__builtin_amdgcn_readfirstlane(wave)) * (kWaveBytes / 4), 0, kWaveBytes, 0x00020000);
-    const int lane_bytes = lane * 4;
-    float bw[2][kDenseBody][4], bh[2][kDenseBody];
-    auto fetch = [&](float (&w4)[kDenseBody][4], float (&w1)[kDenseBody], int body, auto with_hidden) {
+    const int lane_bytes = lane * 16;
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v bw[2][kDenseBody / 4][4], bh[2][kDenseBody / 4];                   // [register set][group of four steps][tile]: a lane's B operands of four steps
+    auto fetch = [&](f32x4v (&w4)[kDenseBody / 4][4], f32x4v (&w1)[kDenseBody / 4], int body, auto with_hidden) {
 #pragma unroll
-        for (int s = 0; s < kDenseBody; ++s) {
+        for (int g = 0; g < kDenseBody / 4; ++g) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w4[s][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_mine, lane_bytes + (s * 5 + q) * 256, body * kBodyBytes, 0));
-            if (decltype(with_hidden)::value) w1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_mine, lane_bytes + (s * 5 + 4) * 256, body * kBodyBytes, 0));
+            for (int q = 0; q < 4; ++q) w4[g][q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(w_mine, lane_bytes + (q * 3 + g) * 1024, body * kBodyBytes, 0));
+            if (decltype(with_hidden)::value) w1[g] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(w_mine, lane_bytes + (4 * 3 + g) * 1024, body * kBodyBytes, 0));
         }
     };
-    auto body_mfmas = [&](const float (&w4)[kDenseBody][4], const float (&w1)[kDenseBody], int body, auto with_hidden) {
+    auto body_mfmas = [&](const f32x4v (&w4)[kDenseBody / 4][4], const f32x4v (&w1)[kDenseBody / 4], int body, auto with_hidden) {
         const char* ap = a_pf + body * kDenseBody * 16;
         const char* av = a_vf + body * kDenseBody * 16;
 #pragma unroll
         for (int s = 0; s < kDenseBody; ++s) {
             const float a = *reinterpret_cast<const float*>(ap + s * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w4[s][q], acc[q], 0, 0, 0);
-            if (decltype(with_hidden)::value) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(*reinterpret_cast<const float*>(av + s * 16), w1[s], acch, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w4[s / 4][q][s % 4], acc[q], 0, 0, 0);
+            if (decltype(with_hidden)::value) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(*reinterpret_cast<const float*>(av + s * 16), w1[s / 4][s % 4], acch, 0, 0, 0);
         }
     };
     constexpr std::integral_constant<bool, true> yes{};
     constexpr std::integral_constant<bool, false> no{};
-    // The 25 bodies are unrolled (straight-line code, ~20 KB): as a loop the two register sets are loop-carried values that the compiler
-    // copies at the loop header behind an s_waitcnt vmcnt(0) -- which exposes the fetch it was meant to hide.  The hidden layer's weights are
-    // fetched for bodies 0 .. 12 only; body 24 fetches the padding.
+    // The 19 bodies are unrolled (straight-line code): as a loop the two register sets are loop-carried values that the compiler copies at the
+    // loop header behind an s_waitcnt vmcnt(0) -- which exposes the fetch it was meant to hide.  The hidden layer's weights are fetched for
+    // bodies 0 .. 9 only; body 18 fetches the padding.
     fetch(bw[0], bh[0], 0, yes);
 #pragma unroll
-    for (int body = 0; body < 25; ++body) {
-        if (body < 12) fetch(bw[(body + 1) & 1], bh[(body + 1) & 1], body + 1, yes); else fetch(bw[(body + 1) & 1], bh[(body + 1) & 1], body + 1, no);
+    for (int body = 0; body < kDenseBodies; ++body) {
+        if (body + 1 < kHiddenBodies) fetch(bw[(body + 1) & 1], bh[(body + 1) & 1], body + 1, yes); else fetch(bw[(body + 1) & 1], bh[(body + 1) & 1], body + 1, no);
         __builtin_amdgcn_sched_barrier(0);
-        if (body < 13) body_mfmas(bw[body & 1], bh[body & 1], body, yes); else body_mfmas(bw[body & 1], bh[body & 1], body, no);
+        if (body < kHiddenBodies) body_mfmas(bw[body & 1], bh[body & 1], body, yes); else body_mfmas(bw[body & 1], bh[body & 1], body, no);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                                          // everybody is done with the activations: their place is reused
@@ -677,16 +680,16 @@ extern "C" int gmk_pvnet_set_dense(gmk_pvnet* net, const float* w_policy, const 
     if (!net || !w_policy || !b_policy || !w_hidden || !b_hidden || !w_out) { gmk::set_error("gmk_pvnet_set_dense: bad arguments"); return GMK_ERR_ARG; }
     // B operands of v_mfma_f32_16x16x4_f32 in lane order: lane l carries W[output = 16 tile + (l & 15)][k = 4 step + (l >> 4)]; per wave and body
     // the nine steps' four policy tiles and hidden tile side by side (zeros: the 16th policy tile, k >= 450 of the hidden layer, the pad body)
-    std::vector<float> wp(static_cast<size_t>(4) * 26 * kDenseBody * 5 * 64, 0.0f), dense(256 + 64 + 64, 0.0f);
+    std::vector<float> wp(static_cast<size_t>(4) * (kDenseBodies + 1) * kDenseBody * 5 * 64, 0.0f), dense(256 + 64 + 64, 0.0f);
     for (int wave = 0; wave < 4; ++wave)
         for (int step = 0; step < kPolicySteps; ++step)
             for (int q = 0; q < 5; ++q)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int k = 4 * step + (lane >> 4);
+                    const int k = 4 * step + (lane >> 4), body = step / kDenseBody, g = (step % kDenseBody) / 4;
                     float v = 0.0f;
                     if (q < 4) { const int o = 16 * (wave + 4 * q) + (lane & 15); if (o < kPix) v = w_policy[static_cast<size_t>(o) * 900 + k]; }
                     else if (k < 450) v = w_hidden[static_cast<size_t>(16 * wave + (lane & 15)) * 450 + k];
-                    wp[((static_cast<size_t>(wave) * 26 * kDenseBody + step) * 5 + q) * 64 + lane] = v;
+                    wp[((((static_cast<size_t>(wave) * (kDenseBodies + 1) + body) * 5 + q) * 3 + g) * 64 + lane) * 4 + (step & 3)] = v;
                 }
     std::memcpy(&dense[0], b_policy, kPix * 4); std::memcpy(&dense[256], b_hidden, 64 * 4); std::memcpy(&dense[320], w_out, 64 * 4);
     if (!net->d_wp) {
