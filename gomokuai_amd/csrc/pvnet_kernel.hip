@@ -66,17 +66,18 @@ __host__ __device__ inline void step_chunk_tap(int step, int& chunk, int& tap) {
 // `in` points at the layer's input activations in LDS, base[t] is this lane's byte offset for tile t:
 // ((lane >> 5) * kPad + padded_index(pixel) - 18) * 4, so that tap (ky, kx) of channel c adds (c * kPad + ky * 17 + kx) * 4.
 //
-// What shapes this loop (tools/mfma_issue_probe.hip, one wavefront per SIMD): back-to-back v_mfma_f32_32x32x2_f32 issue every 64.1 clocks, an LDS
-// read or a global load issued between them costs nothing, but EVERY VECTOR-ALU INSTRUCTION between them costs 20-30 clocks (the f32 matrix
-// instruction runs at the vector FMA rate: it has no shadow for vector work).  So the loop is written to contain none: the nine taps and the CP
-// channel pairs of a chunk are unrolled, which makes every LDS address `a register that changes once per chunk + an immediate` and every weight
-// address `a scalar base + the lane + an immediate`; the only vector instructions left per chunk are the NB address increments.
+// What shapes this loop (tools/mfma_issue_probe.hip, profiles/r04_k9_mfma_issue_probe.txt; one wavefront per SIMD): back-to-back
+// v_mfma_f32_32x32x2_f32 issue every 64.1 clocks and NOTHING but another MFMA overlaps them for free: an MFMA whose B operand an LDS read wrote
+// costs ~2 clocks more, a global load ~20 (28 for 16 bytes per lane), EVERY VECTOR-ALU INSTRUCTION 20-30 (the f32 matrix instruction runs at the
+// vector FMA rate: it has no shadow for vector work).  So the loop contains no vector instruction -- the nine taps and the CP channel pairs of a
+// chunk are unrolled, which makes every LDS address `a register that changes once per chunk + an immediate` and every weight address `a scalar
+// base + the lane + an immediate`; the only vector instructions left per chunk are the NB address increments -- and as few loads as it can.
 //   * Operands are fetched AHEAD of the MFMAs that use them, and the scheduling barriers keep the fetches where they are written (left alone, the
 //     compiler sinks every load to just before its use, and each MFMA then waits for LDS or L2 behind it): a step's CP weights two steps ahead, one
-//     global load per k-pair block, into one of three rotating register sets (three steps per rotation: no register moves); the NB activation
-//     reads of a k-pair AHEAD k-pairs ahead (one everywhere: two or three for the layers whose k-pairs are two to four MFMAs measured the
-//     same), in one burst behind the third MFMA of the current k-pair.  The fetches past the layer's last k-pair read
-//     two steps of padding behind the weights and the LDS behind the activations (both there, both unused).
+//     16-byte global load per four k-pairs, into one of three rotating register sets (three steps per rotation: no register moves); the NB
+//     activation reads of a k-pair AHEAD k-pairs ahead (one everywhere: two or three for the layers whose k-pairs are two to four MFMAs measured
+//     the same), in one burst behind the third MFMA of the current k-pair.  The fetches past the layer's last k-pair read two steps of padding
+//     behind the weights and the LDS behind the activations (both there, both unused).
 //   * CORNER: 225 pixels are seven tiles and ONE pixel, the corner (14, 14).  A 32 x 32 MFMA for it would compute 31 columns nobody reads (64
 //     clocks) and a v_fma costs 20-30 here, so it rides on v_mfma_f32_4x4x1_16B_f32 (8 clocks): A = the A operand the lane holds anyway
 //     (W[channel l & 31][k = 2 kp + (l >> 5)]), B = the corner's activation for that k (one more LDS read per k-pair, base[NB - 1]: the same address

@@ -12,10 +12,10 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int REPS = 2048;
 template <int V>
-__global__ __launch_bounds__(256) void probe(const float* w, float* out, unsigned long long* clk) {
+__global__ __launch_bounds__(512) void probe(const float* w, float* out, unsigned long long* clk) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    for (int i = threadIdx.x; i < 36000; i += blockDim.x) lds[i] = 0.001f * (i & 127);
     __syncthreads();
     f32x16 acc[7] = {};
     float b[2][7];
@@ -59,14 +59,14 @@ __global__ __launch_bounds__(256) void probe(const float* w, float* out, unsigne
     asm volatile("s_waitcnt vmcnt(0)");
     float s = sinkv + sinkf;
     for (int t = 0; t < 7; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[(blockIdx.x * 256 + threadIdx.x) & 65535] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
 template <int V>
 __global__ __launch_bounds__(256) void probe2(const float* w, float* out, unsigned long long* clk) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    for (int i = threadIdx.x; i < 36000; i += blockDim.x) lds[i] = 0.001f * (i & 127);
     __syncthreads();
     f32x16 acc[8] = {};
     const float a = w[lane];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void probe2(const float* w, float* out, unsign
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = sink;
     for (int t = 0; t < 8; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[(blockIdx.x * 256 + threadIdx.x) & 65535] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
 // 11: as 7 (the seven reads of a round in one burst behind its third MFMA), but for the round AFTER the next one (three operand sets): does the cost of
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void probe2(const float* w, float* out, unsign
 __global__ __launch_bounds__(256) void probe3(const float* w, float* out, unsigned long long* clk) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    for (int i = threadIdx.x; i < 36000; i += blockDim.x) lds[i] = 0.001f * (i & 127);
     __syncthreads();
     f32x16 acc[7] = {};
     float b[3][7];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void probe3(const float* w, float* out, unsign
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f;
     for (int t = 0; t < 7; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[(blockIdx.x * 256 + threadIdx.x) & 65535] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
 // 12: two rounds' worth per scheduling block: 14 reads in one burst behind the third MFMA, 14 MFMAs (7 accumulators, two k each): is variant 7's
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void probe3(const float* w, float* out, unsign
 __global__ __launch_bounds__(256) void probe4(const float* w, float* out, unsigned long long* clk) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    for (int i = threadIdx.x; i < 36000; i += blockDim.x) lds[i] = 0.001f * (i & 127);
     __syncthreads();
     f32x16 acc[7] = {};
     float b[2][14];
@@ -175,17 +175,17 @@ __global__ __launch_bounds__(256) void probe4(const float* w, float* out, unsign
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f;
     for (int t = 0; t < 7; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[(blockIdx.x * 256 + threadIdx.x) & 65535] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
 // 17: as 13 with a global_load_dwordx4
 // 13 / 14: as 7 (NT MFMAs + NT reads per round, NT = 7 / 3 / 3) + one global_load_dword per round with NO address arithmetic (scalar base + lane
 // offset + immediate), nobody waits for it: what the weight fetch itself costs; 16: NT = 3 without the load
 template <int NT, int LOAD>
-__global__ __launch_bounds__(256) void probe5(const float* w, float* out, unsigned long long* clk) {
+__global__ __launch_bounds__(512) void probe5(const float* w, float* out, unsigned long long* clk) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    for (int i = threadIdx.x; i < 36000; i += blockDim.x) lds[i] = 0.001f * (i & 127);
     __syncthreads();
     f32x16 acc[NT] = {};
     float b[2][NT];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void probe5(const float* w, float* out, unsign
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = sink + sink4.x + sink4.w;
     for (int t = 0; t < NT; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[(blockIdx.x * 256 + threadIdx.x) & 65535] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
 // 18: eight MFMAs per round fed by FOUR ds_read2st64_b32 (two dwords 2 560 bytes apart per instruction) in one burst behind the third MFMA:
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void probe5(const float* w, float* out, unsign
 __global__ __launch_bounds__(256) void probe6(const float* w, float* out, unsigned long long* clk) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 36000; i += 256) lds[i] = 0.001f * (i & 127);
+    for (int i = threadIdx.x; i < 36000; i += blockDim.x) lds[i] = 0.001f * (i & 127);
     __syncthreads();
     f32x16 acc[8] = {};
     float2 b[2][4];
@@ -258,21 +258,22 @@ __global__ __launch_bounds__(256) void probe6(const float* w, float* out, unsign
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.0f;
     for (int t = 0; t < 8; ++t) for (int i = 0; i < 16; ++i) s += acc[t][i];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[(blockIdx.x * 256 + threadIdx.x) & 65535] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clk = t1 - t0;
 }
 template <class K>
-void run(K kernel, int variant, double per_rep, const float* w, float* out, unsigned long long* clk) {
+void run(K kernel, int variant, double per_rep, const float* w, float* out, unsigned long long* clk, int threads = 256) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    kernel<<<256, 256, 150 * 1024>>>(w, out, clk);
+    kernel<<<256, threads, 150 * 1024>>>(w, out, clk);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 5; ++i) kernel<<<256, 256, 150 * 1024>>>(w, out, clk);
+    for (int i = 0; i < 5; ++i) kernel<<<256, threads, 150 * 1024>>>(w, out, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     unsigned long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
     const double n = per_rep * REPS;
+    if (threads > 256) std::printf("(two wavefronts per SIMD: halve the ticks for the SIMD's cost per MFMA) ");
     std::printf("variant %d: %.2f s_memtime ticks per MFMA, %.2f ns per MFMA wall (whole kernel) -> the clock ran at %.2f GHz; kernel %.3f ms\n", variant, c / n, ms * 1e6 / n, (c / n) / (ms * 1e6 / n), ms);
 }
 int main() {
@@ -285,6 +286,7 @@ int main() {
     run(probe4, 12, 7, w, out, clk);
     run(probe5<7, 1>, 13, 7, w, out, clk); run(probe5<3, 1>, 14, 3, w, out, clk); run(probe5<3, 0>, 16, 3, w, out, clk); run(probe5<7, 4>, 17, 7, w, out, clk);
     run(probe6, 18, 8, w, out, clk);
+    run(probe5<7, 1>, 13, 7, w, out, clk, 512); run(probe5<3, 1>, 14, 3, w, out, clk, 512); run(probe5<7, 4>, 17, 7, w, out, clk, 512); run(probe<9>, 9, 7, w, out, clk, 512);
     run(probe2<4>, 4, 8, w, out, clk); run(probe2<5>, 5, 8, w, out, clk);
     return 0;
 }
