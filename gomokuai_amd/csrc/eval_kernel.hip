@@ -62,6 +62,10 @@ constexpr int kLineWords = 96;                   // line words, 2 bits per cell 
                                                  // (a stone's shift is then 2x for its row and diagonal, 2y for its column and anti-diagonal: two shifted
                                                  // codes per stone instead of four; a reader shifts a diagonal's word down to its first cell)
 constexpr int kColBase = 20, kDiagBase = 36, kAntiBase = 65;
+#ifndef GMK_K1_TOTALS_COPIES
+#define GMK_K1_TOTALS_COPIES 8
+#endif
+constexpr int kTotalsCopies = GMK_K1_TOTALS_COPIES;   // of the per-type totals, in the queue's last words (phase 0 says why); 8 x copies <= 64
 constexpr int kMiscWords = 48;                   // [0] stones black | white << 16, [1] winner bits, [2] error, [3] compound queue count, [4..14] totals,
                                                  // [19..33] the rows (black | white << 16) between three zero rows on either side ([16..18], [34..36])
 constexpr int kBoardWords = kZeroWords + kLineWords + kQueueCap + kMiscWords;
@@ -122,10 +126,10 @@ __device__ __forceinline__ void wave_phase_fence() {
 // record words (pattern_tables.h).  cell_at = cell of the symbol the transition consumed.
 // back_step = -stride: the cells of a match lie behind the symbol that ended it, one multiply-add each.
 __device__ __forceinline__ void deposit_match(uint32_t w0, uint32_t w1, int cell_at, int dir, int back_step,
-                                              uint32_t* s_scores, uint32_t* s_cnt, uint32_t* s_misc) {
+                                              uint32_t* s_scores, uint32_t* s_cnt, uint32_t* s_misc, uint32_t* totals /* this lane's copy of the eight per-type totals */) {
     const int type = w0 & 15, fav = (w0 >> 4) & 1;
     if (type == 8) { atomicOr(&s_misc[1], fav ? 1u : 2u); return; }                 // Five: winner only (Pattern.cpp:140-145)
-    atomicAdd(&s_misc[4 + type], fav ? 0x10000u : 1u);                              // totals row (Pattern.cpp:147, 390-393)
+    atomicAdd(&totals[type], fav ? 0x10000u : 1u);                                  // totals row (Pattern.cpp:147, 390-393)
     const int endcell = cell_at + static_cast<int>((w0 >> 27) & 1u) * back_step;
     const uint32_t score = dir >= 2 ? (w1 >> 16) : (w1 & 0xFFFFu);                  // int(1.2 * score) on diagonals (Pattern.cpp:151-152)
     // Group(favour, favour) is the owner's view, Group(favour, -favour) the opponent's (Pattern.h:159-161): '_' adds the score to both,
@@ -334,6 +338,11 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
     uint32_t* s_lines = s_scores + kZeroWords;
     uint32_t* s_queue = s_lines + kLineWords;
     uint32_t* s_misc = s_queue + kQueueCap;
+#ifndef GMK_K1_TOTALS_HOT
+    uint32_t* const my_totals = s_queue + kQueueCap - 8 * kTotalsCopies + (lane0 & (kTotalsCopies - 1)) * 8;  // this lane's copy of the per-type totals (phase 0 says why)
+#else
+    uint32_t* const my_totals = s_misc + 4;
+#endif
 
     // (no barrier here: the tables are on their way while every wavefront runs phase 0 of its first board, which needs none of them; the one
     // barrier of the kernel stands in front of that board's phase 1)
@@ -413,6 +422,13 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
             s_lines[lane] = line_init_lo;                       // (the all-blank line words wait in two registers, not in LDS: no read before the write)
             if (lane < kLineWords - 64) s_lines[64 + lane] = line_init_hi;
             if (lane < kMiscWords) s_misc[lane] = 0;
+#ifndef GMK_K1_TOTALS_HOT
+            // Per-type totals: one atomic per match on eight addresses is 64 lanes on eight LDS words -- up to ~25 of them on the same one, served
+            // one after the other (phase 2 is 41 % of the LDS pipe's cycles, profiles/r04_k1_lds_phases.txt).  kTotalsCopies copies, a lane adds to copy
+            // lane & (kTotalsCopies - 1); they live in the last words of the transition queue (a board that is not flagged queues < kQueueCap - 64 entries) and are
+            // summed behind phase 2.
+            if (lane < 8 * kTotalsCopies) s_queue[kQueueCap - 8 * kTotalsCopies + lane] = 0;
+#endif
             const uint32_t my_row = take_row(board);
             wave_phase_fence();
             {
@@ -546,11 +562,21 @@ void eval_positions_kernel(const uint16_t* __restrict__ planes, int n_boards, in
                     const int pos = src_step - 1 - (second ? seg_a : 0);
                     const int dir = (job >> 5) & 3, stride = (job >> 7) & 31;
                     const int cell_at = static_cast<int>((job >> 12) & 255u) + pos * stride;
-                    deposit_match(rec_now.x, rec_now.y, cell_at, dir, -stride, s_scores, s_cnt, s_misc);
-                    if (rec_now.z) deposit_match(rec_now.z, rec_now.w, cell_at, dir, -stride, s_scores, s_cnt, s_misc);
+                    deposit_match(rec_now.x, rec_now.y, cell_at, dir, -stride, s_scores, s_cnt, s_misc, my_totals);
+                    if (rec_now.z) deposit_match(rec_now.z, rec_now.w, cell_at, dir, -stride, s_scores, s_cnt, s_misc, my_totals);
                 }
             }
             wave_phase_fence();
+#ifndef GMK_K1_TOTALS_HOT
+            // the copies of the per-type totals (see my_totals) become the totals row; their place is the queue's again from phase 3b on
+            if (lane < 8) {
+                const uint32_t* t = s_queue + kQueueCap - 8 * kTotalsCopies + lane;
+                uint32_t sum = 0;
+#pragma unroll
+                for (int c = 0; c < kTotalsCopies; ++c) sum += t[8 * c];
+                s_misc[4 + lane] = sum;
+            }
+#endif
             GMK_STAMP(3);
 
             // ---- phase 3: one lane per cell: compound candidates (the area bonus is in the block since phase 0) ----
