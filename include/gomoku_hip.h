@@ -386,7 +386,8 @@ int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_p
  * the inputs of the network's dense layers (tf.layers.flatten of the NHWC tensors).
  * gmk_pvnet_set_dense: the three dense layers behind them (network/model_tf.py:53-54 policy_logits / policy_output, :64-66 value_hidden /
  *   value_logits / value_output), host arrays in [out][in] order over the (pixel, channel) flattening: w_policy [225][900], b_policy [225],
- *   w_hidden [64][450], b_hidden [64], w_out [64], b_out; packed once, may be called again with new weights.
+ *   w_hidden [64][450], b_hidden [64], w_out [64], b_out; packed once, may be called again with new weights (a blocking copy: not while a
+ *   gmk_pvnet_evaluate of this handle is in flight on another stream).
  * gmk_pvnet_evaluate: the whole PolicyValueNetwork.eval_state forward (network/model_tf.py:136-145) for a batch, two kernels on `stream`:
  *   d_states float32 [n][6][225] -> d_value float32 [n] = tanh(...), d_probs float32 [n][225] = softmax(...).  The head activations between
  *   the kernels live in the handle (grown on demand).  GMK_ERR_STATE before gmk_pvnet_set_dense. */
