@@ -390,7 +390,8 @@ int gmk_az_root_stats(gmk_az* a, uint32_t* h_visits, float* h_values, float* h_p
  *   gmk_pvnet_evaluate of this handle is in flight on another stream).
  * gmk_pvnet_evaluate: the whole PolicyValueNetwork.eval_state forward (network/model_tf.py:136-145) for a batch, two kernels on `stream`:
  *   d_states float32 [n][6][225] -> d_value float32 [n] = tanh(...), d_probs float32 [n][225] = softmax(...).  The head activations between
- *   the kernels live in the handle (grown on demand).  GMK_ERR_STATE before gmk_pvnet_set_dense. */
+ *   the kernels live in the handle (grown on demand, which synchronises `stream`: let a batch size's first call happen outside a stream
+ *   capture; one handle serves one stream at a time).  GMK_ERR_STATE before gmk_pvnet_set_dense. */
 typedef struct gmk_pvnet gmk_pvnet;
 int gmk_pvnet_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                      const float* w_policy, const float* b_policy, const float* w_value, const float* b_value, gmk_pvnet** out);
