@@ -446,7 +446,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
         def play():                                              # (gigabytes of records, activations and gather buffers: local work that can fail on one rank alone)
             t0 = time.perf_counter()
             rec = selfplay.play_network_games(args.az_selfplay_games, fused, args.az_selfplay_playouts, first_game_id=rank * args.az_selfplay_games, opening_plies=2,
-                                              slots=max(1, args.az_selfplay_games // 4), reuse_subtree=True, root_noise=(0.05, 0.25))
+                                              slots=max(1, args.az_selfplay_games // 2), reuse_subtree=True, root_noise=(0.05, 0.25))
             torch.cuda.synchronize()
             return time.perf_counter() - t0, int(rec.lens.sum()) - 2 * args.az_selfplay_games
         pipe_s, pipe_moves = local_stage("az self-play", play, torch, dev, distributed)
@@ -457,7 +457,7 @@ def bench_az(args, G, torch, dev, rank, world, distributed):
         pipeline = {"metric": "self-play games/s", "value": args.az_selfplay_games * world / pipe_s, "unit": "games/s", "playouts_per_s": pipe_moves * args.az_selfplay_playouts / pipe_s,
                     "seconds": pipe_s, "moves": pipe_moves,
                     "config": {"workload": "network-guided self-play (K7 + K9), %d games per GPU through %d slots, %d playouts per move, kept subtrees and root noise (0.05, 0.25), 2-ply openings; "
-                                           "loop resident on the device (gmk_az_set_slots / gmk_az_advance), leaf batch = the games still played" % (args.az_selfplay_games, max(1, args.az_selfplay_games // 4), args.az_selfplay_playouts)}}
+                                           "loop resident on the device (gmk_az_set_slots / gmk_az_advance), leaf batch = the games still played" % (args.az_selfplay_games, max(1, args.az_selfplay_games // 2), args.az_selfplay_playouts)}}
     conv_flop = 2.0 * 225 * (54 * 32 + 288 * 64 + 576 * 128 + 128 * 6) * n
     return {"metric": "network-guided-playouts/s", "value": n * world * P / (ms * 1e-3), "unit": "playouts/s", "ms_per_step": ms / P,
             "network_ms_per_step": net_ms,
@@ -658,7 +658,7 @@ def parse_args(argv=None):
     ap.add_argument("--evalstate-games", type=int, default=2304, help="games per GPU for the incremental-evaluator measurement (K2); 0 = skip")
     ap.add_argument("--az-games", type=int, default=4096, help="games per GPU for the network-guided search measurement (K7); 0 = skip")
     ap.add_argument("--az-playouts", type=int, default=60)
-    ap.add_argument("--az-selfplay-games", type=int, default=4096, help="whole games per GPU of the network-guided searcher against itself (through a quarter as many slots); 0 = skip")
+    ap.add_argument("--az-selfplay-games", type=int, default=8192, help="whole games per GPU of the network-guided searcher against itself (through half as many slots: tools/az_selfplay_slots.py); 0 = skip")
     ap.add_argument("--az-selfplay-playouts", type=int, default=32)
     ap.add_argument("--trad-games", type=int, default=2048, help="games per GPU for the pattern-guided search measurement (K6); 0 = skip")
     ap.add_argument("--trad-playouts", type=int, default=1000)
