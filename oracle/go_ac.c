@@ -298,8 +298,21 @@ int go_ac_build_default(go_ac *ac) {
 }
 
 const go_ac *go_default_ac(void) {
+    /* built once, also when several host threads ask at the same time (tools/stress_parity.py, bench.py's all-cores baseline): the pointer is
+     * published only behind the finished automaton */
     static go_ac *ac = NULL;
-    if (!ac) { ac = (go_ac *)malloc(sizeof(go_ac)); go_ac_build_default(ac); }
+    static int state = 0;                        /* 0 nobody has started, 1 being built, 2 ready */
+    if (__atomic_load_n(&state, __ATOMIC_ACQUIRE) != 2) {
+        int expected = 0;
+        if (__atomic_compare_exchange_n(&state, &expected, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+            go_ac *fresh = (go_ac *)malloc(sizeof(go_ac));
+            go_ac_build_default(fresh);
+            ac = fresh;
+            __atomic_store_n(&state, 2, __ATOMIC_RELEASE);
+        } else {
+            while (__atomic_load_n(&state, __ATOMIC_ACQUIRE) != 2) { }
+        }
+    }
     return ac;
 }
 

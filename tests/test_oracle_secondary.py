@@ -2,6 +2,7 @@
 sources (survey-session probe).  They are not the reference's own fixtures, so they do not by
 themselves pin parity, but every one of them is reproduced bit for bit."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -114,3 +115,29 @@ def test_philox_kat(oracle):
     assert O.philox([0xffffffff] * 4, [0xffffffff] * 2).tolist() == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]).tolist() == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_oracle_tables_are_built_once_under_threads():
+    """The oracle builds its automaton on first use; tools/stress_parity.py and bench.py's all-cores baseline call it from many host threads, and a
+    fresh process whose FIRST calls come from eight threads at once must get what a serial call gets (the lazy singleton used to publish its
+    pointer before the tables behind it were finished: the first boards of some threads were evaluated on a half-built automaton)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, sys
+        from concurrent.futures import ThreadPoolExecutor
+        sys.path.insert(0, %r)
+        from oracle import oracle as O
+        rng = np.random.default_rng(1)
+        n = 64
+        moves = np.zeros((n, 225), np.uint8); lens = np.full(n, 30, np.int32)
+        for g in range(n):
+            moves[g, :30] = rng.permutation(225)[:30]
+        with ThreadPoolExecutor(8) as pool:
+            parts = list(pool.map(lambda i: O.replay_batch(moves[8 * i:8 * i + 8], lens[8 * i:8 * i + 8]), range(8)))
+        threaded = [np.concatenate([p[k] for p in parts]) for k in range(4)]
+        serial = O.replay_batch(moves, lens)
+        print(all((a == b).all() for a, b in zip(threaded, serial)))
+        """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        assert r.stdout.strip() == "True", (r.stdout[-300:], r.stderr[-500:])

@@ -10,6 +10,8 @@ from oracle import oracle as O
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n, cores = 65536, min(len(os.sched_getaffinity(0)), 16)
 O.lib()
+_m, _l, _ = G.synth_boards(2, 0)
+O.replay_batch(_m, _l)            # the oracle builds its tables on first use, and not under a lock: once, before the threads start
 bad = 0
 t0 = time.time()
 for r in range(rounds):
