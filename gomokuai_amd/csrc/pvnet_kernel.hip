@@ -367,8 +367,10 @@ void pvnet_trunk_kernel(PvParams prm) {
 #pragma unroll
             for (int j = 0; j < kHeadRows; ++j) {
                 float v = ((x[0] * whc[j].x + x[1] * whc[j].y) + x[2] * whc[j].z) + x[3] * whc[j].w;
-#pragma unroll
-                for (int m = 16; m >= 4; m >>= 1) v += __shfl_xor(v, m, 64);
+                // the eight blocks of a half = lanes l, l + 4, .. l + 28: two row rotations (DPP) add the four of a row of 16, one exchange the two rows
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));      // row_ror:8
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));      // row_ror:4
+                v += __shfl_xor(v, 16, 64);
                 if (lane == 0) part[(wave * 8 + j) * 256 + kPix - 1] = v;
             }
         }
